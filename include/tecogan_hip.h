@@ -1,0 +1,168 @@
+/*
+ * tecogan_hip.h -- C ABI of libtecogan_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (thunil/TecoGAN) has no native ABI: its operator surface is the
+ * Python layer lib/ops.py + the TF1 ops it calls.  Each entry point below names
+ * the reference interface it replaces (file:line in /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - return 0 (TG_OK) or a negative TG_E* code; never throw, never allocate,
+ *     never synchronise; enqueue-only on `stream` (a hipStream_t passed as
+ *     void*), hence hipGraph-capturable;
+ *   - every pointer is a caller-owned DEVICE pointer, NHWC-contiguous, 16-byte
+ *     aligned; dtype codes: TG_F32 = 0, TG_BF16 = 1;
+ *   - re-entrant, no mutable globals except the thread-local last-error string.
+ */
+#ifndef TECOGAN_HIP_H
+#define TECOGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_OK        0
+#define TG_EINVAL   -1   /* bad argument / unsupported shape */
+#define TG_ELAUNCH  -2   /* hipLaunch error (see tg_last_error_string) */
+
+#define TG_F32   0
+#define TG_BF16  1
+
+/* activation codes for conv epilogues / pointwise */
+#define TG_ACT_NONE    0
+#define TG_ACT_RELU    1   /* tf.nn.relu                      lib/frvsr.py:53,63,74,77 */
+#define TG_ACT_LRELU   2   /* lrelu(x, alpha)                 lib/ops.py:84-85        */
+#define TG_ACT_TANH    3   /* tanh(x) * alpha                 lib/frvsr.py:39         */
+#define TG_ACT_SIGMOID 4   /* tf.nn.sigmoid                   lib/Teco.py:72          */
+
+int         tg_version(void);
+const char* tg_last_error_string(void);
+
+/* ------------------------------------------------------------------------ *
+ * Convolution engine (implicit GEMM on MFMA).
+ * Replaces slim.conv2d / slim.conv2d_transpose as called by
+ *   conv2       lib/ops.py:47-56   (k3 s1, k4 s2; SAME)
+ *   conv2_tran  lib/ops.py:35-44   (k3 s2 SAME)
+ *   denselayer  lib/ops.py:96-103  (as a 1x1 conv)
+ * and their input-gradients.
+ *
+ * mode 0 (gather):      out[n,oy,ox,:] = sum_{kh,kw} in[n, oy*s-pad_t+kh, ox*s-pad_l+kw, :] . W[kh,kw]
+ * mode 1 (transposed):  out[n,oy,ox,:] = sum_{kh,kw : (oy+pad_t-kh)%s==0 ...}
+ *                                         in[n,(oy+pad_t-kh)/s,(ox+pad_l-kw)/s,:] . W[kh,kw]
+ *   conv fwd            = gather     with W^T copy  (weights_t)
+ *   conv bwd_data       = transposed with the HWIO weights as stored by TF
+ *   conv_transpose fwd  = transposed with the [kh,kw,Cout,Cin] weights as stored by TF, pad 0
+ *   conv_transpose bwd  = gather     with W^T copy, pad 0
+ * The weight operand is always laid out [KH*KW][Cout][Cin] with Cin (the
+ * reduction channel) contiguous; tg_pack_weights produces the transposed copy.
+ *
+ * Epilogue, in this order:  v = acc + bias[co];  v = act(v);  v += res;
+ *                           v *= act'(aux)   (mask_act: RELU -> aux>0, LRELU -> aux>0 ? 1 : mask_alpha)
+ * ------------------------------------------------------------------------ */
+typedef struct tg_conv_desc {
+  int32_t N, Hin, Win, Cin;        /* the tensor that is read                      */
+  int32_t Hout, Wout, Cout;        /* the tensor that is written                   */
+  int32_t KH, KW, stride, pad_t, pad_l;
+  int32_t mode;                    /* 0 gather, 1 transposed                        */
+  int32_t in_dtype, out_dtype;     /* weights share in_dtype; res/aux share out_dtype */
+  int32_t act;  float act_alpha;
+  int32_t mask_act; float mask_alpha;
+} tg_conv_desc;
+
+int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*[KH*KW][Cout][Cin]*/,
+                    const float* bias /*nullable*/, const void* res /*nullable*/,
+                    const void* aux /*nullable*/, void* out, void* stream);
+
+/* Weight gradient of the gather-form convolution described by `d`
+ * (X = the tensor that is gathered, [N,Hin,Win,Cin]; Y = per-output-pixel tensor
+ * [N,Hout,Wout,Cout]):   dW[tap][cx][cy] += sum_m X[m@tap][cx] * Y[m][cy]   (fp32 atomics)
+ *                        dbias[cy]      += sum_m Y[m][cy]                  (if dbias != NULL)
+ * conv:            X = layer input, Y = dOut  -> dW is HWIO            (lib/ops.py:47-56)
+ * conv_transpose:  X = dOut,        Y = layer input -> dW is [kh,kw,Cout,Cin] (lib/ops.py:35-44),
+ *                  dbias must then be reduced over X (use tg_colsum).
+ * x_dtype/y_dtype: TG_F32 / TG_BF16; accumulation and dW are always fp32. */
+int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, const void* y, int y_dtype,
+                  float* dw, float* dbias /*nullable*/, void* stream);
+
+/* out[c] += sum over rows of x[rows][C]  (bias gradient helper) */
+int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream);
+
+/* Weight re-layout: dst[tap][b][a] = (dst_dtype) src[tap][a][b]  (transpose=1) or a dtype-converting
+ * copy (transpose=0), for `count` tensors described by the device table `tab`
+ * (4 x int64 per tensor: src offset, dst offset (in elements), taps, then A<<32|B). */
+int tg_pack_weights(const float* src_base, void* dst_base, int dst_dtype, const int64_t* tab,
+                    int count, int transpose, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Fused recurrent input builder:
+ *   tf.contrib.image.dense_image_warp(pre_HR, upscale_four(4*flow_lr))    lib/Teco.py:113,140 main.py:212-215
+ *   -> deprocess (scale,shift)                                            lib/Teco.py:143
+ *   -> space-to-depth(4)                                                  lib/Teco.py:145-148 main.py:201
+ *   -> concat(LR frame, .)                                                lib/Teco.py:150     main.py:202
+ * out[b,i,j,0:3] = lr ; out[b,i,j,3+(dy*4+dx)*3+c] = warp(pre)[b,4i+dy,4j+dx,c]*scale+shift ;
+ * out[...,51:Cpad] = 0.   pre == NULL writes zeros (first frame, lib/Teco.py:127-129).
+ * flow_lr is [B,hf,wf,2] with hf<=h, wf<=w: rows/cols beyond are SYMMETRIC-mirrored (main.py:188-190,212).
+ * ------------------------------------------------------------------------ */
+int tg_warp_s2d_forward(const float* pre /*[B,4h,4w,3] nullable*/, const float* flow_lr /*nullable iff pre NULL*/,
+                        const float* lr /*[B,h,w,3]*/, void* out /*[B,h,w,Cpad]*/, int out_dtype,
+                        int B, int h, int w, int hf, int wf, int Cpad, float scale, float shift,
+                        float* warped /*[B,4h,4w,3] nullable: also store the warped frame*/, void* stream);
+
+/* Backward of the above.  d_pre += scatter (atomics; caller zero-fills or pre-loads),
+ * d_flow_lr += flow gradient (through alpha and upscale_four(4*.)), hf==h && wf==w required. */
+int tg_warp_s2d_backward(const void* d_out /*[B,h,w,Cpad]*/, int dtype, const float* pre, const float* flow_lr,
+                         float* d_pre, float* d_flow_lr /*nullable*/, int B, int h, int w, int Cpad,
+                         float scale, void* stream);
+
+/* Plain dense_image_warp (lib/Teco.py:120,224,254): out = warp(img[B,H,W,C], flow[B,H,W,2]). */
+int tg_warp_forward(const float* img, const float* flow, float* out, int B, int H, int W, int C, void* stream);
+int tg_warp_backward(const float* d_out, const float* img, const float* flow, float* d_img /*+= atomics, nullable*/,
+                     float* d_flow /*=, nullable*/, int B, int H, int W, int C, void* stream);
+
+/* upscale_four (lib/ops.py:126-163) == legacy bilinear x4 (lib/Teco.py:244); out = gain*up4(in). */
+int tg_upscale4_forward(const float* in, float* out, int B, int h, int w, int C, float gain, void* stream);
+int tg_upscale4_backward(const float* d_out, float* d_in, int B, int h, int w, int C, float gain, void* stream);
+
+/* slim.max_pool2d 2x2 s2 VALID (lib/ops.py:92-93).  bwd routes to the first max in scan order. */
+int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream);
+int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W, int C,
+                         void* stream);
+
+/* tf.image.resize_images x2, legacy bilinear (lib/frvsr.py:21-22). */
+int tg_upsample2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream);
+int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, int N, int H, int W, int C, void* stream);
+
+/* out = (conv_out + bicubic_four(lr)) * 2 - 1   (lib/frvsr.py:81-87, lib/ops.py:166-212).
+ * lr is read from the first 3 channels of the generator input buffer [B,h,w,Cpad]. */
+int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void* gen_in, int in_dtype, int Cpad,
+                              float* out, int B, int h, int w, void* stream);
+
+/* Pointwise activation gradient: d_in = d_out * act'(y) with y the activation OUTPUT
+ * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask). */
+int tg_act_backward(const void* d_out, const void* y, void* d_in, int dtype, int64_t n, int act, float alpha,
+                    void* stream);
+
+/* slim.batch_norm(train, scale=False, eps) + LeakyReLU (lib/ops.py:88-90, lib/Teco.py:38-39).
+ * stats: [2][C] fp32 (mean, biased var) written by forward, read by backward. */
+int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t rows, int C, const float* beta, float eps,
+                        float alpha, float* stats, float* moving /*[2][C] nullable, decay .9*/, void* stream);
+int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_y, void* d_x, int dtype, int64_t rows, int C,
+                         const float* stats, float eps, float alpha, float* d_beta /*+=*/,
+                         float* ws /*[2][C] scratch*/, void* stream);
+
+/* tf.train.AdamOptimizer step over a flat fp32 buffer (lib/Teco.py:425,439-440), TF flavour:
+ * p -= lr_t * m / (sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) read from `hyper` = device
+ * {lr_t, beta1, beta2, eps, gate}; gate==0 skips the update (the tf.cond D-gate, lib/Teco.py:493-494). */
+int tg_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float grad_scale,
+               void* stream);
+
+/* Loss reductions (lib/Teco.py:296,322,331,347-352,367): out[0] += scale * sum(...) */
+int tg_sum_sq_diff(const void* a, const void* b, int dtype, int64_t n, float scale, float* out, void* stream);
+int tg_sum_abs_diff(const void* a, const void* b, int dtype, int64_t n, float scale, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TECOGAN_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libtecogan_hip.so (the C ABI declared in include/tecogan_hip.h).
+
+The library is the product: if it is missing, or a call fails, this module raises --
+there is no CPU or eager fallback anywhere in `tecogan_amd`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtecogan_hip.so")
+
+TG_F32, TG_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+                ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("mode", C.c_int32),
+                ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
+                ("act", C.c_int32), ("act_alpha", C.c_float),
+                ("mask_act", C.c_int32), ("mask_alpha", C.c_float)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_D = C.POINTER(ConvDesc)
+
+# name -> argtypes; every function returns int (0 = ok)
+SIGNATURES = {
+    "tg_conv_forward": [_D, _P, _P, _P, _P, _P, _P, _P],
+    "tg_conv_wgrad": [_D, _P, _I, _P, _I, _P, _P, _P],
+    "tg_colsum": [_P, _I, _L, _I, _P, _P],
+    "tg_pack_weights": [_P, _P, _I, _P, _I, _I, _P],
+    "tg_warp_s2d_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
+    "tg_warp_s2d_backward": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "tg_warp_forward": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "tg_warp_backward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tg_upscale4_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "tg_upscale4_backward": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "tg_maxpool2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tg_maxpool2_backward": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "tg_upsample2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tg_upsample2_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tg_bicubic_add_preprocess": [_P, _P, _I, _I, _P, _I, _I, _I, _P],
+    "tg_act_backward": [_P, _P, _P, _I, _L, _I, _F, _P],
+    "tg_bn_lrelu_forward": [_P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P],
+    "tg_bn_lrelu_backward": [_P, _P, _P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P],
+    "tg_adam_tf": [_P, _P, _P, _P, _L, _P, _F, _P],
+    "tg_sum_sq_diff": [_P, _P, _I, _L, _F, _P, _P],
+    "tg_sum_abs_diff": [_P, _P, _I, _L, _F, _P, _P],
+}
+
+_lib = None
+
+
+class TecoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TecoHipError(
+                "libtecogan_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python tecogan_amd/build.py`; tecogan_amd has no fallback path." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        h.tg_last_error_string.restype = C.c_char_p
+        h.tg_version.restype = C.c_int
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise TecoHipError("%s failed (%d): %s" % (what, rc, lib().tg_last_error_string().decode()))

@@ -1,0 +1,82 @@
+// Shared device/host helpers for libtecogan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tecogan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+void tg_set_error(const char* fmt, ...);
+
+#define TG_CHECK_ARG(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      tg_set_error("%s: %s", __func__, msg);                      \
+      return TG_EINVAL;                                           \
+    }                                                             \
+  } while (0)
+
+#define TG_CHECK_LAUNCH()                                         \
+  do {                                                            \
+    hipError_t e_ = hipGetLastError();                            \
+    if (e_ != hipSuccess) {                                       \
+      tg_set_error("%s: %s", __func__, hipGetErrorString(e_));    \
+      return TG_ELAUNCH;                                          \
+    }                                                             \
+    return TG_OK;                                                 \
+  } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even; NaN kept quiet) ------------------
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<u16> {
+  static __device__ __forceinline__ float ld(const u16* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(u16* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act, float alpha) {
+  switch (act) {
+    case TG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case TG_ACT_LRELU: return v > 0.f ? v : v * alpha;
+    case TG_ACT_TANH: return tanhf(v) * alpha;
+    case TG_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+// derivative factor from the activation OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float alpha) {
+  switch (act) {
+    case TG_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case TG_ACT_LRELU: return y > 0.f ? 1.f : alpha;
+    case TG_ACT_TANH: return alpha - y * y / alpha;
+    case TG_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int grid_1d(int64_t work, int block, int cap = 256 * 16) {
+  int64_t g = cdiv64(work, block);
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}

@@ -1,0 +1,209 @@
+// Weight-gradient kernel for the convolution engine (gfx950, fp32 MFMA, split-K + fp32 atomics).
+//
+// For the gather-form convolution described by the descriptor (X gathered, Y per output pixel):
+//   dW[tap][cx][cy] += sum_m X[m@tap][cx] * Y[m][cy]       GEMM: M'=Cx, N'=Cy, K'=output pixels
+//   dbias[cy]       += sum_m Y[m][cy]
+// Covers slim.conv2d (X = layer input, Y = dOut -> HWIO) and slim.conv2d_transpose
+// (X = dOut, Y = layer input -> [kh,kw,Cout,Cin]) of reference lib/ops.py:35-56.
+//
+// Both operands arrive pixel-major (NHWC rows), which is exactly the K-major layout the
+// 16x16x4 fp32 MFMA wants for A^T/B: lane (i=lane&15, g=lane>>4) reads Xs[4g+j][i] -- 64 lanes hit
+// 64 distinct banks with a 68-float row pitch.  bf16 operands are widened to fp32 while staging
+// (weight gradients are accumulated in full fp32 products; the flat fp32 gradient buffer is also
+// the RCCL all-reduce buffer).  grid = (taps, Cx/64 * Cy/64 tiles, pixel chunks).
+#include "common.h"
+
+struct WgradP {
+  const void* x;
+  const void* y;
+  float* dw;
+  float* dbias;
+  int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
+  int M, chunk;     // total output pixels, pixels per block (multiple of 32)
+  int ytiles;
+};
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+  constexpr int PITCH = 68;  // floats per LDS row (64 + 4): (4*PITCH) % 32 == 16
+  __shared__ __attribute__((aligned(16))) float Xs[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) float Ys[32 * PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tap = blockIdx.x, kh = tap / p.KW, kw = tap % p.KW;
+  const int xt = blockIdx.y / p.ytiles, yt = blockIdx.y % p.ytiles;
+  const int cx0 = xt * 64, cy0 = yt * 64;
+  const int mbeg = blockIdx.z * p.chunk;
+  const int mend = min(mbeg + p.chunk, p.M);
+  const bool do_bias = p.dbias != nullptr && tap == 0 && xt == 0;
+
+  const TX* __restrict__ gx = static_cast<const TX*>(p.x);
+  const TY* __restrict__ gy = static_cast<const TY*>(p.y);
+
+  // staging assignment: item = (row in 0..31, 4-channel group in 0..15); two items per thread
+  const int srow = tid >> 4, sgrp = tid & 15;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int frow = lane & 15, fg = lane >> 4;
+
+  for (int mb = mbeg; mb < mend; mb += 32) {
+    // ---- stage 32 pixels x 64 channels of X (gathered at this tap) and Y -------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = srow + h * 16;
+      const int m = mb + r;
+      float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx;
+      if (m < mend) {
+        const int ox = m % p.Wy, t = m / p.Wy;
+        const int oy = t % p.Hy, n = t / p.Hy;
+        const int iy = oy * p.s - p.pt + kh, ix = ox * p.s - p.pl + kw;
+        const int cx = cx0 + sgrp * 4, cy = cy0 + sgrp * 4;
+        if (iy >= 0 && iy < p.Hx && ix >= 0 && ix < p.Wx && cx < p.Cx) {
+          const TX* px = gx + ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.Cx + cx;
+          if (cx + 3 < p.Cx) {
+            vx = make_float4(Elem<TX>::ld(px), Elem<TX>::ld(px + 1), Elem<TX>::ld(px + 2), Elem<TX>::ld(px + 3));
+          } else {
+            vx.x = Elem<TX>::ld(px);
+            if (cx + 1 < p.Cx) vx.y = Elem<TX>::ld(px + 1);
+            if (cx + 2 < p.Cx) vx.z = Elem<TX>::ld(px + 2);
+          }
+        }
+        if (cy < p.Cy) {
+          const TY* py = gy + (int64_t)m * p.Cy + cy;
+          if (cy + 3 < p.Cy) {
+            vy = make_float4(Elem<TY>::ld(py), Elem<TY>::ld(py + 1), Elem<TY>::ld(py + 2), Elem<TY>::ld(py + 3));
+          } else {
+            vy.x = Elem<TY>::ld(py);
+            if (cy + 1 < p.Cy) vy.y = Elem<TY>::ld(py + 1);
+            if (cy + 2 < p.Cy) vy.z = Elem<TY>::ld(py + 2);
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&Xs[r * PITCH + sgrp * 4]) = vx;
+      *reinterpret_cast<float4*>(&Ys[r * PITCH + sgrp * 4]) = vy;
+    }
+    __syncthreads();
+    if (do_bias && tid < 64) {
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) bsum += Ys[r * PITCH + tid];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 16) {
+      float a[2][4], b[2][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = (kk + fg * 4 + e) * PITCH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i][e] = Xs[row + wm * 32 + i * 16 + frow];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j][e] = Ys[row + wn * 32 + j * 16 + frow];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float* __restrict__ dw = p.dw + (int64_t)tap * p.Cx * p.Cy;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cx = cx0 + wm * 32 + i * 16 + fg * 4 + r;
+        const int cy = cy0 + wn * 32 + j * 16 + frow;
+        if (cx < p.Cx && cy < p.Cy) unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[i][j][r]);
+      }
+  if (do_bias && tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, bsum);
+}
+
+extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, const void* y, int y_dtype,
+                             float* dw, float* dbias, void* stream) {
+  TG_CHECK_ARG(d && x && y && dw, "null pointer");
+  TG_CHECK_ARG(d->mode == 0, "descriptor must be the gather form");
+  TG_CHECK_ARG(d->stride >= 1 && d->stride <= 2, "stride must be 1 or 2");
+  TG_CHECK_ARG((int64_t)d->N * d->Hout * d->Wout < (1ll << 31), "too many pixels");
+  WgradP p;
+  p.x = x; p.y = y; p.dw = dw; p.dbias = dbias;
+  p.N = d->N; p.Hx = d->Hin; p.Wx = d->Win; p.Cx = d->Cin;
+  p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.M = d->N * d->Hout * d->Wout;
+  const int xtiles = (p.Cx + 63) / 64;
+  p.ytiles = (p.Cy + 63) / 64;
+  const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
+  // aim for ~2048 blocks, at least 64 pixels of reduction per block
+  int ksplit = (2048 + base_blocks - 1) / base_blocks;
+  const int max_split = (p.M + 63) / 64;
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  p.chunk = (((p.M + ksplit - 1) / ksplit) + 31) / 32 * 32;
+  ksplit = (p.M + p.chunk - 1) / p.chunk;
+  dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (x_dtype == TG_F32 && y_dtype == TG_F32)
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, float>), grid, dim3(256), 0, st, p);
+  else if (x_dtype == TG_BF16 && y_dtype == TG_BF16)
+    hipLaunchKernelGGL((conv_wgrad_kernel<u16, u16>), grid, dim3(256), 0, st, p);
+  else if (x_dtype == TG_BF16 && y_dtype == TG_F32)
+    hipLaunchKernelGGL((conv_wgrad_kernel<u16, float>), grid, dim3(256), 0, st, p);
+  else if (x_dtype == TG_F32 && y_dtype == TG_BF16)
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, u16>), grid, dim3(256), 0, st, p);
+  else
+    TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sum: out[c] += sum_rows x[row][c]   (bias gradient of conv_transpose, BN beta, ...)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, int C,
+                                                     float* __restrict__ out) {
+  // block handles a strip of rows; thread t handles channel (t % Cb) for rows stepping by 256/Cb
+  __shared__ float red[256];
+  const int Cb = C < 256 ? C : 256;
+  const int lanes_per_c = 256 / Cb;          // rows processed in parallel per channel
+  for (int c0 = blockIdx.y * Cb; c0 < C; c0 += gridDim.y * Cb) {
+    const int c = c0 + (threadIdx.x % Cb);
+    const int rsub = threadIdx.x / Cb;
+    float s = 0.f;
+    if (rsub < lanes_per_c && c < C)
+      for (int64_t r = (int64_t)blockIdx.x * lanes_per_c + rsub; r < rows; r += (int64_t)gridDim.x * lanes_per_c)
+        s += Elem<T>::ld(x + r * C + c);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < Cb && c < C) {
+      float t = 0.f;
+      for (int k = 0; k < lanes_per_c; ++k) t += red[k * Cb + threadIdx.x];
+      unsafeAtomicAdd(out + c, t);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream) {
+  TG_CHECK_ARG(x && out && rows > 0 && C > 0, "bad argument");
+  const int Cb = C < 256 ? C : 256;
+  const int lpc = 256 / Cb;
+  int gx = (int)cdiv64(rows, (int64_t)lpc * 64);
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  dim3 grid(gx, (C + Cb - 1) / Cb);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == TG_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, C, out);
+  else hipLaunchKernelGGL((colsum_kernel<u16>), grid, dim3(256), 0, st, (const u16*)x, rows, C, out);
+  TG_CHECK_LAUNCH();
+}

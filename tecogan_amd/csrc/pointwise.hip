@@ -1,0 +1,494 @@
+// HBM-bound companions of the convolution engine (gfx950): pooling, legacy resizes, bicubic
+// epilogue, BatchNorm+LeakyReLU, activation gradients, TF-flavoured Adam, weight re-layout and the
+// loss reductions.  Each kernel cites the reference op it replaces.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// slim.max_pool2d([2,2]) stride 2 VALID -- reference lib/ops.py:92-93  [TF1] A.3
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H,
+                                                           int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t n = (int64_t)N * Ho * Wo * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int x = (int)(t % Wo);
+    t /= Wo;
+    const int y = (int)(t % Ho), b = (int)(t / Ho);
+    const T* __restrict__ p = in + ((int64_t)(b * H + 2 * y) * W + 2 * x) * C + c;
+    const float v0 = Elem<T>::ld(p), v1 = Elem<T>::ld(p + C), v2 = Elem<T>::ld(p + (int64_t)W * C),
+                v3 = Elem<T>::ld(p + (int64_t)W * C + C);
+    Elem<T>::st(out + e, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ in, const T* __restrict__ d_out,
+                                                           T* __restrict__ d_in, int N, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t n = (int64_t)N * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H), b = (int)(t / H);
+    float g = 0.f;
+    const int oy = y >> 1, ox = x >> 1;
+    if (oy < Ho && ox < Wo) {
+      const T* __restrict__ p = in + ((int64_t)(b * H + 2 * oy) * W + 2 * ox) * C + c;
+      const float v[4] = {Elem<T>::ld(p), Elem<T>::ld(p + C), Elem<T>::ld(p + (int64_t)W * C),
+                          Elem<T>::ld(p + (int64_t)W * C + C)};
+      int am = 0;
+      float m = v[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k] > m) {
+          m = v[k];
+          am = k;
+        }
+      if (am == ((y & 1) * 2 + (x & 1))) g = Elem<T>::ld(d_out + ((int64_t)(b * Ho + oy) * Wo + ox) * C + c);
+    }
+    Elem<T>::st(d_in + e, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.image.resize_images x2, legacy bilinear -- reference lib/frvsr.py:21-22  [TF1] A.4
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H,
+                                                            int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t n = (int64_t)N * Ho * Wo * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int X = (int)(t % Wo);
+    t /= Wo;
+    const int Y = (int)(t % Ho), b = (int)(t / Ho);
+    const int i = Y >> 1, j = X >> 1, i1 = min(i + 1, H - 1), j1 = min(j + 1, W - 1);
+    const float ya = 0.5f * (Y & 1), xa = 0.5f * (X & 1);
+    const T* __restrict__ base = in + (int64_t)b * H * W * C + c;
+    const float tl = Elem<T>::ld(base + ((int64_t)i * W + j) * C), tr = Elem<T>::ld(base + ((int64_t)i * W + j1) * C);
+    const float bl = Elem<T>::ld(base + ((int64_t)i1 * W + j) * C), br = Elem<T>::ld(base + ((int64_t)i1 * W + j1) * C);
+    const float top = tl + (tr - tl) * xa, bot = bl + (br - bl) * xa;
+    Elem<T>::st(out + e, top + (bot - top) * ya);
+  }
+}
+
+// contributions of output index o to input index i along one axis: list (o, weight)
+__device__ __forceinline__ int up2_terms(int i, int n, int* o, float* wgt) {
+  int k = 0;
+  o[k] = 2 * i;
+  wgt[k++] = 1.f;
+  o[k] = 2 * i + 1;
+  wgt[k++] = (i == n - 1) ? 1.f : 0.5f;
+  if (i >= 1) {
+    o[k] = 2 * i - 1;
+    wgt[k++] = 0.5f;
+  }
+  return k;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const T* __restrict__ d_out, T* __restrict__ d_in, int N,
+                                                            int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t n = (int64_t)N * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int j = (int)(t % W);
+    t /= W;
+    const int i = (int)(t % H), b = (int)(t / H);
+    int oy[3], ox[3];
+    float wy[3], wx[3];
+    const int ny = up2_terms(i, H, oy, wy), nx = up2_terms(j, W, ox, wx);
+    const T* __restrict__ g = d_out + (int64_t)b * Ho * Wo * C + c;
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int d = 0; d < nx; ++d) s += wy[a] * wx[d] * Elem<T>::ld(g + ((int64_t)oy[a] * Wo + ox[d]) * C);
+    Elem<T>::st(d_in + e, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = (conv_out + bicubic_four(lr)) * 2 - 1 -- reference lib/frvsr.py:81-87, lib/ops.py:166-212
+// Keys a=-0.75 weights for t in {0,.25,.5,.75}; all exactly representable (multiples of 2^-8).
+__constant__ float kBicubic[4][4] = {{0.f, 1.f, 0.f, 0.f},
+                                     {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f},
+                                     {-0.09375f, 0.59375f, 0.59375f, -0.09375f},
+                                     {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f}};
+
+template <typename TI>
+__global__ __launch_bounds__(256) void bicubic_add_kernel(const float* __restrict__ conv_out,
+                                                          const TI* __restrict__ gen_in, int Cpad,
+                                                          float* __restrict__ out, int B, int h, int w) {
+  const int H = 4 * h, W = 4 * w;
+  const int64_t n = (int64_t)B * H * W;
+  for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += (int64_t)gridDim.x * blockDim.x) {
+    const int X = (int)(pix % W), Y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    const int i = Y >> 2, j = X >> 2;
+    const float* wy = kBicubic[Y & 3];
+    const float* wx = kBicubic[X & 3];
+    int ry[4], rx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ry[k] = min(max(i + k - 1, 0), h - 1);   // replicate pad: 1 top/left, 2 bottom/right
+      rx[k] = min(max(j + k - 1, 0), w - 1);
+    }
+    const TI* __restrict__ base = gen_in + (int64_t)b * h * w * Cpad;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float col[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // rows first (lib/ops.py:190-198)
+        const float p0 = Elem<TI>::ld(base + ((int64_t)ry[0] * w + rx[k]) * Cpad + c);
+        const float p1 = Elem<TI>::ld(base + ((int64_t)ry[1] * w + rx[k]) * Cpad + c);
+        const float p2 = Elem<TI>::ld(base + ((int64_t)ry[2] * w + rx[k]) * Cpad + c);
+        const float p3 = Elem<TI>::ld(base + ((int64_t)ry[3] * w + rx[k]) * Cpad + c);
+        col[k] = wy[0] * p0 + wy[1] * p1 + wy[2] * p2 + wy[3] * p3;
+      }
+      const float bic = wx[0] * col[0] + wx[1] * col[1] + wx[2] * col[2] + wx[3] * col[3];
+      out[pix * 3 + c] = (conv_out[pix * 3 + c] + bic) * 2.f - 1.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ d_out, const T* __restrict__ y,
+                                                      T* __restrict__ d_in, int64_t n, int act, float alpha) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(d_in + e, Elem<T>::ld(d_out + e) * act_grad_from_out(Elem<T>::ld(y + e), act, alpha));
+}
+
+// ------------------------------------------------------------------------------------------------
+// slim.batch_norm(is_training=True, scale=False, eps=1e-3, decay=.9) + lrelu(0.2)
+// reference lib/ops.py:88-90, lib/Teco.py:38-39  [TF1] A.7.   x viewed as [rows][C].
+// pass 0: mean; pass 1: biased variance around that mean (two-pass, no E[x^2]-E[x]^2 cancellation).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t rows, int C,
+                                                       float* __restrict__ stats, int pass) {
+  __shared__ float red[256];
+  const int Cb = C < 256 ? C : 256, lpc = 256 / Cb;
+  const float inv = 1.f / (float)rows;
+  for (int c0 = blockIdx.y * Cb; c0 < C; c0 += gridDim.y * Cb) {
+    const int c = c0 + (threadIdx.x % Cb), rsub = threadIdx.x / Cb;
+    float s = 0.f;
+    if (rsub < lpc && c < C) {
+      const float mu = pass ? stats[c] : 0.f;
+      for (int64_t r = (int64_t)blockIdx.x * lpc + rsub; r < rows; r += (int64_t)gridDim.x * lpc) {
+        const float v = Elem<T>::ld(x + r * C + c) - mu;
+        s += pass ? v * v : v;
+      }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < Cb && c < C) {
+      float t = 0.f;
+      for (int k = 0; k < lpc; ++k) t += red[k * Cb + threadIdx.x];
+      unsafeAtomicAdd(stats + pass * C + c, t * inv);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows,
+                                                             int C, const float* __restrict__ beta,
+                                                             const float* __restrict__ stats, float eps, float alpha,
+                                                             float* __restrict__ moving) {
+  const int64_t n = rows * C;
+  if (moving && blockIdx.x == 0) {   // [TF1] moving stats: decay .9, unbiased variance fed to the average
+    const float corr = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      moving[c] = moving[c] * 0.9f + stats[c] * 0.1f;
+      moving[C + c] = moving[C + c] * 0.9f + stats[C + c] * corr * 0.1f;
+    }
+  }
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const float v = (Elem<T>::ld(x + e) - stats[c]) * rsqrtf(stats[C + c] + eps) + beta[c];
+    Elem<T>::st(y + e, v > 0.f ? v : v * alpha);
+  }
+}
+
+// sums[0][c] = sum dz, sums[1][c] = sum dz*xhat  with dz = dy * lrelu'(y)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                          const T* __restrict__ dy, int64_t rows, int C,
+                                                          const float* __restrict__ stats, float eps, float alpha,
+                                                          float* __restrict__ sums) {
+  __shared__ float red0[256], red1[256];
+  const int Cb = C < 256 ? C : 256, lpc = 256 / Cb;
+  for (int c0 = blockIdx.y * Cb; c0 < C; c0 += gridDim.y * Cb) {
+    const int c = c0 + (threadIdx.x % Cb), rsub = threadIdx.x / Cb;
+    float s0 = 0.f, s1 = 0.f;
+    if (rsub < lpc && c < C) {
+      const float mu = stats[c], rstd = rsqrtf(stats[C + c] + eps);
+      for (int64_t r = (int64_t)blockIdx.x * lpc + rsub; r < rows; r += (int64_t)gridDim.x * lpc) {
+        const float dz = Elem<T>::ld(dy + r * C + c) * (Elem<T>::ld(y + r * C + c) > 0.f ? 1.f : alpha);
+        s0 += dz;
+        s1 += dz * (Elem<T>::ld(x + r * C + c) - mu) * rstd;
+      }
+    }
+    red0[threadIdx.x] = s0;
+    red1[threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < Cb && c < C) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int k = 0; k < lpc; ++k) {
+        t0 += red0[k * Cb + threadIdx.x];
+        t1 += red1[k * Cb + threadIdx.x];
+      }
+      unsafeAtomicAdd(sums + c, t0);
+      unsafeAtomicAdd(sums + C + c, t1);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                           const T* __restrict__ dy, T* __restrict__ dx, int64_t rows,
+                                                           int C, const float* __restrict__ stats, float eps,
+                                                           float alpha, const float* __restrict__ sums,
+                                                           float* __restrict__ d_beta) {
+  const int64_t n = rows * C;
+  const float inv = 1.f / (float)rows;
+  if (d_beta && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) d_beta[c] += sums[c];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const float rstd = rsqrtf(stats[C + c] + eps);
+    const float xhat = (Elem<T>::ld(x + e) - stats[c]) * rstd;
+    const float dz = Elem<T>::ld(dy + e) * (Elem<T>::ld(y + e) > 0.f ? 1.f : alpha);
+    Elem<T>::st(dx + e, rstd * (dz - sums[c] * inv - xhat * sums[C + c] * inv));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer (reference lib/Teco.py:425,439-440)  [TF1] A.11
+// hyper = {lr_t, beta1, beta2, eps, gate}; gate == 0 leaves p, m, v untouched (tf.cond D-gate).
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                      const float* __restrict__ hyper, float grad_scale) {
+  const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  if (hyper[4] == 0.f) return;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float gr = g[e] * grad_scale;
+    const float mm = m[e] * b1 + gr * (1.f - b1);
+    const float vv = v[e] * b2 + gr * gr * (1.f - b2);
+    m[e] = mm;
+    v[e] = vv;
+    p[e] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight re-layout: dst[tap][b][a] = src[tap][a][b] (or plain converting copy); table-driven so one
+// launch re-packs every weight of the flat parameter buffer.
+template <typename TD>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src, TD* __restrict__ dst,
+                                                           const int64_t* __restrict__ tab, int transpose) {
+  const int64_t* t = tab + (int64_t)blockIdx.y * 4;
+  const int64_t so = t[0], dof = t[1], taps = t[2];
+  const int A = (int)(t[3] >> 32), Bd = (int)(t[3] & 0xffffffff);
+  const int64_t n = taps * A * Bd;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s = e;
+    if (transpose) {  // e indexes dst [tap][b][a]
+      const int a = (int)(e % A);
+      const int64_t r = e / A;
+      const int b = (int)(r % Bd);
+      const int64_t tap = r / Bd;
+      s = (tap * A + a) * Bd + b;
+    }
+    Elem<TD>::st(dst + dof + e, src[so + s]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss reductions: out[0] += scale * sum f(a-b)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void sum_diff_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n,
+                                                       float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float d = Elem<T>::ld(a + e) - Elem<T>::ld(b + e);
+    s += MODE == 0 ? d * d : fabsf(d);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+// ================================================================================================
+#define ST(s) static_cast<hipStream_t>(s)
+#define DISPATCH_DT(dtype, KERNEL, grid, ...)                                                    \
+  if ((dtype) == TG_F32) hipLaunchKernelGGL((KERNEL<float>), grid, dim3(256), 0, ST(stream), __VA_ARGS__); \
+  else if ((dtype) == TG_BF16) hipLaunchKernelGGL((KERNEL<u16>), grid, dim3(256), 0, ST(stream), __VA_ARGS__); \
+  else TG_CHECK_ARG(false, "bad dtype")
+
+extern "C" int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream) {
+  TG_CHECK_ARG(in && out && N > 0 && H > 1 && W > 1 && C > 0, "bad argument");
+  dim3 grid(grid_1d((int64_t)N * (H / 2) * (W / 2) * C, 256));
+  if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_fwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (float*)out, N, H, W, C);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_fwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W,
+                                    int C, void* stream) {
+  TG_CHECK_ARG(in && d_out && d_in && N > 0 && H > 1 && W > 1 && C > 0, "bad argument");
+  dim3 grid(grid_1d((int64_t)N * H * W * C, 256));
+  if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (const float*)d_out, (float*)d_in, N, H, W, C);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_upsample2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream) {
+  TG_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
+  dim3 grid(grid_1d((int64_t)N * H * W * 4 * C, 256));
+  if (dtype == TG_F32) hipLaunchKernelGGL((upsample2_fwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (float*)out, N, H, W, C);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((upsample2_fwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, int N, int H, int W, int C,
+                                     void* stream) {
+  TG_CHECK_ARG(d_out && d_in && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
+  dim3 grid(grid_1d((int64_t)N * H * W * C, 256));
+  if (dtype == TG_F32) hipLaunchKernelGGL((upsample2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (float*)d_in, N, H, W, C);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((upsample2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (u16*)d_in, N, H, W, C);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_in, int in_dtype, int Cpad, float* out,
+                                         int B, int h, int w, void* stream) {
+  TG_CHECK_ARG(conv_out && gen_in && out && B > 0 && h > 0 && w > 0 && Cpad >= 3, "bad argument");
+  dim3 grid(grid_1d((int64_t)B * h * w * 16, 256));
+  if (in_dtype == TG_F32) hipLaunchKernelGGL((bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
+  else if (in_dtype == TG_BF16) hipLaunchKernelGGL((bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_act_backward(const void* d_out, const void* y, void* d_in, int dtype, int64_t n, int act, float alpha,
+                               void* stream) {
+  TG_CHECK_ARG(d_out && y && d_in && n > 0, "bad argument");
+  dim3 grid(grid_1d(n, 256));
+  if (dtype == TG_F32) hipLaunchKernelGGL((act_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (const float*)y, (float*)d_in, n, act, alpha);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((act_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (const u16*)y, (u16*)d_in, n, act, alpha);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+static dim3 reduce_grid(int64_t rows, int C) {
+  const int Cb = C < 256 ? C : 256, lpc = 256 / Cb;
+  int gx = (int)cdiv64(rows, (int64_t)lpc * 32);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  return dim3(gx, (C + Cb - 1) / Cb);
+}
+
+extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t rows, int C, const float* beta, float eps,
+                                   float alpha, float* stats, float* moving, void* stream) {
+  TG_CHECK_ARG(x && y && beta && stats && rows > 0 && C > 0, "bad argument");
+  TG_CHECK_ARG(dtype == TG_F32 || dtype == TG_BF16, "bad dtype");
+  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
+    tg_set_error("tg_bn_lrelu_forward: memset failed");
+    return TG_ELAUNCH;
+  }
+  const dim3 rg = reduce_grid(rows, C);
+  const dim3 eg(grid_1d(rows * C, 256));
+  if (dtype == TG_F32) {
+    hipLaunchKernelGGL((bn_stats_kernel<float>), rg, dim3(256), 0, ST(stream), (const float*)x, rows, C, stats, 0);
+    hipLaunchKernelGGL((bn_stats_kernel<float>), rg, dim3(256), 0, ST(stream), (const float*)x, rows, C, stats, 1);
+    hipLaunchKernelGGL((bn_lrelu_apply_kernel<float>), eg, dim3(256), 0, ST(stream), (const float*)x, (float*)y, rows, C, beta, stats, eps, alpha, moving);
+  } else {
+    hipLaunchKernelGGL((bn_stats_kernel<u16>), rg, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats, 0);
+    hipLaunchKernelGGL((bn_stats_kernel<u16>), rg, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats, 1);
+    hipLaunchKernelGGL((bn_lrelu_apply_kernel<u16>), eg, dim3(256), 0, ST(stream), (const u16*)x, (u16*)y, rows, C, beta, stats, eps, alpha, moving);
+  }
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_y, void* d_x, int dtype, int64_t rows,
+                                    int C, const float* stats, float eps, float alpha, float* d_beta, float* ws,
+                                    void* stream) {
+  TG_CHECK_ARG(x && y && d_y && d_x && stats && ws && rows > 0 && C > 0, "bad argument");
+  TG_CHECK_ARG(dtype == TG_F32 || dtype == TG_BF16, "bad dtype");
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
+    tg_set_error("tg_bn_lrelu_backward: memset failed");
+    return TG_ELAUNCH;
+  }
+  const dim3 rg = reduce_grid(rows, C);
+  const dim3 eg(grid_1d(rows * C, 256));
+  if (dtype == TG_F32) {
+    hipLaunchKernelGGL((bn_bwd_sums_kernel<float>), rg, dim3(256), 0, ST(stream), (const float*)x, (const float*)y, (const float*)d_y, rows, C, stats, eps, alpha, ws);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), eg, dim3(256), 0, ST(stream), (const float*)x, (const float*)y, (const float*)d_y, (float*)d_x, rows, C, stats, eps, alpha, ws, d_beta);
+  } else {
+    hipLaunchKernelGGL((bn_bwd_sums_kernel<u16>), rg, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows, C, stats, eps, alpha, ws);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<u16>), eg, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, (u16*)d_x, rows, C, stats, eps, alpha, ws, d_beta);
+  }
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                          float grad_scale, void* stream) {
+  TG_CHECK_ARG(p && g && m && v && hyper && n > 0, "bad argument");
+  hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_1d(n, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, hyper,
+                     grad_scale);
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_pack_weights(const float* src_base, void* dst_base, int dst_dtype, const int64_t* tab, int count,
+                               int transpose, void* stream) {
+  TG_CHECK_ARG(src_base && dst_base && tab && count > 0, "bad argument");
+  dim3 grid(64, count);
+  if (dst_dtype == TG_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, ST(stream), src_base, (float*)dst_base, tab, transpose);
+  else if (dst_dtype == TG_BF16) hipLaunchKernelGGL((pack_weights_kernel<u16>), grid, dim3(256), 0, ST(stream), src_base, (u16*)dst_base, tab, transpose);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_sum_sq_diff(const void* a, const void* b, int dtype, int64_t n, float scale, float* out,
+                              void* stream) {
+  TG_CHECK_ARG(a && b && out && n > 0, "bad argument");
+  dim3 grid(grid_1d(n, 256 * 8, 1024));
+  if (dtype == TG_F32) hipLaunchKernelGGL((sum_diff_kernel<float, 0>), grid, dim3(256), 0, ST(stream), (const float*)a, (const float*)b, n, scale, out);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((sum_diff_kernel<u16, 0>), grid, dim3(256), 0, ST(stream), (const u16*)a, (const u16*)b, n, scale, out);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_sum_abs_diff(const void* a, const void* b, int dtype, int64_t n, float scale, float* out,
+                               void* stream) {
+  TG_CHECK_ARG(a && b && out && n > 0, "bad argument");
+  dim3 grid(grid_1d(n, 256 * 8, 1024));
+  if (dtype == TG_F32) hipLaunchKernelGGL((sum_diff_kernel<float, 1>), grid, dim3(256), 0, ST(stream), (const float*)a, (const float*)b, n, scale, out);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((sum_diff_kernel<u16, 1>), grid, dim3(256), 0, ST(stream), (const u16*)a, (const u16*)b, n, scale, out);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+#include <stdarg.h>
+static thread_local char g_err[512] = "";
+void tg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tg_last_error_string(void) { return g_err; }
+extern "C" int tg_version(void) { return 1; }

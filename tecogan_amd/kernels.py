@@ -1,0 +1,165 @@
+"""Tensor-level (no autograd) wrappers of the C ABI: torch is only the owner of device memory
+and of the HIP stream.  Every function enqueues on torch's current stream (hipGraph capturable)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, TG_BF16, TG_F32, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return TG_F32
+    if t.dtype == torch.bfloat16:
+        return TG_BF16
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.TecoHipError("tensor is not on the GPU: tecogan_amd has no CPU path")
+    if not t.is_contiguous():
+        raise L.TecoHipError("tensor must be contiguous (NHWC)")
+    return C.c_void_p(t.data_ptr())
+
+
+def same_pad(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+def conv_desc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, mode, in_dt, out_dt,
+              act=0, act_alpha=0.0, mask_act=0, mask_alpha=0.0):
+    return ConvDesc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, mode, in_dt, out_dt,
+                    act, act_alpha, mask_act, mask_alpha)
+
+
+def conv_forward(desc, x, w, bias, res, aux, out):
+    check(lib().tg_conv_forward(C.byref(desc), _p(x), _p(w), _p(bias), _p(res), _p(aux), _p(out), _stream()),
+          "tg_conv_forward")
+    return out
+
+
+def conv_wgrad(desc, x, y, dw, dbias):
+    check(lib().tg_conv_wgrad(C.byref(desc), _p(x), dt(x), _p(y), dt(y), _p(dw), _p(dbias), _stream()),
+          "tg_conv_wgrad")
+
+
+def colsum(x, rows, Cn, out):
+    check(lib().tg_colsum(_p(x), dt(x), rows, Cn, _p(out), _stream()), "tg_colsum")
+
+
+def pack_weights(src_base, dst_base, tab, count, transpose):
+    check(lib().tg_pack_weights(_p(src_base), _p(dst_base), dt(dst_base), _p(tab), count, int(transpose), _stream()),
+          "tg_pack_weights")
+
+
+def warp_s2d_forward(pre, flow_lr, lr, out, scale, shift, warped=None):
+    B, h, w, _ = lr.shape
+    hf, wf = (flow_lr.shape[1], flow_lr.shape[2]) if flow_lr is not None else (h, w)
+    check(lib().tg_warp_s2d_forward(_p(pre), _p(flow_lr), _p(lr), _p(out), dt(out), B, h, w, hf, wf, out.shape[3],
+                                    scale, shift, _p(warped), _stream()), "tg_warp_s2d_forward")
+    return out
+
+
+def warp_s2d_backward(d_out, pre, flow_lr, d_pre, d_flow_lr, scale):
+    B, h, w, Cpad = d_out.shape
+    check(lib().tg_warp_s2d_backward(_p(d_out), dt(d_out), _p(pre), _p(flow_lr), _p(d_pre), _p(d_flow_lr), B, h, w,
+                                     Cpad, scale, _stream()), "tg_warp_s2d_backward")
+
+
+def warp_forward(img, flow, out):
+    B, H, W, Cn = img.shape
+    check(lib().tg_warp_forward(_p(img), _p(flow), _p(out), B, H, W, Cn, _stream()), "tg_warp_forward")
+    return out
+
+
+def warp_backward(d_out, img, flow, d_img, d_flow):
+    B, H, W, Cn = img.shape
+    check(lib().tg_warp_backward(_p(d_out), _p(img), _p(flow), _p(d_img), _p(d_flow), B, H, W, Cn, _stream()),
+          "tg_warp_backward")
+
+
+def upscale4_forward(x, out, gain=1.0):
+    B, h, w, Cn = x.shape
+    check(lib().tg_upscale4_forward(_p(x), _p(out), B, h, w, Cn, gain, _stream()), "tg_upscale4_forward")
+    return out
+
+
+def upscale4_backward(d_out, d_in, gain=1.0):
+    B, h, w, Cn = d_in.shape
+    check(lib().tg_upscale4_backward(_p(d_out), _p(d_in), B, h, w, Cn, gain, _stream()), "tg_upscale4_backward")
+    return d_in
+
+
+def maxpool2_forward(x, out):
+    N, H, W, Cn = x.shape
+    check(lib().tg_maxpool2_forward(_p(x), _p(out), dt(x), N, H, W, Cn, _stream()), "tg_maxpool2_forward")
+    return out
+
+
+def maxpool2_backward(x, d_out, d_in):
+    N, H, W, Cn = x.shape
+    check(lib().tg_maxpool2_backward(_p(x), _p(d_out), _p(d_in), dt(x), N, H, W, Cn, _stream()),
+          "tg_maxpool2_backward")
+    return d_in
+
+
+def upsample2_forward(x, out):
+    N, H, W, Cn = x.shape
+    check(lib().tg_upsample2_forward(_p(x), _p(out), dt(x), N, H, W, Cn, _stream()), "tg_upsample2_forward")
+    return out
+
+
+def upsample2_backward(d_out, d_in):
+    N, H, W, Cn = d_in.shape
+    check(lib().tg_upsample2_backward(_p(d_out), _p(d_in), dt(d_in), N, H, W, Cn, _stream()),
+          "tg_upsample2_backward")
+    return d_in
+
+
+def bicubic_add_preprocess(conv_out, gen_in, out):
+    B, h, w, Cpad = gen_in.shape
+    check(lib().tg_bicubic_add_preprocess(_p(conv_out), _p(gen_in), dt(gen_in), Cpad, _p(out), B, h, w, _stream()),
+          "tg_bicubic_add_preprocess")
+    return out
+
+
+def act_backward(d_out, y, d_in, act, alpha):
+    check(lib().tg_act_backward(_p(d_out), _p(y), _p(d_in), dt(y), y.numel(), act, alpha, _stream()),
+          "tg_act_backward")
+    return d_in
+
+
+def bn_lrelu_forward(x, y, beta, eps, alpha, stats, moving):
+    Cn = x.shape[-1]
+    check(lib().tg_bn_lrelu_forward(_p(x), _p(y), dt(x), x.numel() // Cn, Cn, _p(beta), eps, alpha, _p(stats),
+                                    _p(moving), _stream()), "tg_bn_lrelu_forward")
+    return y
+
+
+def bn_lrelu_backward(x, y, d_y, d_x, stats, eps, alpha, d_beta, ws):
+    Cn = x.shape[-1]
+    check(lib().tg_bn_lrelu_backward(_p(x), _p(y), _p(d_y), _p(d_x), dt(x), x.numel() // Cn, Cn, _p(stats), eps,
+                                     alpha, _p(d_beta), _p(ws), _stream()), "tg_bn_lrelu_backward")
+    return d_x
+
+
+def adam_tf(p, g, m, v, hyper, grad_scale=1.0):
+    check(lib().tg_adam_tf(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), grad_scale, _stream()), "tg_adam_tf")
+
+
+def sum_sq_diff(a, b, scale, out):
+    check(lib().tg_sum_sq_diff(_p(a), _p(b), dt(a), a.numel(), scale, _p(out), _stream()), "tg_sum_sq_diff")
+
+
+def sum_abs_diff(a, b, scale, out):
+    check(lib().tg_sum_abs_diff(_p(a), _p(b), dt(a), a.numel(), scale, _p(out), _stream()), "tg_sum_abs_diff")

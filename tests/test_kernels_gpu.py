@@ -1,0 +1,380 @@
+"""Kernel-level parity: every HIP entry point of the C ABI against the CPU oracle (fp32: 1e-4 abs/rel
+unless stated; index shuffles bit-exact).  These call through libtecogan_hip.so via ctypes."""
+import pytest
+import torch
+
+import oracle.ops as O
+from tecogan_amd import kernels as K
+from tecogan_amd._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, TG_BF16, TG_F32)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, tol=1e-4, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * max(1.0, ref), "%s: max err %g (ref max %g)" % (what, err, ref)
+
+
+def tdt(dtype):
+    return TG_F32 if dtype == torch.float32 else TG_BF16
+
+
+def run_conv_fwd(x, w_hwio, b, stride, act=ACT_NONE, alpha=0.0, res=None, dtype=torch.float32, out_dtype=None):
+    """conv2 forward through the gather engine; w operand = [tap][Cout][Cin]."""
+    out_dtype = out_dtype or dtype
+    N, H, W, Cin = x.shape
+    kh, kw, _, Cout = w_hwio.shape
+    Ho, pt = K.same_pad(H, kh, stride)
+    Wo, pl = K.same_pad(W, kw, stride)
+    wt = w_hwio.permute(0, 1, 3, 2).reshape(kh * kw, Cout, Cin).contiguous().to(DEV, dtype)
+    out = torch.empty(N, Ho, Wo, Cout, device=DEV, dtype=out_dtype)
+    d = K.conv_desc(N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pt, pl, 0, tdt(dtype), tdt(out_dtype), act, alpha)
+    K.conv_forward(d, x.to(DEV, dtype).contiguous(), wt, None if b is None else b.to(DEV), 
+                   None if res is None else res.to(DEV, out_dtype).contiguous(), None, out)
+    return out
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, s
+    (2, 8, 8, 64, 64, 3, 1),
+    (1, 5, 7, 8, 32, 3, 1),
+    (2, 9, 13, 56, 64, 3, 1),
+    (1, 16, 16, 64, 3, 3, 1),
+    (3, 6, 6, 32, 2, 3, 1),
+    (2, 16, 16, 64, 64, 4, 2),
+    (1, 9, 11, 32, 128, 4, 2),
+    (1, 4, 4, 256, 1, 1, 1),
+    (1, 12, 12, 128, 256, 3, 1),
+    (1, 33, 35, 64, 64, 3, 1),
+    (1, 6, 6, 51, 64, 3, 1),     # scalar (non-vector) channel path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_fp32(case):
+    N, H, W, Cin, Cout, k, s = case
+    x, w, b = rnd(N, H, W, Cin, seed=1), rnd(k, k, Cin, Cout, seed=2, scale=0.2), rnd(Cout, seed=3)
+    ref = O.conv2(x, w, b, s)
+    got = run_conv_fwd(x, w, b, s)
+    close(got, ref, 1e-4, "conv fwd %s" % (case,))
+
+
+def test_conv_forward_epilogues():
+    x, w, b = rnd(2, 8, 8, 64, seed=1), rnd(3, 3, 64, 64, seed=2, scale=0.2), rnd(64, seed=3)
+    res = rnd(2, 8, 8, 64, seed=4)
+    pre = O.conv2(x, w, b, 1)
+    close(run_conv_fwd(x, w, b, 1, ACT_RELU), torch.relu(pre), 1e-4, "relu")
+    close(run_conv_fwd(x, w, b, 1, ACT_LRELU, 0.2), O.lrelu(pre, 0.2), 1e-4, "lrelu")
+    close(run_conv_fwd(x, w, b, 1, ACT_TANH, 24.0), torch.tanh(pre) * 24.0, 1e-4, "tanh")
+    close(run_conv_fwd(x, w, b, 1, ACT_SIGMOID), torch.sigmoid(pre), 1e-4, "sigmoid")
+    close(run_conv_fwd(x, w, b, 1, ACT_NONE, 0.0, res), pre + res, 1e-4, "residual")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_bf16(case):
+    N, H, W, Cin, Cout, k, s = case
+    x, w, b = rnd(N, H, W, Cin, seed=1), rnd(k, k, Cin, Cout, seed=2, scale=0.2), rnd(Cout, seed=3)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    ref = O.conv2(xb, wb, b, s)
+    got = run_conv_fwd(x, w, b, s, dtype=torch.bfloat16, out_dtype=torch.float32)
+    close(got, ref, 2e-4, "conv bf16 fwd (f32 out) %s" % (case,))
+    got = run_conv_fwd(x, w, b, s, dtype=torch.bfloat16)
+    close(got, ref, 1e-2, "conv bf16 fwd %s" % (case,))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bwd_data_and_wgrad_fp32(case):
+    N, H, W, Cin, Cout, k, s = case
+    x = rnd(N, H, W, Cin, seed=1).requires_grad_()
+    w = rnd(k, k, Cin, Cout, seed=2, scale=0.2).requires_grad_()
+    b = rnd(Cout, seed=3).requires_grad_()
+    y = O.conv2(x, w, b, s)
+    gy = rnd(*y.shape, seed=5)
+    y.backward(gy)
+    Ho, pt = K.same_pad(H, k, s)
+    Wo, pl = K.same_pad(W, k, s)
+    # bwd_data = transposed mode with the HWIO weights as stored: operand [tap][n=Cin][k=Cout]
+    d = K.conv_desc(N, Ho, Wo, Cout, H, W, Cin, k, k, s, pt, pl, 1, TG_F32, TG_F32)
+    dx = torch.empty(N, H, W, Cin, device=DEV)
+    K.conv_forward(d, gy.to(DEV), w.detach().reshape(k * k, Cin, Cout).contiguous().to(DEV), None, None, None, dx)
+    close(dx, x.grad, 1e-4, "bwd_data %s" % (case,))
+    dg = K.conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 0, TG_F32, TG_F32)
+    dw = torch.zeros(k, k, Cin, Cout, device=DEV)
+    db = torch.zeros(Cout, device=DEV)
+    K.conv_wgrad(dg, x.detach().to(DEV), gy.to(DEV), dw, db)
+    close(dw, w.grad, 2e-4, "wgrad %s" % (case,))
+    close(db, b.grad, 2e-4, "bgrad %s" % (case,))
+
+
+def test_conv_bwd_mask_and_residual_epilogue():
+    """dx = (bwd_data(dy) + res) * relu'(aux): the fused form used between res-block layers."""
+    N, H, W, Cc = 2, 8, 8, 64
+    w = rnd(3, 3, Cc, Cc, seed=2, scale=0.2)
+    gy, res, aux = rnd(N, H, W, Cc, seed=5), rnd(N, H, W, Cc, seed=6), rnd(N, H, W, Cc, seed=7)
+    x = torch.zeros(N, H, W, Cc, requires_grad=True)
+    O.conv2(x, w, None, 1).backward(gy)
+    for act, alpha, fac in ((ACT_RELU, 0.0, (aux > 0).float()), (ACT_LRELU, 0.2, torch.where(aux > 0, 1.0, 0.2))):
+        d = K.conv_desc(N, H, W, Cc, H, W, Cc, 3, 3, 1, 1, 1, 1, TG_F32, TG_F32, 0, 0.0, act, alpha)
+        dx = torch.empty(N, H, W, Cc, device=DEV)
+        K.conv_forward(d, gy.to(DEV), w.reshape(9, Cc, Cc).contiguous().to(DEV), None, res.to(DEV), aux.to(DEV), dx)
+        close(dx, (x.grad + res) * fac, 1e-4, "mask epilogue act=%d" % act)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 64), (1, 5, 7, 64, 64), (1, 16, 16, 32, 64)])
+def test_deconv_fwd_bwd_fp32(shape):
+    N, H, W, Cin, Cout = shape
+    x = rnd(N, H, W, Cin, seed=1).requires_grad_()
+    w = rnd(3, 3, Cout, Cin, seed=2, scale=0.2).requires_grad_()      # TF conv2d_transpose layout
+    b = rnd(Cout, seed=3).requires_grad_()
+    y = O.conv2_tran(x, w, b, 2)
+    gy = rnd(*y.shape, seed=5)
+    y.backward(gy)
+    # forward: transposed mode, pad 0, weights as stored ([tap][Cout][Cin])
+    d = K.conv_desc(N, H, W, Cin, 2 * H, 2 * W, Cout, 3, 3, 2, 0, 0, 1, TG_F32, TG_F32, ACT_NONE)
+    out = torch.empty(N, 2 * H, 2 * W, Cout, device=DEV)
+    K.conv_forward(d, x.detach().to(DEV), w.detach().reshape(9, Cout, Cin).contiguous().to(DEV), b.detach().to(DEV),
+                   None, None, out)
+    close(out, y, 1e-4, "deconv fwd")
+    # bwd_data: gather s2 pad 0 over dy with operand [tap][n=Cin][k=Cout]
+    dg = K.conv_desc(N, 2 * H, 2 * W, Cout, H, W, Cin, 3, 3, 2, 0, 0, 0, TG_F32, TG_F32)
+    dx = torch.empty(N, H, W, Cin, device=DEV)
+    K.conv_forward(dg, gy.to(DEV), w.detach().permute(0, 1, 3, 2).reshape(9, Cin, Cout).contiguous().to(DEV), None,
+                   None, None, dx)
+    close(dx, x.grad, 1e-4, "deconv bwd_data")
+    # wgrad: X = dy (gathered), Y = x -> [tap][Cout][Cin]; bias grad = colsum(dy)
+    dw = torch.zeros(3, 3, Cout, Cin, device=DEV)
+    K.conv_wgrad(dg, gy.to(DEV), x.detach().to(DEV), dw, None)
+    close(dw, w.grad, 2e-4, "deconv wgrad")
+    db = torch.zeros(Cout, device=DEV)
+    K.colsum(gy.to(DEV), gy.numel() // Cout, Cout, db)
+    close(db, b.grad, 2e-4, "deconv bgrad")
+
+
+def test_wgrad_bf16_inputs():
+    N, H, W, Cin, Cout = 2, 8, 8, 64, 64
+    x, gy = rnd(N, H, W, Cin, seed=1).bfloat16(), rnd(N, H, W, Cout, seed=5).bfloat16()
+    xr = x.float().requires_grad_()
+    w = torch.zeros(3, 3, Cin, Cout, requires_grad=True)
+    O.conv2(xr, w, None, 1).backward(gy.float())
+    d = K.conv_desc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16)
+    dw = torch.zeros(3, 3, Cin, Cout, device=DEV)
+    K.conv_wgrad(d, x.to(DEV), gy.to(DEV), dw, None)
+    close(dw, w.grad, 2e-4, "wgrad bf16 operands")
+
+
+# --------------------------------------------------------------------------------------------
+def oracle_gen_input(pre, flow_lr, lr, scale, shift, cpad):
+    B, h, w, _ = lr.shape
+    if pre is None:
+        s2d = torch.zeros(B, h, w, 48)
+    else:
+        hf, wf = flow_lr.shape[1:3]
+        fl = flow_lr
+        if hf < h:     # main.py:212 tf.pad(..., "SYMMETRIC"): mirror including the edge row
+            fl = torch.cat((fl, fl[:, hf - (h - hf):].flip(1)), 1)
+        if wf < w:
+            fl = torch.cat((fl, fl[:, :, wf - (w - wf):].flip(2)), 2)
+        warped = O.dense_image_warp(pre, O.upscale_four(fl * 4.0))
+        s2d = O.space_to_depth4(warped * scale + shift)
+    return torch.cat((lr, s2d, torch.zeros(B, h, w, cpad - 51)), -1)
+
+
+@pytest.mark.parametrize("B,h,w", [(2, 8, 8), (1, 5, 9), (4, 32, 32)])
+def test_warp_s2d_forward_backward(B, h, w):
+    pre = rnd(B, 4 * h, 4 * w, 3, seed=1).requires_grad_()
+    flow = rnd(B, h, w, 2, seed=2, scale=3.0).requires_grad_()
+    lr = rnd(B, h, w, 3, seed=3)
+    ref = oracle_gen_input(pre, flow, lr, 0.5, 0.5, 56)
+    out = torch.empty(B, h, w, 56, device=DEV)
+    K.warp_s2d_forward(pre.detach().to(DEV), flow.detach().to(DEV), lr.to(DEV), out, 0.5, 0.5)
+    close(out, ref, 2e-5, "warp_s2d fwd")
+    g = rnd(B, h, w, 56, seed=4)
+    ref.backward(g)
+    d_pre = torch.zeros(B, 4 * h, 4 * w, 3, device=DEV)
+    d_flow = torch.zeros(B, h, w, 2, device=DEV)
+    K.warp_s2d_backward(g.to(DEV), pre.detach().to(DEV), flow.detach().to(DEV), d_pre, d_flow, 0.5)
+    close(d_pre, pre.grad, 1e-4, "warp_s2d d_pre")
+    close(d_flow, flow.grad, 5e-4, "warp_s2d d_flow")
+
+
+def test_warp_s2d_zero_flow_is_exact_shuffle():
+    """Bit-exact: zero flow -> the s2d channels are exactly the reshuffled input."""
+    B, h, w = 2, 8, 8
+    pre, lr = rnd(B, 4 * h, 4 * w, 3, seed=1), rnd(B, h, w, 3, seed=3)
+    out = torch.empty(B, h, w, 56, device=DEV)
+    K.warp_s2d_forward(pre.to(DEV), torch.zeros(B, h, w, 2, device=DEV), lr.to(DEV), out, 1.0, 0.0)
+    assert torch.equal(out[..., 3:51].cpu(), O.space_to_depth4(pre))
+    assert torch.equal(out[..., :3].cpu(), lr)
+    assert torch.equal(out[..., 51:].cpu(), torch.zeros(B, h, w, 5))
+
+
+def test_warp_s2d_first_frame_and_symmetric_pad():
+    B, h, w = 1, 9, 12
+    lr = rnd(B, h, w, 3, seed=3)
+    out = torch.empty(B, h, w, 56, device=DEV)
+    K.warp_s2d_forward(None, None, lr.to(DEV), out, 0.5, 0.5)
+    close(out, oracle_gen_input(None, None, lr, 0.5, 0.5, 56), 0, "first frame")
+    pre = rnd(B, 4 * h, 4 * w, 3, seed=1)
+    flow = rnd(B, 8, 8, 2, seed=2, scale=2.0)     # h%8=1, w%8=4 rows/cols mirrored
+    K.warp_s2d_forward(pre.to(DEV), flow.to(DEV), lr.to(DEV), out, 1.0, 0.0)
+    close(out, oracle_gen_input(pre, flow, lr, 1.0, 0.0, 56), 2e-5, "symmetric-padded flow")
+
+
+def test_warp_plain_forward_backward():
+    B, H, W, Cc = 2, 16, 12, 3
+    img = rnd(B, H, W, Cc, seed=1).requires_grad_()
+    flow = rnd(B, H, W, 2, seed=2, scale=4.0).requires_grad_()
+    ref = O.dense_image_warp(img, flow)
+    out = torch.empty(B, H, W, Cc, device=DEV)
+    K.warp_forward(img.detach().to(DEV), flow.detach().to(DEV), out)
+    close(out, ref, 2e-5, "warp fwd")
+    g = rnd(B, H, W, Cc, seed=3)
+    ref.backward(g)
+    d_img = torch.zeros(B, H, W, Cc, device=DEV)
+    d_flow = torch.empty(B, H, W, 2, device=DEV)
+    K.warp_backward(g.to(DEV), img.detach().to(DEV), flow.detach().to(DEV), d_img, d_flow)
+    close(d_img, img.grad, 1e-4, "warp d_img")
+    close(d_flow, flow.grad, 1e-4, "warp d_flow")
+
+
+def test_warp_integer_flow_and_clamp():
+    """KAT: integer flow shifts; out-of-range queries clamp to the edge."""
+    B, H, W = 1, 8, 8
+    img = rnd(B, H, W, 3, seed=1)
+    flow = torch.zeros(B, H, W, 2)
+    flow[..., 0], flow[..., 1] = 2.0, -1.0
+    out = torch.empty(B, H, W, 3, device=DEV)
+    K.warp_forward(img.to(DEV), flow.to(DEV), out)
+    out = out.cpu()
+    assert torch.equal(out[0, 2:, :7], img[0, :6, 1:])
+    assert torch.equal(out[0, 0, :7], img[0, 0, 1:])     # clamped rows
+
+
+def test_upscale4_forward_backward():
+    x = rnd(2, 6, 5, 2, seed=1).requires_grad_()
+    ref = O.upscale_four(x * 4.0)
+    out = torch.empty(2, 24, 20, 2, device=DEV)
+    K.upscale4_forward(x.detach().to(DEV), out, 4.0)
+    close(out, ref, 1e-5, "upscale4 fwd")
+    g = rnd(2, 24, 20, 2, seed=2)
+    ref.backward(g)
+    d_in = torch.empty(2, 6, 5, 2, device=DEV)
+    K.upscale4_backward(g.to(DEV), d_in, 4.0)
+    close(d_in, x.grad, 1e-4, "upscale4 bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 9, 7, 64)])
+def test_maxpool_and_upsample2(shape, dtype):
+    x0 = rnd(*shape, seed=1).to(dtype).float()
+    x = x0.clone().requires_grad_()
+    N, H, W, Cc = shape
+    ref = O.maxpool(x)
+    out = torch.empty(N, H // 2, W // 2, Cc, device=DEV, dtype=dtype)
+    K.maxpool2_forward(x0.to(DEV, dtype), out)
+    assert torch.equal(out.float().cpu(), ref.detach())
+    g = rnd(*ref.shape, seed=2).to(dtype).float()
+    ref.backward(g)
+    d_in = torch.empty(*shape, device=DEV, dtype=dtype)
+    K.maxpool2_backward(x0.to(DEV, dtype), g.to(DEV, dtype), d_in)
+    assert torch.equal(d_in.float().cpu(), x.grad)
+    x = x0.clone().requires_grad_()
+    ref = O.upsample2_legacy(x)
+    out = torch.empty(N, 2 * H, 2 * W, Cc, device=DEV, dtype=dtype)
+    K.upsample2_forward(x0.to(DEV, dtype), out)
+    close(out, ref, 1e-6 if dtype == torch.float32 else 1e-2, "upsample2 fwd")
+    g = rnd(*ref.shape, seed=3).to(dtype).float()
+    ref.backward(g)
+    d_in = torch.empty(*shape, device=DEV, dtype=dtype)
+    K.upsample2_backward(g.to(DEV, dtype), d_in)
+    close(d_in, x.grad, 1e-5 if dtype == torch.float32 else 2e-2, "upsample2 bwd")
+
+
+def test_bicubic_add_preprocess():
+    B, h, w = 2, 7, 9
+    gen_in = rnd(B, h, w, 56, seed=1)
+    conv_out = rnd(B, 4 * h, 4 * w, 3, seed=2)
+    ref = O.preprocess(conv_out + O.bicubic_four(gen_in[..., :3]))
+    out = torch.empty(B, 4 * h, 4 * w, 3, device=DEV)
+    K.bicubic_add_preprocess(conv_out.to(DEV), gen_in.to(DEV), out)
+    close(out, ref, 2e-6, "bicubic epilogue")
+
+
+def test_bn_lrelu_forward_backward():
+    x = (rnd(6, 8, 8, 64, seed=1) * 2 + 0.7).requires_grad_()
+    beta = rnd(64, seed=2).requires_grad_()
+    y, mean, var = O.batchnorm(x, beta)
+    y = O.lrelu(y, 0.2)
+    xd = x.detach().to(DEV)
+    out = torch.empty_like(xd)
+    stats = torch.empty(2, 64, device=DEV)
+    moving = torch.stack((torch.zeros(64), torch.ones(64))).to(DEV)
+    K.bn_lrelu_forward(xd, out, beta.detach().to(DEV), 1e-3, 0.2, stats, moving)
+    close(out, y, 1e-5, "bn fwd")
+    close(stats[0], mean, 1e-5, "bn mean")
+    close(stats[1], var, 1e-5, "bn var")
+    n = 6 * 8 * 8
+    close(moving[0], mean * 0.1, 1e-5, "moving mean")
+    close(moving[1], 0.9 + var * (n / (n - 1)) * 0.1, 1e-5, "moving var")
+    g = rnd(*y.shape, seed=3)
+    y.backward(g)
+    dx = torch.empty_like(xd)
+    dbeta = torch.zeros(64, device=DEV)
+    ws = torch.empty(2, 64, device=DEV)
+    K.bn_lrelu_backward(xd, out, g.to(DEV), dx, stats, 1e-3, 0.2, dbeta, ws)
+    close(dx, x.grad, 1e-4, "bn dx")
+    close(dbeta, beta.grad, 1e-4, "bn dbeta")
+
+
+def test_adam_and_gate():
+    p, g = rnd(1000, seed=1), rnd(1000, seed=2)
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    import math
+    for t in (1, 2, 3):
+        O.adam_tf_step(pr, g, mr, vr, t, 5e-5)
+        lr_t = 5e-5 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        hyper = torch.tensor([lr_t, 0.9, 0.999, 1e-8, 1.0], device=DEV)
+        K.adam_tf(pd, g.to(DEV), md, vd, hyper)
+    close(pd, pr, 1e-6, "adam p")
+    close(vd, vr, 1e-6, "adam v")
+    before = pd.clone()
+    K.adam_tf(pd, g.to(DEV), md, vd, torch.tensor([1.0, 0.9, 0.999, 1e-8, 0.0], device=DEV))
+    assert torch.equal(pd, before)
+
+
+def test_act_backward_and_reductions():
+    y, g = rnd(3, 5, 7, 2, seed=1) * 20, rnd(3, 5, 7, 2, seed=2)
+    d = torch.empty(3, 5, 7, 2, device=DEV)
+    K.act_backward(g.to(DEV), y.to(DEV), d, ACT_TANH, 24.0)
+    close(d, g * (24.0 - y * y / 24.0), 1e-5, "tanh bwd")
+    a, b = rnd(4, 33, 17, 3, seed=3), rnd(4, 33, 17, 3, seed=4)
+    out = torch.zeros(2, device=DEV)
+    K.sum_sq_diff(a.to(DEV), b.to(DEV), 0.5, out[0:1])
+    K.sum_abs_diff(a.to(DEV), b.to(DEV), 2.0, out[1:2])
+    close(out[0], ((a - b) ** 2).sum() * 0.5, 1e-5, "sum sq")
+    close(out[1], (a - b).abs().sum() * 2.0, 1e-5, "sum abs")
+
+
+def test_pack_weights():
+    flat = rnd(9 * 8 * 16 + 16 * 4, seed=1).to(DEV)
+    tab = torch.tensor([[0, 0, 9, (8 << 32) | 16], [9 * 8 * 16, 9 * 8 * 16, 1, (16 << 32) | 4]], dtype=torch.int64,
+                       device=DEV)
+    for dtype in (torch.float32, torch.bfloat16):
+        dst = torch.empty(flat.numel(), device=DEV, dtype=dtype)
+        K.pack_weights(flat, dst, tab, 2, True)
+        ref0 = flat[:9 * 8 * 16].reshape(9, 8, 16).permute(0, 2, 1).reshape(-1).to(dtype)
+        ref1 = flat[9 * 8 * 16:].reshape(1, 16, 4).permute(0, 2, 1).reshape(-1).to(dtype)
+        assert torch.equal(dst[:9 * 8 * 16], ref0) and torch.equal(dst[9 * 8 * 16:], ref1)
+        K.pack_weights(flat, dst, tab, 2, False)
+        assert torch.equal(dst, flat.to(dtype))
