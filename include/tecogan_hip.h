@@ -83,15 +83,17 @@ int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*
  * conv_transpose:  X = dOut,        Y = layer input -> dW is [kh,kw,Cout,Cin] (lib/ops.py:35-44),
  *                  dbias must then be reduced over X (use tg_colsum).
  * x_dtype/y_dtype: TG_F32 / TG_BF16; accumulation and dW are always fp32. */
-int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, const void* y, int y_dtype,
-                  float* dw, float* dbias /*nullable*/, void* stream);
+int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, int ldx /*channel stride of x, 0 = Cin*/,
+                  const void* y, int y_dtype, int ldy /*0 = Cout*/, float* dw, float* dbias /*nullable*/,
+                  void* stream);
 
 /* out[c] += sum over rows of x[rows][C]  (bias gradient helper) */
 int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream);
 
-/* Weight re-layout: dst[tap][b][a] = (dst_dtype) src[tap][a][b]  (transpose=1) or a dtype-converting
- * copy (transpose=0), for `count` tensors described by the device table `tab`
- * (4 x int64 per tensor: src offset, dst offset (in elements), taps, then A<<32|B). */
+/* Weight re-layout for `count` tensors described by the device table `tab` (6 x int64 per tensor:
+ * src offset, dst offset (elements), taps, A, B, Apad).  src is [tap][A][B] fp32;
+ * transpose=1: dst[tap][b][a_pad] ; transpose=0: dst[tap][a_pad][b] ; rows a >= A are zero
+ * (channel padding of the first layers: 51->56, 6->8, 27->32, 3->8). */
 int tg_pack_weights(const float* src_base, void* dst_base, int dst_dtype, const int64_t* tab,
                     int count, int transpose, void* stream);
 
@@ -127,22 +129,41 @@ int tg_upscale4_backward(const float* d_out, float* d_in, int B, int h, int w, i
 
 /* slim.max_pool2d 2x2 s2 VALID (lib/ops.py:92-93).  bwd routes to the first max in scan order. */
 int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream);
+/* act/alpha: derivative of the activation that produced `in`, fused into the routed gradient. */
 int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W, int C,
-                         void* stream);
+                         int act, float alpha, void* stream);
 
 /* tf.image.resize_images x2, legacy bilinear (lib/frvsr.py:21-22). */
 int tg_upsample2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream);
-int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, int N, int H, int W, int C, void* stream);
+int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, int N, int H, int W, int C,
+                          const void* y /*nullable: activation output to mask with*/, int act, float alpha,
+                          void* stream);
 
 /* out = (conv_out + bicubic_four(lr)) * 2 - 1   (lib/frvsr.py:81-87, lib/ops.py:166-212).
  * lr is read from the first 3 channels of the generator input buffer [B,h,w,Cpad]. */
 int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void* gen_in, int in_dtype, int Cpad,
                               float* out, int B, int h, int w, void* stream);
 
-/* Pointwise activation gradient: d_in = d_out * act'(y) with y the activation OUTPUT
- * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask). */
-int tg_act_backward(const void* d_out, const void* y, void* d_in, int dtype, int64_t n, int act, float alpha,
-                    void* stream);
+/* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
+ * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.
+ * d_out and y share in_dtype; d_in has out_dtype. */
+int tg_act_backward(const void* d_out, const void* y /*nullable*/, void* d_in, int in_dtype, int out_dtype,
+                    int64_t n, int act, float alpha, float scale, void* stream);
+
+/* out[pix][0:Ca] = a ; [Ca:Ca+Cb] = b ; [Ca+Cb:Cpad] = 0  -- tf.concat of lib/Teco.py:108, main.py:209
+ * (fnet input) and the channel padding of first-layer inputs. */
+int tg_concat2_pad(const float* a, int Ca, const float* b /*nullable*/, int Cb, void* out, int out_dtype, int Cpad,
+                   int64_t npix, void* stream);
+
+/* out (=|+=) alpha*a + beta*b   (loss-gradient seeds: lib/Teco.py:320-331) */
+int tg_lincomb(const float* a, const float* b /*nullable*/, float* out, int64_t n, float alpha, float beta,
+               int accumulate, void* stream);
+
+/* Device-side schedule (lib/Teco.py:95-99,415-417,425,439-440,493-494): advances global_step, the
+ * lr decay, each optimiser's Adam bias correction and the EMA(0.99)/tf.cond D-gate; fills
+ * hyper[k] = {lr_t, beta1, beta2, eps, gate, lr, 0, 0} for tg_adam_tf.  state layout: schedule.hip. */
+int tg_schedule_step(double* state, float* hyper, int nopt, int gated_opt, const float* t_balance /*nullable*/,
+                     float beta1, float beta2, float eps, void* stream);
 
 /* slim.batch_norm(train, scale=False, eps) + LeakyReLU (lib/ops.py:88-90, lib/Teco.py:38-39).
  * stats: [2][C] fp32 (mean, biased var) written by forward, read by backward. */

@@ -29,7 +29,7 @@ _D = C.POINTER(ConvDesc)
 # name -> argtypes; every function returns int (0 = ok)
 SIGNATURES = {
     "tg_conv_forward": [_D, _P, _P, _P, _P, _P, _P, _P],
-    "tg_conv_wgrad": [_D, _P, _I, _P, _I, _P, _P, _P],
+    "tg_conv_wgrad": [_D, _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "tg_colsum": [_P, _I, _L, _I, _P, _P],
     "tg_pack_weights": [_P, _P, _I, _P, _I, _I, _P],
     "tg_warp_s2d_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
@@ -39,11 +39,14 @@ SIGNATURES = {
     "tg_upscale4_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
     "tg_upscale4_backward": [_P, _P, _I, _I, _I, _I, _F, _P],
     "tg_maxpool2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "tg_maxpool2_backward": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "tg_maxpool2_backward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "tg_upsample2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "tg_upsample2_backward": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tg_upsample2_backward": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P],
     "tg_bicubic_add_preprocess": [_P, _P, _I, _I, _P, _I, _I, _I, _P],
-    "tg_act_backward": [_P, _P, _P, _I, _L, _I, _F, _P],
+    "tg_act_backward": [_P, _P, _P, _I, _I, _L, _I, _F, _F, _P],
+    "tg_concat2_pad": [_P, _I, _P, _I, _P, _I, _I, _L, _P],
+    "tg_lincomb": [_P, _P, _P, _L, _F, _F, _I, _P],
+    "tg_schedule_step": [_P, _P, _I, _I, _P, _F, _F, _F, _P],
     "tg_bn_lrelu_forward": [_P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P],
     "tg_bn_lrelu_backward": [_P, _P, _P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P],
     "tg_adam_tf": [_P, _P, _P, _P, _L, _P, _F, _P],

@@ -21,6 +21,7 @@ struct WgradP {
   int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
   int M, chunk;     // total output pixels, pixels per block (multiple of 32)
   int ytiles;
+  int ldx, ldy;     // channel strides of X / Y in memory (>= Cx / Cy: zero-padded buffers)
 };
 
 template <typename TX, typename TY>
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         const int iy = oy * p.s - p.pt + kh, ix = ox * p.s - p.pl + kw;
         const int cx = cx0 + sgrp * 4, cy = cy0 + sgrp * 4;
         if (iy >= 0 && iy < p.Hx && ix >= 0 && ix < p.Wx && cx < p.Cx) {
-          const TX* px = gx + ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.Cx + cx;
+          const TX* px = gx + ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.ldx + cx;
           if (cx + 3 < p.Cx) {
             vx = make_float4(Elem<TX>::ld(px), Elem<TX>::ld(px + 1), Elem<TX>::ld(px + 2), Elem<TX>::ld(px + 3));
           } else {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
           }
         }
         if (cy < p.Cy) {
-          const TY* py = gy + (int64_t)m * p.Cy + cy;
+          const TY* py = gy + (int64_t)m * p.ldy + cy;
           if (cy + 3 < p.Cy) {
             vy = make_float4(Elem<TY>::ld(py), Elem<TY>::ld(py + 1), Elem<TY>::ld(py + 2), Elem<TY>::ld(py + 3));
           } else {
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   if (do_bias && tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, bsum);
 }
 
-extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, const void* y, int y_dtype,
-                             float* dw, float* dbias, void* stream) {
+extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, int ldx, const void* y, int y_dtype,
+                             int ldy, float* dw, float* dbias, void* stream) {
   TG_CHECK_ARG(d && x && y && dw, "null pointer");
   TG_CHECK_ARG(d->mode == 0, "descriptor must be the gather form");
   TG_CHECK_ARG(d->stride >= 1 && d->stride <= 2, "stride must be 1 or 2");
@@ -142,6 +143,9 @@ extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, 
   p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.M = d->N * d->Hout * d->Wout;
+  p.ldx = ldx > 0 ? ldx : d->Cin;
+  p.ldy = ldy > 0 ? ldy : d->Cout;
+  TG_CHECK_ARG(p.ldx >= d->Cin && p.ldy >= d->Cout, "channel stride smaller than channel count");
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;

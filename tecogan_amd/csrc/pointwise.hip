@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ in, const T* __restrict__ d_out,
-                                                           T* __restrict__ d_in, int N, int H, int W, int C) {
+                                                           T* __restrict__ d_in, int N, int H, int W, int C, int act,
+                                                           float alpha) {
   const int Ho = H / 2, Wo = W / 2;
   const int64_t n = (int64_t)N * H * W * C;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
           m = v[k];
           am = k;
         }
-      if (am == ((y & 1) * 2 + (x & 1))) g = Elem<T>::ld(d_out + ((int64_t)(b * Ho + oy) * Wo + ox) * C + c);
+      if (am == ((y & 1) * 2 + (x & 1)))  // `in` is the activation OUTPUT: fuse its derivative here
+        g = Elem<T>::ld(d_out + ((int64_t)(b * Ho + oy) * Wo + ox) * C + c) * act_grad_from_out(m, act, alpha);
     }
     Elem<T>::st(d_in + e, g);
   }
@@ -93,7 +95,8 @@ __device__ __forceinline__ int up2_terms(int i, int n, int* o, float* wgt) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const T* __restrict__ d_out, T* __restrict__ d_in, int N,
-                                                            int H, int W, int C) {
+                                                            int H, int W, int C, const T* __restrict__ y, int act,
+                                                            float alpha) {
   const int Ho = 2 * H, Wo = 2 * W;
   const int64_t n = (int64_t)N * H * W * C;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const T* __restrict_
     float s = 0.f;
     for (int a = 0; a < ny; ++a)
       for (int d = 0; d < nx; ++d) s += wy[a] * wx[d] * Elem<T>::ld(g + ((int64_t)oy[a] * Wo + ox[d]) * C);
+    if (y) s *= act_grad_from_out(Elem<T>::ld(y + e), act, alpha);
     Elem<T>::st(d_in + e, s);
   }
 }
@@ -157,11 +161,40 @@ __global__ __launch_bounds__(256) void bicubic_add_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ d_out, const T* __restrict__ y,
-                                                      T* __restrict__ d_in, int64_t n, int act, float alpha) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    Elem<T>::st(d_in + e, Elem<T>::ld(d_out + e) * act_grad_from_out(Elem<T>::ld(y + e), act, alpha));
+// d_in = scale * d_out * act'(y)   (y nullable -> plain scale + cast)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const TI* __restrict__ d_out, const TI* __restrict__ y,
+                                                      TO* __restrict__ d_in, int64_t n, int act, float alpha,
+                                                      float scale) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float g = Elem<TI>::ld(d_out + e) * scale;
+    if (y) g *= act_grad_from_out(Elem<TI>::ld(y + e), act, alpha);
+    Elem<TO>::st(d_in + e, g);
+  }
+}
+
+// out[pix][0:Ca] = a, [Ca:Ca+Cb] = b, rest 0  (builds the zero-padded NHWC inputs of the first convs)
+template <typename TO>
+__global__ __launch_bounds__(256) void concat2_pad_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b,
+                                                          int Cb, TO* __restrict__ out, int Cpad, int64_t npix) {
+  const int64_t n = npix * Cpad;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Cpad);
+    const int64_t pix = e / Cpad;
+    float v = 0.f;
+    if (c < Ca) v = a[pix * Ca + c];
+    else if (c < Ca + Cb) v = b[pix * Cb + c - Ca];
+    Elem<TO>::st(out + e, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, int64_t n, float alpha, float beta,
+                                                      int accumulate) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float v = alpha * a[e] + (b ? beta * b[e] : 0.f);
+    out[e] = accumulate ? out[e] + v : v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,20 +326,25 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
 template <typename TD>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src, TD* __restrict__ dst,
                                                            const int64_t* __restrict__ tab, int transpose) {
-  const int64_t* t = tab + (int64_t)blockIdx.y * 4;
+  const int64_t* t = tab + (int64_t)blockIdx.y * 6;
   const int64_t so = t[0], dof = t[1], taps = t[2];
-  const int A = (int)(t[3] >> 32), Bd = (int)(t[3] & 0xffffffff);
-  const int64_t n = taps * A * Bd;
+  const int A = (int)t[3], Bd = (int)t[4], Ap = (int)t[5];   // src [tap][A][B]; A zero-padded to Ap in dst
+  const int64_t n = taps * Ap * Bd;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    int64_t s = e;
-    if (transpose) {  // e indexes dst [tap][b][a]
-      const int a = (int)(e % A);
-      const int64_t r = e / A;
-      const int b = (int)(r % Bd);
-      const int64_t tap = r / Bd;
-      s = (tap * A + a) * Bd + b;
+    int a, b;
+    int64_t tap;
+    if (transpose) {  // e indexes dst [tap][b][a_pad]
+      a = (int)(e % Ap);
+      const int64_t r = e / Ap;
+      b = (int)(r % Bd);
+      tap = r / Bd;
+    } else {          // e indexes dst [tap][a_pad][b]
+      b = (int)(e % Bd);
+      const int64_t r = e / Bd;
+      a = (int)(r % Ap);
+      tap = r / Ap;
     }
-    Elem<TD>::st(dst + dof + e, src[so + s]);
+    Elem<TD>::st(dst + dof + e, a < A ? src[so + (tap * A + a) * Bd + b] : 0.f);
   }
 }
 
@@ -344,11 +382,11 @@ extern "C" int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, 
 }
 
 extern "C" int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W,
-                                    int C, void* stream) {
+                                    int C, int act, float alpha, void* stream) {
   TG_CHECK_ARG(in && d_out && d_in && N > 0 && H > 1 && W > 1 && C > 0, "bad argument");
   dim3 grid(grid_1d((int64_t)N * H * W * C, 256));
-  if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (const float*)d_out, (float*)d_in, N, H, W, C);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C);
+  if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (const float*)d_out, (float*)d_in, N, H, W, C, act, alpha);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -363,11 +401,11 @@ extern "C" int tg_upsample2_forward(const void* in, void* out, int dtype, int N,
 }
 
 extern "C" int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, int N, int H, int W, int C,
-                                     void* stream) {
+                                     const void* y, int act, float alpha, void* stream) {
   TG_CHECK_ARG(d_out && d_in && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
   dim3 grid(grid_1d((int64_t)N * H * W * C, 256));
-  if (dtype == TG_F32) hipLaunchKernelGGL((upsample2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (float*)d_in, N, H, W, C);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((upsample2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (u16*)d_in, N, H, W, C);
+  if (dtype == TG_F32) hipLaunchKernelGGL((upsample2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (float*)d_in, N, H, W, C, (const float*)y, act, alpha);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((upsample2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (u16*)d_in, N, H, W, C, (const u16*)y, act, alpha);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -382,13 +420,32 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
   TG_CHECK_LAUNCH();
 }
 
-extern "C" int tg_act_backward(const void* d_out, const void* y, void* d_in, int dtype, int64_t n, int act, float alpha,
-                               void* stream) {
-  TG_CHECK_ARG(d_out && y && d_in && n > 0, "bad argument");
+extern "C" int tg_act_backward(const void* d_out, const void* y, void* d_in, int in_dtype, int out_dtype, int64_t n,
+                               int act, float alpha, float scale, void* stream) {
+  TG_CHECK_ARG(d_out && d_in && n > 0, "bad argument");
   dim3 grid(grid_1d(n, 256));
-  if (dtype == TG_F32) hipLaunchKernelGGL((act_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (const float*)y, (float*)d_in, n, act, alpha);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((act_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (const u16*)y, (u16*)d_in, n, act, alpha);
+  if (in_dtype == TG_F32 && out_dtype == TG_F32) hipLaunchKernelGGL((act_bwd_kernel<float, float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (const float*)y, (float*)d_in, n, act, alpha, scale);
+  else if (in_dtype == TG_F32 && out_dtype == TG_BF16) hipLaunchKernelGGL((act_bwd_kernel<float, u16>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (const float*)y, (u16*)d_in, n, act, alpha, scale);
+  else if (in_dtype == TG_BF16 && out_dtype == TG_BF16) hipLaunchKernelGGL((act_bwd_kernel<u16, u16>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (const u16*)y, (u16*)d_in, n, act, alpha, scale);
+  else if (in_dtype == TG_BF16 && out_dtype == TG_F32) hipLaunchKernelGGL((act_bwd_kernel<u16, float>), grid, dim3(256), 0, ST(stream), (const u16*)d_out, (const u16*)y, (float*)d_in, n, act, alpha, scale);
   else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_concat2_pad(const float* a, int Ca, const float* b, int Cb, void* out, int out_dtype, int Cpad,
+                              int64_t npix, void* stream) {
+  TG_CHECK_ARG(a && out && Ca > 0 && Cb >= 0 && (b || Cb == 0) && Cpad >= Ca + Cb && npix > 0, "bad argument");
+  dim3 grid(grid_1d(npix * Cpad, 256));
+  if (out_dtype == TG_F32) hipLaunchKernelGGL((concat2_pad_kernel<float>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (float*)out, Cpad, npix);
+  else if (out_dtype == TG_BF16) hipLaunchKernelGGL((concat2_pad_kernel<u16>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (u16*)out, Cpad, npix);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+extern "C" int tg_lincomb(const float* a, const float* b, float* out, int64_t n, float alpha, float beta,
+                          int accumulate, void* stream) {
+  TG_CHECK_ARG(a && out && n > 0, "bad argument");
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, ST(stream), a, b, out, n, alpha, beta, accumulate);
   TG_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,197 @@
+"""Training engine: the FRVSR / TecoGAN step of reference lib/Teco.py:77-517 as ONE explicit kernel
+program (forward, hand-written backward, RCCL gradient all-reduce, device-side schedule, fused
+TF-Adam), captured once into a hipGraph and replayed per step -- no tracing compiler, no autograd tape,
+no host round trip inside a step (the tf.cond D-gate is a device-side predicate).
+
+Data layout: sequences are frame-major `[T, B, ...]` NHWC so that each recurrent frame, each FNet pair
+and each flow slab is a contiguous `[B, ...]` block.  Semantics that differ from the reference on
+purpose: all gradients are taken from the pre-update weights, then D (gate permitting), G and FNet
+are applied (the TF1 graph has an ordering race there).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+from .nets import DIS_CPAD, FNET_CPAD, GEN_CPAD, VGG_CPAD, VGG_TAPS, Discriminator, FNet, Generator, VGG19
+from .params import (ParamStore, discriminator_spec, fnet_spec, generator_spec, init_values, vgg_spec)
+
+LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_loss_3", "vgg_loss_4", "vgg_loss_5",
+              "t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output", "t_discrim_fake_output",
+              "D_layer_0_loss", "D_layer_1_loss", "D_layer_2_loss", "D_layer_3_loss"]
+LI = {n: i for i, n in enumerate(LOSS_NAMES)}
+
+
+class TrainEngine:
+    def __init__(self, flags, device="cuda", gan=True, act_dtype=torch.float32, seed=42, process_group=None,
+                 use_graph=True):
+        F = self.F = flags
+        self.dev, self.gan, self.act_dtype = torch.device(device), gan, act_dtype
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.B, self.T0, self.cs = F.batch_size, F.RNN_N, F.crop_size
+        self.T = 2 * self.T0 - 1 if F.pingpang else self.T0
+        self.use_vgg = F.vgg_scaling > 0
+        specs = OrderedDict()
+        specs["generator"] = generator_spec(F.num_resblock)
+        specs["fnet"] = fnet_spec()
+        if gan:
+            specs["tdiscriminator"] = discriminator_spec()
+        self.ps = ParamStore(specs, self.dev, act_dtype)
+        vals = OrderedDict()
+        vals.update(init_values(specs["generator"], seed))
+        vals.update(init_values(specs["fnet"], seed + 1))
+        if gan:
+            vals.update(init_values(specs["tdiscriminator"], seed + 2))
+        self.ps.load(vals)
+        self.G, self.Fn = Generator(self.ps, F.num_resblock), FNet(self.ps)
+        self.D = Discriminator(self.ps) if gan else None
+        if self.use_vgg:
+            self.vps = ParamStore(OrderedDict(vgg=vgg_spec()), self.dev, act_dtype, trainable=False)
+            self.vps.load(init_values(vgg_spec(), seed + 3, he_normal=True))
+            self.V = VGG19(self.vps)
+        # optimisers: index 0 = discriminator (gated) when present
+        self.opt_scopes = (["tdiscriminator"] if gan else []) + ["generator", "fnet"]
+        nopt = len(self.opt_scopes)
+        st = torch.zeros(8 + 2 * nopt, dtype=torch.float64)
+        st[2], st[3], st[4], st[5] = F.learning_rate, F.decay_step, F.decay_rate, 1.0 if F.stair else 0.0
+        st[6] = F.Dbalance
+        st[7] = 1.0 if F.Dt_mergeDs else 0.3                     # lib/Teco.py:423-424
+        self.sched = st.to(self.dev)
+        self.hyper = torch.zeros(nopt, 8, device=self.dev)
+        self.loss = torch.zeros(len(LOSS_NAMES), device=self.dev)
+        h = self.cs
+        self.in_lr = torch.zeros(self.B, self.T0, h, h, 3, device=self.dev)
+        self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
+        idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
+        self.seq_idx = torch.tensor(idx, device=self.dev)
+        self.graph = None
+        self.use_graph = use_graph
+        self.gen = None
+
+    # ------------------------------------------------------------------------------------------
+    def set_batch(self, r_inputs, r_targets):
+        """r_inputs [B,T0,h,w,3] in [0,1]; r_targets [B,T0,4h,4w,3] in [-1,1] (lib/Teco.py:78)."""
+        self.in_lr.copy_(r_inputs, non_blocking=True)
+        self.in_hr.copy_(r_targets, non_blocking=True)
+
+    def step(self, r_inputs=None, r_targets=None):
+        if r_inputs is not None:
+            self.set_batch(r_inputs, r_targets)
+        if not self.use_graph:
+            self._program()
+            return
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+
+    def _capture(self):
+        # warm-up run on a side stream (allocator pools, lazy module loads), with state restored afterwards
+        snap = [t.clone() for t in (self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper)]
+        moving = [m.clone() for m in self.D.moving] if self.gan else []
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._program()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, c in zip((self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper), snap):
+            t.copy_(c)
+        for m, c in zip(self.D.moving if self.gan else [], moving):
+            m.copy_(c)
+        self.ps.repack()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._program()
+
+    # ------------------------------------------------------------------------------------------
+    def _program(self):
+        F, ps, B, T, h = self.F, self.ps, self.B, self.T, self.cs
+        H = 4 * h
+        ps.grad.zero_()
+        self.loss.zero_()
+        lr_seq = self.in_lr.transpose(0, 1).index_select(0, self.seq_idx).contiguous()      # [T,B,h,h,3]
+        hr_seq = self.in_hr.transpose(0, 1).index_select(0, self.seq_idx).contiguous()      # [T,B,H,H,3]
+        npair = (T - 1) * B
+        # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
+        pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
+        cur_lr = lr_seq[1:].reshape(npair, h, h, 3)
+        fnet_in = K.concat2_pad(pre_lr, cur_lr, torch.empty(npair, h, h, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
+        flow, fsaved = self.Fn.forward(fnet_in)                                              # [npair,h,h,2] fp32
+        # ---- LR warp loss (lib/Teco.py:120-122,329-333) and its gradient to the flow ----------------
+        warped_lr = K.warp_forward(pre_lr, flow, torch.empty_like(pre_lr))
+        npx = float(npair * h * h)
+        K.sum_sq_diff(cur_lr, warped_lr, 1.0 / npx, self.loss[LI["l2_warp_loss"]:LI["l2_warp_loss"] + 1])
+        c = 2.0 * F.warp_scaling / npx
+        d_wl = K.lincomb(warped_lr, cur_lr, torch.empty_like(warped_lr), c, -c)
+        d_flow = torch.empty_like(flow)
+        K.warp_backward(d_wl, pre_lr, flow, None, d_flow)
+        # ---- recurrent generator (lib/Teco.py:125-155) ------------------------------------------------
+        gen = torch.empty(T, B, H, H, 3, device=self.dev)
+        flow_t = flow.view(T - 1, B, h, h, 2)
+        saved = []
+        for t in range(T):
+            x_in = torch.empty(B, h, h, GEN_CPAD, device=self.dev, dtype=self.act_dtype)
+            K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], x_in, 0.5, 0.5)
+            _, sv = self.G.forward(x_in, out=gen[t])
+            saved.append(sv)
+        self.gen = gen
+        # ---- generator losses seeded into d_gen -------------------------------------------------------
+        nhr = float(T * B * H * H)
+        K.sum_sq_diff(gen, hr_seq, 1.0 / nhr, self.loss[LI["l2_content_loss"]:LI["l2_content_loss"] + 1])
+        d_gen = K.lincomb(gen, hr_seq, torch.empty_like(gen), 2.0 / nhr, -2.0 / nhr)         # lib/Teco.py:320-322
+        if F.pingpang:
+            self._pingpong(gen, d_gen)
+        if self.use_vgg:
+            self._vgg(gen, hr_seq, d_gen)
+        if self.gan:
+            self._gan(gen, hr_seq, lr_seq, flow_t, d_gen)
+        # ---- backward through the recurrence ------------------------------------------------------------
+        d_flow_t = d_flow.view(T - 1, B, h, h, 2)
+        for t in range(T - 1, -1, -1):
+            dx = self.G.backward(saved[t], d_gen[t], need_dx=t > 0)
+            saved[t] = None
+            if t > 0:
+                K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
+        self.Fn.backward(fsaved, d_flow)
+        # ---- data-parallel exchange: one flat all-reduce per optimiser scope (RCCL over xGMI) -----------
+        if self.world > 1:
+            self._allreduce()
+        # ---- schedule, three TF-Adams, refresh compute copies -------------------------------------------
+        tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1] if self.gan else None
+        K.schedule_step(self.sched, self.hyper, len(self.opt_scopes), 0 if self.gan else -1, tb, F.beta, 0.999,
+                        F.adameps)
+        for k, scope in enumerate(self.opt_scopes):
+            a, b = ps.scope_range[scope]
+            K.adam_tf(ps.flat[a:b], ps.grad[a:b], ps.m[a:b], ps.v[a:b], self.hyper[k], 1.0 / self.world)
+        ps.repack()
+
+    # ------------------------------------------------------------------------------------------
+    def _allreduce(self):
+        import torch.distributed as dist
+        if self.gan:
+            # every rank must take the same D-gate branch: average t_balance first (1 float)
+            tbv = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
+            dist.all_reduce(tbv, group=self.pg)
+            tbv.mul_(1.0 / self.world)
+        for scope in self.opt_scopes:
+            a, b = self.ps.scope_range[scope]
+            dist.all_reduce(self.ps.grad[a:b], group=self.pg)     # sum; the 1/world is folded into Adam's grad_scale
+
+    def _pingpong(self, gen, d_gen):
+        raise NotImplementedError
+
+    def _vgg(self, gen, hr_seq, d_gen):
+        raise NotImplementedError
+
+    def _gan(self, gen, hr_seq, lr_seq, flow_t, d_gen):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------------------------------
+    def losses(self):
+        vals = self.loss.detach().cpu().tolist()
+        return OrderedDict(zip(LOSS_NAMES, vals))
+
+    def global_step(self):
+        return int(self.sched[0].item())

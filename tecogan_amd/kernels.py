@@ -48,8 +48,8 @@ def conv_forward(desc, x, w, bias, res, aux, out):
     return out
 
 
-def conv_wgrad(desc, x, y, dw, dbias):
-    check(lib().tg_conv_wgrad(C.byref(desc), _p(x), dt(x), _p(y), dt(y), _p(dw), _p(dbias), _stream()),
+def conv_wgrad(desc, x, y, dw, dbias, ldx=0, ldy=0):
+    check(lib().tg_conv_wgrad(C.byref(desc), _p(x), dt(x), ldx, _p(y), dt(y), ldy, _p(dw), _p(dbias), _stream()),
           "tg_conv_wgrad")
 
 
@@ -106,9 +106,9 @@ def maxpool2_forward(x, out):
     return out
 
 
-def maxpool2_backward(x, d_out, d_in):
+def maxpool2_backward(x, d_out, d_in, act=0, alpha=0.0):
     N, H, W, Cn = x.shape
-    check(lib().tg_maxpool2_backward(_p(x), _p(d_out), _p(d_in), dt(x), N, H, W, Cn, _stream()),
+    check(lib().tg_maxpool2_backward(_p(x), _p(d_out), _p(d_in), dt(x), N, H, W, Cn, act, alpha, _stream()),
           "tg_maxpool2_backward")
     return d_in
 
@@ -119,9 +119,9 @@ def upsample2_forward(x, out):
     return out
 
 
-def upsample2_backward(d_out, d_in):
+def upsample2_backward(d_out, d_in, y=None, act=0, alpha=0.0):
     N, H, W, Cn = d_in.shape
-    check(lib().tg_upsample2_backward(_p(d_out), _p(d_in), dt(d_in), N, H, W, Cn, _stream()),
+    check(lib().tg_upsample2_backward(_p(d_out), _p(d_in), dt(d_in), N, H, W, Cn, _p(y), act, alpha, _stream()),
           "tg_upsample2_backward")
     return d_in
 
@@ -133,10 +133,27 @@ def bicubic_add_preprocess(conv_out, gen_in, out):
     return out
 
 
-def act_backward(d_out, y, d_in, act, alpha):
-    check(lib().tg_act_backward(_p(d_out), _p(y), _p(d_in), dt(y), y.numel(), act, alpha, _stream()),
-          "tg_act_backward")
+def act_backward(d_out, y, d_in, act=0, alpha=0.0, scale=1.0):
+    check(lib().tg_act_backward(_p(d_out), _p(y), _p(d_in), dt(d_out), dt(d_in), d_out.numel(), act, alpha, scale,
+                                _stream()), "tg_act_backward")
     return d_in
+
+
+def concat2_pad(a, b, out):
+    Ca, Cb, Cpad = a.shape[-1], (b.shape[-1] if b is not None else 0), out.shape[-1]
+    check(lib().tg_concat2_pad(_p(a), Ca, _p(b), Cb, _p(out), dt(out), Cpad, out.numel() // Cpad, _stream()),
+          "tg_concat2_pad")
+    return out
+
+
+def lincomb(a, b, out, alpha, beta=0.0, accumulate=False):
+    check(lib().tg_lincomb(_p(a), _p(b), _p(out), a.numel(), alpha, beta, int(accumulate), _stream()), "tg_lincomb")
+    return out
+
+
+def schedule_step(state, hyper, nopt, gated_opt, t_balance, beta1, beta2, eps):
+    check(lib().tg_schedule_step(_p(state), _p(hyper), nopt, gated_opt, _p(t_balance), beta1, beta2, eps, _stream()),
+          "tg_schedule_step")
 
 
 def bn_lrelu_forward(x, y, beta, eps, alpha, stats, moving):

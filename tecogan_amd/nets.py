@@ -1,0 +1,337 @@
+"""FNet, generator_F, discriminator_F and VGG-19 as explicit kernel schedules (forward + hand-written
+backward) over the C-ABI kernels -- no autograd graph, no tracing: every launch below is an enqueue on
+the current HIP stream, so a whole training step is one capturable hipGraph.
+
+Fusion plan (what the reference runs as separate TF ops, lib/frvsr.py / lib/Teco.py / lib/ops.py):
+  forward : conv + bias + {ReLU | LeakyReLU | tanh*24 | sigmoid} + residual add    -> one MFMA kernel
+  backward: bwd_data + residual-gradient add + act'(saved output) of the PRODUCER   -> one MFMA kernel
+            maxpool/upsample backward also apply the producer's LeakyReLU derivative
+  weights : gradients are accumulated straight into the flat fp32 gradient buffer (ParamStore.grad).
+Activations are NHWC in `ps.act_dtype` (fp32 parity mode / bf16 throughput mode); network outputs
+that feed losses or the recurrence (HR frame, flow, D probability) are fp32.
+"""
+import torch
+
+from . import kernels as K
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from .params import DIS_BLOCKS, FNET_BLOCKS, VGG_CFG, pad8
+
+_F32 = torch.float32
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------------
+# layer primitives
+# --------------------------------------------------------------------------------------------------
+def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None):
+    """slim.conv2d SAME (reference lib/ops.py:47-56) + fused epilogue.  x [N,H,W,Cin_pad]."""
+    e = ps.entries[wname]
+    N, H, W, Cp = x.shape
+    assert Cp == e["Apad"], (wname, Cp, e["Apad"])
+    k = e["k"]
+    Ho, pt = K.same_pad(H, k, stride)
+    Wo, pl = K.same_pad(W, k, stride)
+    out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
+    d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha)
+    K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
+    return out
+
+
+def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=ACT_NONE, mask_alpha=0.0):
+    """Input gradient of conv_fwd: transposed mode over the natural (HWIO) copy.  -> [N,H,W,Cin_pad]."""
+    e = ps.entries[wname]
+    N, Ho, Wo, Co = dy.shape
+    H, W = in_hw
+    k = e["k"]
+    _, pt = K.same_pad(H, k, stride)
+    _, pl = K.same_pad(W, k, stride)
+    dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy)
+    d = K.conv_desc(N, Ho, Wo, Co, H, W, e["Apad"], k, k, stride, pt, pl, 1, K.dt(dy), K.dt(dx), 0, 0.0,
+                    mask_act, mask_alpha)
+    K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)
+    return dx
+
+
+def conv_wgrad(ps, wname, bname, x, dy, stride=1):
+    """dW (HWIO) and dbias accumulated into the flat gradient buffer."""
+    e = ps.entries[wname]
+    N, H, W, Cp = x.shape
+    _, Ho, Wo, Co = dy.shape
+    k = e["k"]
+    _, pt = K.same_pad(H, k, stride)
+    _, pl = K.same_pad(W, k, stride)
+    d = K.conv_desc(N, H, W, e["A"], Ho, Wo, Co, k, k, stride, pt, pl, 0, 0, 0)
+    K.conv_wgrad(d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, ldx=Cp, ldy=Co)
+
+
+def deconv_fwd(ps, wname, bname, x, act=ACT_NONE, alpha=0.0):
+    """slim.conv2d_transpose k3 s2 SAME (reference lib/ops.py:35-44, [TF1] A.2): transposed mode, pad 0."""
+    e = ps.entries[wname]                      # TF layout [kh,kw,Cout,Cin] -> A = Cout, B = Cin
+    N, H, W, Ci = x.shape
+    k = e["k"]
+    out = _empty((N, 2 * H, 2 * W, e["A"]), ps.act_dtype, x)
+    d = K.conv_desc(N, H, W, Ci, 2 * H, 2 * W, e["A"], k, k, 2, 0, 0, 1, K.dt(x), K.dt(out), act, alpha)
+    K.conv_forward(d, x, ps.packed(wname, False), ps.view(bname), None, None, out)
+    return out
+
+
+def deconv_bwd_data(ps, wname, dy, aux=None, mask_act=ACT_NONE, mask_alpha=0.0):
+    e = ps.entries[wname]
+    N, H2, W2, Co = dy.shape
+    k = e["k"]
+    dx = _empty((N, H2 // 2, W2 // 2, e["B"]), ps.act_dtype, dy)
+    d = K.conv_desc(N, H2, W2, Co, H2 // 2, W2 // 2, e["B"], k, k, 2, 0, 0, 0, K.dt(dy), K.dt(dx), 0, 0.0,
+                    mask_act, mask_alpha)
+    K.conv_forward(d, dy, ps.packed(wname, True), None, None, aux, dx)
+    return dx
+
+
+def deconv_wgrad(ps, wname, bname, x, dy):
+    """dW in TF [kh,kw,Cout,Cin] layout: X := dy (gathered, stride 2), Y := x; dbias = colsum(dy)."""
+    e = ps.entries[wname]
+    N, H2, W2, Co = dy.shape
+    k = e["k"]
+    d = K.conv_desc(N, H2, W2, Co, H2 // 2, W2 // 2, e["B"], k, k, 2, 0, 0, 0, 0, 0)
+    K.conv_wgrad(d, dy, x, ps.gview(wname), None)
+    K.colsum(dy, dy.numel() // Co, Co, ps.gview(bname))
+
+
+# --------------------------------------------------------------------------------------------------
+# generator_F -- reference lib/frvsr.py:44-88
+# --------------------------------------------------------------------------------------------------
+GEN_CPAD = pad8(51)
+
+
+class Generator:
+    P = "generator/generator_unit/"
+
+    def __init__(self, ps, num_resblock):
+        self.ps, self.nres = ps, num_resblock
+
+    def forward(self, x_in, keep=True, out=None):
+        """x_in [B,h,w,56] (LR frame | s2d(warped prev HR) | 0-pad) -> HR frame [B,4h,4w,3] fp32 in [-1,1]."""
+        ps, p = self.ps, self.P
+        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU)
+        acts = [a]
+        for i in range(1, self.nres + 1):
+            s = p + "resblock_%d/" % i
+            r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU)
+            a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a)
+            acts += [r, a]
+        s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
+        t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU)
+        t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU)
+        c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1,
+                     out_dtype=_F32)
+        out = K.bicubic_add_preprocess(c, x_in, torch.empty_like(c) if out is None else out)  # (c+bicubic(LR))*2-1
+        saved = (x_in, acts, t1, t2) if keep else None
+        return out, saved
+
+    def backward(self, saved, d_out, need_dx=True):
+        """d_out: gradient w.r.t. the HR frame (fp32).  Accumulates weight gradients; returns d x_in or None."""
+        ps, p = self.ps, self.P
+        x_in, acts, t1, t2 = saved
+        h, w = x_in.shape[1], x_in.shape[2]
+        dc = K.act_backward(d_out, None, _empty(d_out.shape, ps.act_dtype, d_out), scale=2.0)   # d/dc of (.)*2-1
+        wn, bn = p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases"
+        conv_wgrad(ps, wn, bn, t2, dc)
+        g = conv_bwd_data(ps, wn, dc, (4 * h, 4 * w), 1, aux=t2, mask_act=ACT_RELU)            # d pre-ReLU of tran2
+        s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
+        deconv_wgrad(ps, s % 2 + "weights", s % 2 + "biases", t1, g)
+        g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=t1, mask_act=ACT_RELU)               # d pre-ReLU of tran1
+        a_last = acts[-1]
+        deconv_wgrad(ps, s % 1 + "weights", s % 1 + "biases", a_last, g)
+        g = deconv_bwd_data(ps, s % 1 + "weights", g)                                          # d a_N
+        for i in range(self.nres, 0, -1):
+            sc = p + "resblock_%d/" % i
+            a_prev, r = acts[2 * i - 2], acts[2 * i - 1]
+            conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", r, g)
+            dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=r, mask_act=ACT_RELU)
+            conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", a_prev, dr)
+            # d a_prev = bwd(conv_1)(dr) + skip gradient; the first block's input is itself a ReLU output
+            g = conv_bwd_data(ps, sc + "conv_1/Conv/weights", dr, (h, w), 1, res=g,
+                              aux=a_prev if i == 1 else None, mask_act=ACT_RELU if i == 1 else ACT_NONE)
+        if self.nres == 0:
+            g = K.act_backward(g, acts[0], torch.empty_like(g), ACT_RELU)
+        wn, bn = p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases"
+        conv_wgrad(ps, wn, bn, x_in, g)
+        return conv_bwd_data(ps, wn, g, (h, w), 1) if need_dx else None
+
+
+# --------------------------------------------------------------------------------------------------
+# fnet -- reference lib/frvsr.py:4-41
+# --------------------------------------------------------------------------------------------------
+FNET_CPAD = pad8(6)
+
+
+class FNet:
+    P = "fnet/autoencode_unit/"
+
+    def __init__(self, ps):
+        self.ps = ps
+
+    def forward(self, x, keep=True):
+        """x [N,h,w,8] (prev LR | cur LR | 0-pad) -> flow [N,h',w',2] fp32 (h' = h - h%8)."""
+        ps, p = self.ps, self.P
+        saved = []
+        net = x
+        for name, _, _ in FNET_BLOCKS:
+            s = p + name
+            c1 = conv_fwd(ps, s + "/conv_1/Conv/weights", s + "/conv_1/Conv/biases", net, 1, ACT_LRELU, 0.2)
+            c2 = conv_fwd(ps, s + "/conv_2/Conv/weights", s + "/conv_2/Conv/biases", c1, 1, ACT_LRELU, 0.2)
+            N, H, W, Cc = c2.shape
+            if name.startswith("encoder"):
+                nxt = K.maxpool2_forward(c2, _empty((N, H // 2, W // 2, Cc), c2.dtype, c2))
+            else:
+                nxt = K.upsample2_forward(c2, _empty((N, 2 * H, 2 * W, Cc), c2.dtype, c2))
+            saved.append((net, c1, c2))
+            net = nxt
+        s = p + "output_stage/"
+        o1 = conv_fwd(ps, s + "conv1/Conv/weights", s + "conv1/Conv/biases", net, 1, ACT_LRELU, 0.2)
+        flow = conv_fwd(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, 1, ACT_TANH, 24.0, out_dtype=_F32)
+        return flow, ((saved, net, o1, flow) if keep else None)
+
+    def backward(self, saved_all, d_flow):
+        ps, p = self.ps, self.P
+        saved, net_last, o1, flow = saved_all
+        s = p + "output_stage/"
+        g = K.act_backward(d_flow, flow, _empty(flow.shape, ps.act_dtype, flow), ACT_TANH, 24.0)
+        conv_wgrad(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, g)
+        g = conv_bwd_data(ps, s + "conv2/Conv/weights", g, o1.shape[1:3], 1, aux=o1, mask_act=ACT_LRELU, mask_alpha=0.2)
+        conv_wgrad(ps, s + "conv1/Conv/weights", s + "conv1/Conv/biases", net_last, g)
+        g = conv_bwd_data(ps, s + "conv1/Conv/weights", g, net_last.shape[1:3], 1)          # d (resampled map)
+        for bi in range(len(FNET_BLOCKS) - 1, -1, -1):
+            name = FNET_BLOCKS[bi][0]
+            sc = p + name
+            x_in, c1, c2 = saved[bi]
+            if name.startswith("encoder"):
+                g = K.maxpool2_backward(c2, g, torch.empty_like(c2), ACT_LRELU, 0.2)
+            else:
+                g = K.upsample2_backward(g, torch.empty_like(c2), c2, ACT_LRELU, 0.2)
+            conv_wgrad(ps, sc + "/conv_2/Conv/weights", sc + "/conv_2/Conv/biases", c1, g)
+            g = conv_bwd_data(ps, sc + "/conv_2/Conv/weights", g, c1.shape[1:3], 1, aux=c1, mask_act=ACT_LRELU,
+                              mask_alpha=0.2)
+            conv_wgrad(ps, sc + "/conv_1/Conv/weights", sc + "/conv_1/Conv/biases", x_in, g)
+            if bi > 0:
+                g = conv_bwd_data(ps, sc + "/conv_1/Conv/weights", g, x_in.shape[1:3], 1)
+        return None
+
+
+# --------------------------------------------------------------------------------------------------
+# discriminator_F -- reference lib/Teco.py:30-74
+# --------------------------------------------------------------------------------------------------
+DIS_CPAD = pad8(27)
+
+
+class Discriminator:
+    P = "tdiscriminator/discriminator_unit/"
+
+    def __init__(self, ps):
+        self.ps = ps
+        dev = ps.device
+        # [mean, var] moving statistics per block ([TF1] A.7; updated, never read by the path)
+        self.moving = [torch.stack((torch.zeros(co), torch.ones(co))).to(dev).contiguous() for _, _, co in DIS_BLOCKS]
+
+    def forward(self, x, keep=True, update_moving=True):
+        """x [tb,H,W,32] -> (prob [tb,H/16,W/16,1] fp32, [4 layer maps], saved)."""
+        ps, p = self.ps, self.P
+        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x, 1, ACT_LRELU, 0.2)
+        saved, layers, net = [], [], a
+        for bi, (name, _, co) in enumerate(DIS_BLOCKS):
+            c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2)
+            y = torch.empty_like(c)
+            stats = _empty((2, co), _F32, c)
+            K.bn_lrelu_forward(c, y, ps.view(p + name + "/BatchNorm/beta"), 1e-3, 0.2, stats,
+                               self.moving[bi] if update_moving else None)
+            saved.append((net, c, y, stats))
+            layers.append(y)
+            net = y
+        prob = conv_fwd(ps, p + "dense_layer_2/dense/kernel", p + "dense_layer_2/dense/bias", net, 1, ACT_SIGMOID,
+                        out_dtype=_F32)
+        return prob, layers, ((x, a, saved, prob) if keep else None)
+
+    def backward(self, saved_all, d_prob, d_layers=None, wgrad=True, need_dx=False):
+        """d_prob fp32 [tb,h,w,1]; d_layers: optional list of 4 gradients (act dtype) w.r.t. the layer maps.
+        wgrad=False leaves the discriminator's own gradients untouched (generator-side pass)."""
+        ps, p = self.ps, self.P
+        x, a, saved, prob = saved_all
+        g = K.act_backward(d_prob, prob, _empty(prob.shape, ps.act_dtype, prob), ACT_SIGMOID)
+        wn, bn = p + "dense_layer_2/dense/kernel", p + "dense_layer_2/dense/bias"
+        y_last = saved[-1][2]
+        if wgrad:
+            conv_wgrad(ps, wn, bn, y_last, g)
+        g = conv_bwd_data(ps, wn, g, y_last.shape[1:3], 1, res=d_layers[3] if d_layers else None)
+        for bi in range(len(DIS_BLOCKS) - 1, -1, -1):
+            name, _, co = DIS_BLOCKS[bi]
+            net_in, c, y, stats = saved[bi]
+            ws = _empty((2, co), _F32, c)
+            dbeta = ps.gview(p + name + "/BatchNorm/beta") if wgrad else None
+            dcv = K.bn_lrelu_backward(c, y, g, torch.empty_like(c), stats, 1e-3, 0.2, dbeta, ws)
+            if wgrad:
+                conv_wgrad(ps, p + name + "/conv1/Conv/weights", None, net_in, dcv, 2)
+            if bi > 0:
+                g = conv_bwd_data(ps, p + name + "/conv1/Conv/weights", dcv, net_in.shape[1:3], 2,
+                                  res=d_layers[bi - 1] if d_layers else None)
+            else:   # net_in = a = lrelu(input conv)
+                g = conv_bwd_data(ps, p + name + "/conv1/Conv/weights", dcv, net_in.shape[1:3], 2, aux=a,
+                                  mask_act=ACT_LRELU, mask_alpha=0.2)
+        wn, bn = p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases"
+        if wgrad:
+            conv_wgrad(ps, wn, bn, x, g)
+        return conv_bwd_data(ps, wn, g, x.shape[1:3], 1) if need_dx else None
+
+
+# --------------------------------------------------------------------------------------------------
+# VGG-19 feature taps -- reference lib/Teco.py:5-24, lib/ops.py:287-334 (weights frozen, main.py:322-324)
+# --------------------------------------------------------------------------------------------------
+VGG_TAPS = ("vgg_19/conv2/conv2_2", "vgg_19/conv3/conv3_4", "vgg_19/conv4/conv4_4", "vgg_19/conv5/conv5_4")
+VGG_CPAD = pad8(3)
+
+
+class VGG19:
+    def __init__(self, ps):
+        self.ps = ps
+
+    def forward(self, x, keep=True):
+        """x [N,H,W,8]: VGG-preprocessed image (lib/Teco.py:9-10) zero-padded to 8 channels.
+        Returns the four post-ReLU taps (un-normalised) and the activations for backward."""
+        ps = self.ps
+        net, acts, taps = x, [], {}
+        for blk, reps, _, _ in VGG_CFG:
+            for j in range(1, reps + 1):
+                key = "vgg_19/conv%d/conv%d_%d" % (blk, blk, j)
+                inp = net
+                net = conv_fwd(ps, key + "/weights", key + "/biases", inp, 1, ACT_RELU)
+                acts.append((key, inp, net))
+                if key in VGG_TAPS:
+                    taps[key] = net
+            if key == VGG_TAPS[-1]:
+                break
+            N, H, W, Cc = net.shape
+            pooled = K.maxpool2_forward(net, _empty((N, H // 2, W // 2, Cc), net.dtype, net))
+            acts.append(("pool%d" % blk, net, pooled))
+            net = pooled
+        return taps, (acts if keep else None)
+
+    def backward(self, acts, d_taps):
+        """d_taps: key -> gradient w.r.t. the (post-ReLU) tap.  Returns d x [N,H,W,8] (dX only: the VGG
+        weights are frozen).  `g` is always the gradient w.r.t. a conv's PRE-activation: the ReLU
+        derivative of the producing layer is fused into the consumer's bwd_data epilogue (conv -> conv)
+        or into the max-pool backward (conv -> pool)."""
+        ps = self.ps
+        g = None
+        for idx in range(len(acts) - 1, -1, -1):
+            key, inp, out = acts[idx]
+            if key.startswith("pool"):
+                g = K.maxpool2_backward(inp, g, torch.empty_like(inp), ACT_RELU, 0.0)
+                continue
+            if key in d_taps:                      # every tap is followed by a pool or is the last layer
+                t = K.act_backward(d_taps[key], out, torch.empty_like(out), ACT_RELU)
+                g = t if g is None else g.add_(t)
+            producer_is_conv = idx > 0 and not acts[idx - 1][0].startswith("pool")
+            g = conv_bwd_data(ps, key + "/weights", g, inp.shape[1:3], 1, aux=inp if producer_is_conv else None,
+                              mask_act=ACT_RELU if producer_is_conv else ACT_NONE)
+        return g

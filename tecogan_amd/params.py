@@ -1,0 +1,191 @@
+"""Flat parameter store for the FRVSR/TecoGAN networks (MI355X layout).
+
+All trainable parameters of a run live in ONE fp32 device buffer (`flat`), ordered by optimiser scope
+(generator | fnet | tdiscriminator, reference lib/Teco.py:421,441-442), with matching flat gradient /
+Adam-m / Adam-v buffers.  The gradient buffer is what the conv weight-gradient kernels accumulate
+into (fp32 atomics), what the fused TF-Adam kernel consumes, and what RCCL all-reduces -- no per-tensor
+copies anywhere.  Individual parameters are views keyed by the reference's TF variable names
+ so checkpoints interchange.
+
+The MFMA convolution engine reads weights as [tap][out][in] panels; `repack()` produces, in two
+launches for the whole store, the transposed (`wT`) and natural (`wN`) compute copies in the
+activation dtype with first-layer input channels zero-padded to a multiple of 8.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+
+SCOPES = ("generator", "fnet", "tdiscriminator")
+
+FNET_BLOCKS = [("encoder_1", 6, 32), ("encoder_2", 32, 64), ("encoder_3", 64, 128),
+               ("decoder_1", 128, 256), ("decoder_2", 256, 128), ("decoder_3", 128, 64)]
+DIS_BLOCKS = [("disblock_1", 64, 64), ("disblock_3", 64, 64), ("disblock_5", 64, 128), ("disblock_7", 128, 256)]
+VGG_CFG = [(1, 2, 3, 64), (2, 2, 64, 128), (3, 4, 128, 256), (4, 4, 256, 512), (5, 4, 512, 512)]
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def generator_spec(num_resblock, cin=51, cout=3):
+    """Variables of generator_F (reference lib/frvsr.py:44-88)."""
+    s, p = OrderedDict(), "generator/generator_unit/"
+    s[p + "input_stage/conv/Conv/weights"] = (3, 3, cin, 64)
+    s[p + "input_stage/conv/Conv/biases"] = (64,)
+    for i in range(1, num_resblock + 1):
+        for j in (1, 2):
+            s[p + "resblock_%d/conv_%d/Conv/weights" % (i, j)] = (3, 3, 64, 64)
+            s[p + "resblock_%d/conv_%d/Conv/biases" % (i, j)] = (64,)
+    for j in (1, 2):
+        s[p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/weights" % j] = (3, 3, 64, 64)
+        s[p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/biases" % j] = (64,)
+    s[p + "output_stage/conv/Conv/weights"] = (3, 3, 64, cout)
+    s[p + "output_stage/conv/Conv/biases"] = (cout,)
+    return s
+
+
+def fnet_spec():
+    """Variables of fnet (reference lib/frvsr.py:4-41)."""
+    s, p = OrderedDict(), "fnet/autoencode_unit/"
+    for name, cin, cout in FNET_BLOCKS:
+        s[p + name + "/conv_1/Conv/weights"] = (3, 3, cin, cout)
+        s[p + name + "/conv_1/Conv/biases"] = (cout,)
+        s[p + name + "/conv_2/Conv/weights"] = (3, 3, cout, cout)
+        s[p + name + "/conv_2/Conv/biases"] = (cout,)
+    s[p + "output_stage/conv1/Conv/weights"] = (3, 3, 64, 32)
+    s[p + "output_stage/conv1/Conv/biases"] = (32,)
+    s[p + "output_stage/conv2/Conv/weights"] = (3, 3, 32, 2)
+    s[p + "output_stage/conv2/Conv/biases"] = (2,)
+    return s
+
+
+def discriminator_spec(cin=27):
+    """Trainable variables of discriminator_F (reference lib/Teco.py:30-74)."""
+    s, p = OrderedDict(), "tdiscriminator/discriminator_unit/"
+    s[p + "input_stage/conv/Conv/weights"] = (3, 3, cin, 64)
+    s[p + "input_stage/conv/Conv/biases"] = (64,)
+    for name, ci, co in DIS_BLOCKS:
+        s[p + name + "/conv1/Conv/weights"] = (4, 4, ci, co)
+        s[p + name + "/BatchNorm/beta"] = (co,)
+    s[p + "dense_layer_2/dense/kernel"] = (256, 1)
+    s[p + "dense_layer_2/dense/bias"] = (1,)
+    return s
+
+
+def vgg_spec():
+    """Variables of vgg_19 up to conv5_4 (reference lib/ops.py:319-327)."""
+    s = OrderedDict()
+    for blk, reps, cin, cout in VGG_CFG:
+        for j in range(1, reps + 1):
+            s["vgg_19/conv%d/conv%d_%d/weights" % (blk, blk, j)] = (3, 3, cin if j == 1 else cout, cout)
+            s["vgg_19/conv%d/conv%d_%d/biases" % (blk, blk, j)] = (cout,)
+    return s
+
+
+def init_values(spec, seed, he_normal=False):
+    """Seeded xavier-uniform (reference lib/ops.py:40,52) / zeros; float64 draws from a torch.Generator
+    in spec order, cast to fp32 -- the same stream the test oracle uses, so weights match bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    for name, shape in spec.items():
+        if len(shape) == 1:
+            out[name] = torch.zeros(shape)
+            continue
+        if len(shape) == 4:
+            rf = shape[0] * shape[1]
+            fan_in, fan_out = rf * shape[2], rf * shape[3]
+            if "Conv2d_transpose" in name:
+                fan_in, fan_out = rf * shape[3], rf * shape[2]
+        else:
+            fan_in, fan_out = shape
+        if he_normal:
+            w = torch.randn(shape, generator=g, dtype=torch.float64) * math.sqrt(2.0 / fan_in)
+        else:
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            w = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * lim
+        out[name] = w.float()
+    return out
+
+
+class ParamStore:
+    """One flat fp32 buffer + compute copies.  `specs`: OrderedDict scope -> OrderedDict(name -> shape)."""
+
+    def __init__(self, specs, device, act_dtype=torch.float32, trainable=True):
+        self.device, self.act_dtype, self.trainable = device, act_dtype, trainable
+        self.entries = OrderedDict()
+        self.scope_range = OrderedDict()
+        off = poff = 0
+        rows = []
+        for scope, spec in specs.items():
+            start = off
+            for name, shape in spec.items():
+                n = 1
+                for d in shape:
+                    n *= d
+                e = dict(offset=off, shape=tuple(shape), numel=n, scope=scope, packed=None)
+                if len(shape) in (2, 4):
+                    shp = shape if len(shape) == 4 else (1, 1) + tuple(shape)
+                    taps, A, Bd = shp[0] * shp[1], shp[2], shp[3]
+                    Ap = pad8(A)
+                    e.update(packed=poff, taps=taps, A=A, B=Bd, Apad=Ap, k=shp[0])
+                    rows.append([off, poff, taps, A, Bd, Ap])
+                    poff += (taps * Ap * Bd + 7) // 8 * 8          # keep every packed tensor 16-B aligned
+                self.entries[name] = e
+                off += n
+            off = (off + 3) // 4 * 4                               # 16-B aligned scope boundaries
+            self.scope_range[scope] = (start, off)
+        self.numel, self.packed_numel = off, poff
+        self.flat = torch.zeros(off, device=device)
+        if trainable:
+            self.grad = torch.zeros(off, device=device)
+            self.m = torch.zeros(off, device=device)
+            self.v = torch.zeros(off, device=device)
+        self.wT = torch.zeros(max(poff, 8), device=device, dtype=act_dtype)
+        self.wN = torch.zeros(max(poff, 8), device=device, dtype=act_dtype)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=device).contiguous()
+        self.ntab = len(rows)
+
+    # ---- views ------------------------------------------------------------------------------
+    def view(self, name, buf=None):
+        e = self.entries[name]
+        b = self.flat if buf is None else buf
+        return b[e["offset"]:e["offset"] + e["numel"]].view(e["shape"])
+
+    def gview(self, name):
+        return self.view(name, self.grad)
+
+    def packed(self, name, transposed):
+        """Compute copy of a weight: [tap][B][Apad] if transposed else [tap][Apad][B] (flat view)."""
+        e = self.entries[name]
+        n = e["taps"] * e["Apad"] * e["B"]
+        return (self.wT if transposed else self.wN)[e["packed"]:e["packed"] + n]
+
+    def scope_slice(self, scope, buf):
+        a, b = self.scope_range[scope]
+        return buf[a:b]
+
+    # ---- state ------------------------------------------------------------------------------
+    def load(self, values):
+        """values: name -> CPU/GPU tensor with the TF shape."""
+        for name, t in values.items():
+            if name not in self.entries:
+                raise KeyError("unknown variable " + name)
+            if tuple(t.shape) != self.entries[name]["shape"]:
+                raise ValueError("shape mismatch for %s: %s vs %s" % (name, tuple(t.shape), self.entries[name]["shape"]))
+            self.view(name).copy_(t.to(self.device, torch.float32))
+        self.repack()
+
+    def state_dict(self):
+        return OrderedDict((n, self.view(n).detach().cpu().clone()) for n in self.entries)
+
+    def repack(self):
+        """Refresh both compute copies from the fp32 master (two launches for the whole store)."""
+        if self.ntab:
+            K.pack_weights(self.flat, self.wT, self.table, self.ntab, True)
+            K.pack_weights(self.flat, self.wN, self.table, self.ntab, False)
+
+    def zero_grad(self):
+        self.grad.zero_()

@@ -356,7 +356,7 @@ def test_adam_and_gate():
 def test_act_backward_and_reductions():
     y, g = rnd(3, 5, 7, 2, seed=1) * 20, rnd(3, 5, 7, 2, seed=2)
     d = torch.empty(3, 5, 7, 2, device=DEV)
-    K.act_backward(g.to(DEV), y.to(DEV), d, ACT_TANH, 24.0)
+    K.act_backward(g.to(DEV), y.to(DEV), d, ACT_TANH, 24.0, 1.0)
     close(d, g * (24.0 - y * y / 24.0), 1e-5, "tanh bwd")
     a, b = rnd(4, 33, 17, 3, seed=3), rnd(4, 33, 17, 3, seed=4)
     out = torch.zeros(2, device=DEV)
@@ -368,7 +368,7 @@ def test_act_backward_and_reductions():
 
 def test_pack_weights():
     flat = rnd(9 * 8 * 16 + 16 * 4, seed=1).to(DEV)
-    tab = torch.tensor([[0, 0, 9, (8 << 32) | 16], [9 * 8 * 16, 9 * 8 * 16, 1, (16 << 32) | 4]], dtype=torch.int64,
+    tab = torch.tensor([[0, 0, 9, 8, 16, 8], [9 * 8 * 16, 9 * 8 * 16, 1, 16, 4, 16]], dtype=torch.int64,
                        device=DEV)
     for dtype in (torch.float32, torch.bfloat16):
         dst = torch.empty(flat.numel(), device=DEV, dtype=dtype)
