@@ -26,7 +26,7 @@ def default_flags(**kw):
 
 def frvsr_flags(**kw):
     """runGan.py:250-272 (case 4): no D, no ping-pong, 10 res blocks, VGG off."""
-    base = dict(num_resblock=10, pingpang=False, ratio=-0.01, vgg_scaling=-0.2, learning_rate=1e-4)
+    base = dict(num_resblock=10, pingpang=False, ratio=-0.01, vgg_scaling=-0.002, learning_rate=5e-5, stair=True)
     base.update(kw)
     return default_flags(**base)
 

@@ -84,6 +84,9 @@ class TrainEngine:
         if self.graph is None:
             self._capture()
         self.graph.replay()
+        if self.world > 1:          # RCCL exchange stays outside the captured graphs (eager, same stream)
+            self._allreduce()
+            self.graph_update.replay()
 
     def _capture(self):
         # warm-up run on a side stream (allocator pools, lazy module loads), with state restored afterwards
@@ -102,11 +105,24 @@ class TrainEngine:
         self.ps.repack()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._program()
+        if self.world == 1:
+            with torch.cuda.graph(self.graph):
+                self._program()
+        else:
+            with torch.cuda.graph(self.graph):
+                self._program_compute()
+            self.graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_update):
+                self._program_update()
 
     # ------------------------------------------------------------------------------------------
     def _program(self):
+        self._program_compute()
+        if self.world > 1:
+            self._allreduce()
+        self._program_update()
+
+    def _program_compute(self):
         F, ps, B, T, h = self.F, self.ps, self.B, self.T, self.cs
         H = 4 * h
         ps.grad.zero_()
@@ -155,10 +171,10 @@ class TrainEngine:
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
         self.Fn.backward(fsaved, d_flow)
-        # ---- data-parallel exchange: one flat all-reduce per optimiser scope (RCCL over xGMI) -----------
-        if self.world > 1:
-            self._allreduce()
-        # ---- schedule, three TF-Adams, refresh compute copies -------------------------------------------
+
+    def _program_update(self):
+        """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""
+        F, ps = self.F, self.ps
         tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1] if self.gan else None
         K.schedule_step(self.sched, self.hyper, len(self.opt_scopes), 0 if self.gan else -1, tb, F.beta, 0.999,
                         F.adameps)
