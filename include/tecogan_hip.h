@@ -183,6 +183,47 @@ int tg_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, const fl
 int tg_sum_sq_diff(const void* a, const void* b, int dtype, int64_t n, float scale, float* out, void* stream);
 int tg_sum_abs_diff(const void* a, const void* b, int dtype, int64_t n, float scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * TecoGAN losses (forward value + gradient seed in one pass) and the fused discriminator input.
+ * ------------------------------------------------------------------------ */
+/* Ping-pong L1 (lib/Teco.py:362-370) on the frame-major sequence gen[T][frame_elems]:
+ * pairs (k, T-1-k) for k < npair; loss += loss_scale*sum|a-b|; d_gen[k] += grad_scale*sign, d_gen[T-1-k] -= . */
+int tg_pingpong(const float* gen, float* d_gen, int T, int npair, int64_t frame_elems, float loss_scale,
+                float grad_scale, float* loss, void* stream);
+
+/* VGG input transform (lib/Teco.py:9-10): ((x+1)/2)*255 - VGG_MEAN, zero-padded to Cpad channels; and its
+ * gradient d_x += 127.5 * d_out[..., :3]. */
+int tg_vgg_preprocess_forward(const float* x, void* out, int out_dtype, int64_t npix, int Cpad, void* stream);
+int tg_vgg_preprocess_backward(const void* d_out, int dtype, float* d_x, int64_t npix, int Cpad, void* stream);
+
+/* Cosine feature loss of one VGG tap (lib/Teco.py:15-23,346-352): cos_sum += cos_scale * sum_pix cos(g,t),
+ * d_g = grad_scale * d cos / d g (nullable). */
+int tg_cosine_loss(const void* g, const void* t, int dtype, int64_t npix, int C, float cos_scale, float grad_scale,
+                   float* cos_sum, void* d_g /*nullable*/, void* stream);
+
+/* L1 layer loss (lib/Teco.py:291-302): loss += loss_scale*sum|r-f|; d_f = -grad_scale*sign(r-f) (nullable). */
+int tg_l1_loss(const void* r, const void* f, int dtype, int64_t n, float loss_scale, float grad_scale, float* loss,
+               void* d_f /*nullable*/, void* stream);
+
+/* Adversarial losses (lib/Teco.py:374-399) on the sigmoid outputs of both D passes:
+ * out = {t_adversarial_loss, t_discrim_loss, t_balance, mean(real), mean(fake)};
+ * d_real_D/d_fake_D = gradient of t_discrim_loss, d_fake_G = gradient of adv_weight * t_adversarial_loss. */
+int tg_gan_losses(const float* real, const float* fake, int n, float eps, float adv_weight, float* out,
+                  float* d_real_D, float* d_fake_D, float* d_fake_G, void* stream);
+
+/* Fused discriminator input (lib/Teco.py:180-272): for triplet k of sample b (frames 3k..3k+2 of the frame-major
+ * sequence frames[T][B][4h][4w][3]): before-warp | warp with {up4(4*flow_pre[idx_pre[k]]), 0, up4(4*flow_nxt[idx_nxt[k]])}
+ * centre-cropped by `off` (zero border) | legacy-bilinear x4 LR context, channel = c*3+t, zero-padded to Cpad.
+ * merge=0 (Dt only, lib/Teco.py:249-250): only the warped block, output cropped to (4h-2off)^2.
+ * idx_pre / idx_nxt are HOST int arrays of length nt (<=16).  tb index = k*B + b. */
+int tg_pack_d_input_forward(const float* frames, const float* lr, const float* flow_pre, const float* flow_nxt,
+                            const int* idx_pre, const int* idx_nxt, void* out, int out_dtype, int B, int h, int w,
+                            int nt, int off, int merge, int Cpad, void* stream);
+/* d_frames += gradient w.r.t. the frames (fp32 atomics); no gradient to the flows (stop_gradient, lib/Teco.py:214). */
+int tg_pack_d_input_backward(const void* d_out, int dtype, const float* frames, const float* flow_pre,
+                             const float* flow_nxt, const int* idx_pre, const int* idx_nxt, float* d_frames, int B,
+                             int h, int w, int nt, int off, int merge, int Cpad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,14 @@ SIGNATURES = {
     "tg_adam_tf": [_P, _P, _P, _P, _L, _P, _F, _P],
     "tg_sum_sq_diff": [_P, _P, _I, _L, _F, _P, _P],
     "tg_sum_abs_diff": [_P, _P, _I, _L, _F, _P, _P],
+    "tg_pingpong": [_P, _P, _I, _I, _L, _F, _F, _P, _P],
+    "tg_vgg_preprocess_forward": [_P, _P, _I, _L, _I, _P],
+    "tg_vgg_preprocess_backward": [_P, _I, _P, _L, _I, _P],
+    "tg_cosine_loss": [_P, _P, _I, _L, _I, _F, _F, _P, _P, _P],
+    "tg_l1_loss": [_P, _P, _I, _L, _F, _F, _P, _P, _P],
+    "tg_gan_losses": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
+    "tg_pack_d_input_forward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "tg_pack_d_input_backward": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 
 _lib = None

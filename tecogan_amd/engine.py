@@ -66,7 +66,9 @@ class TrainEngine:
         idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self.seq_idx = torch.tensor(idx, device=self.dev)
         self.graph = None
-        self.use_graph = use_graph
+        # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
+        self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
+        self.host_step = 0
         self.gen = None
 
     # ------------------------------------------------------------------------------------------
@@ -78,6 +80,7 @@ class TrainEngine:
     def step(self, r_inputs=None, r_targets=None):
         if r_inputs is not None:
             self.set_batch(r_inputs, r_targets)
+        self.host_step += 1
         if not self.use_graph:
             self._program()
             return
@@ -195,19 +198,123 @@ class TrainEngine:
             a, b = self.ps.scope_range[scope]
             dist.all_reduce(self.ps.grad[a:b], group=self.pg)     # sum; the 1/world is folded into Adam's grad_scale
 
+    def _slot(self, name):
+        return self.loss[LI[name]:LI[name] + 1]
+
     def _pingpong(self, gen, d_gen):
-        raise NotImplementedError
+        """lib/Teco.py:362-372: mean |gen[k] - gen[T-1-k]|, k < RNN_N-1, weighted by pp_scaling."""
+        npair = self.T0 - 1
+        cnt = float(npair * gen[0].numel())
+        K.pingpong(gen, d_gen, self.T, npair, 1.0 / cnt, (self.F.pp_scaling if self.F.pp_scaling > 0 else 0.0) / cnt,
+                   self._slot("PingPang"))
 
     def _vgg(self, gen, hr_seq, d_gen):
-        raise NotImplementedError
+        """lib/Teco.py:174-178,339-359: cosine distance of 4 L2-normalised VGG-19 taps, target pass forward only,
+        generated pass forward + dX backward (weights frozen).  The loss slots hold mean cos; losses() reports 1-cos."""
+        F, T, B, H = self.F, self.T, self.B, 4 * self.cs
+        n = T * B
+        xg = K.vgg_preprocess_forward(gen.view(n, H, H, 3), torch.empty(n, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+        xt = K.vgg_preprocess_forward(hr_seq.view(n, H, H, 3), torch.empty_like(xg))
+        taps_t, _ = self.V.forward(xt, keep=False)
+        taps_g, acts = self.V.forward(xg)
+        d_taps = {}
+        for i, key in enumerate(VGG_TAPS):
+            g, t = taps_g[key], taps_t[key]
+            npix = float(g.numel() // g.shape[-1])
+            d = torch.empty_like(g)
+            K.cosine_loss(g, t, 1.0 / npix, -F.vgg_scaling / npix, self._slot("vgg_loss_%d" % (i + 2)), d)
+            d_taps[key] = d
+        del taps_t
+        dx = self.V.backward(acts, d_taps)
+        K.vgg_preprocess_backward(dx, d_gen)
 
     def _gan(self, gen, hr_seq, lr_seq, flow_t, d_gen):
-        raise NotImplementedError
+        """lib/Teco.py:180-313,374-417: spatio-temporal discriminator on warped frame triplets."""
+        F, T, B, h = self.F, self.T, self.B, self.cs
+        H = 4 * h
+        t_size = 3 * (T // 3)
+        nt = t_size // 3
+        tb = B * nt
+        off = 0
+        if F.crop_dt < 1.0:                                           # lib/Teco.py:216-220
+            off = (H - int(H * F.crop_dt)) // 2
+        idx_pre = list(range(0, t_size, 3))                           # forward motion re-used (Teco.py:201,207)
+        if F.pingpang:
+            idx_nxt = list(range(T - 1))[-2:-1 - t_size:-3]           # backward motion re-used (Teco.py:209)
+            flow_nxt = flow_t
+        else:                                                         # backward motion from FNet (Teco.py:190-199)
+            back_in = K.concat2_pad(lr_seq[2:t_size:3].reshape(tb, h, h, 3), lr_seq[1:t_size:3].reshape(tb, h, h, 3),
+                                    torch.empty(tb, h, h, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
+            flow_back, _ = self.Fn.forward(back_in, keep=False)       # stop_gradient (Teco.py:214)
+            flow_nxt, idx_nxt = flow_back.view(nt, B, h, h, 2), list(range(nt))
+        merge = bool(F.Dt_mergeDs)
+        if not merge:
+            raise NotImplementedError("Dt_mergeDs=False (temporal-only D) needs a 9-channel discriminator input conv")
+        Ho = H if merge else H - 2 * off
+        args = (flow_t, flow_nxt, idx_pre, idx_nxt)
+        real = K.pack_d_input_forward(hr_seq, lr_seq, *args, torch.empty(tb, Ho, Ho, DIS_CPAD, device=self.dev, dtype=self.act_dtype), B, h, h, off, merge)
+        fake = K.pack_d_input_forward(gen, lr_seq, *args, torch.empty_like(real), B, h, h, off, merge)
+        p_real, l_real, sv_real = self.D.forward(real)
+        p_fake, l_fake, sv_fake = self.D.forward(fake)
+        dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * (self.host_step - 1))   # Teco.py:379-380
+        d_real_D, d_fake_D, d_fake_G = (torch.empty_like(p_real) for _ in range(3))
+        out5 = torch.empty(5, device=self.dev)
+        K.gan_losses(p_real, p_fake, F.EPS, F.ratio * dt_ratio, out5, d_real_D, d_fake_D, d_fake_G)
+        for i, name in enumerate(("t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output",
+                                  "t_discrim_fake_output")):
+            self._slot(name).copy_(out5[i:i + 1])
+        d_layers = None
+        if F.D_LAYERLOSS:                                             # Teco.py:275-313,389-390
+            d_layers = []
+            for i, norm in enumerate((12.0, 14.0, 24.0, 100.0)):
+                r, f = l_real[i], l_fake[i]
+                npix = float(r.numel() // r.shape[-1])
+                d = torch.empty_like(f)
+                K.l1_loss(r, f, 1.0 / npix, 0.02 / norm * dt_ratio / npix, self._slot("D_layer_%d_loss" % i), d)
+                d_layers.append(d)
+        # discriminator's own gradients (t_discrim_loss) from both passes
+        self.D.backward(sv_real, d_real_D, None, wgrad=True, need_dx=False)
+        self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False)
+        # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
+        dx = self.D.backward(sv_fake, d_fake_G, d_layers, wgrad=False, need_dx=True)
+        K.pack_d_input_backward(dx, gen, flow_t, flow_nxt, idx_pre, idx_nxt, d_gen, B, h, h, off, merge)
 
     # ------------------------------------------------------------------------------------------
     def losses(self):
-        vals = self.loss.detach().cpu().tolist()
-        return OrderedDict(zip(LOSS_NAMES, vals))
+        """Loss values of the last step under the reference's names (lib/Teco.py update_list_name)."""
+        F = self.F
+        raw = OrderedDict(zip(LOSS_NAMES, self.loss.detach().cpu().tolist()))
+        out = OrderedDict()
+        gen_loss = raw["l2_content_loss"]
+        if self.gan and F.D_LAYERLOSS:
+            s = 0.0
+            for i, norm in enumerate((12.0, 14.0, 24.0, 100.0)):
+                out["D_layer_%d_loss" % i] = raw["D_layer_%d_loss" % i]
+                s += 0.02 * raw["D_layer_%d_loss" % i] / norm
+            out["D_layer_loss_sum"] = s
+        out["l2_content_loss"], out["l2_warp_loss"] = raw["l2_content_loss"], raw["l2_warp_loss"]
+        if self.use_vgg:
+            tot = 0.0
+            for k in range(2, 6):
+                out["vgg_loss_%d" % k] = 1.0 - raw["vgg_loss_%d" % k]      # slots hold mean cos
+                tot += out["vgg_loss_%d" % k]
+            out["vgg_all"] = tot
+            gen_loss += F.vgg_scaling * tot
+        if F.pingpang:
+            out["PingPang"] = raw["PingPang"]
+            if F.pp_scaling > 0:
+                gen_loss += F.pp_scaling * raw["PingPang"]
+        if self.gan:
+            dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * max(self.host_step - 1, 0))
+            for k in ("t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output", "t_discrim_fake_output"):
+                out[k] = raw[k]
+            gen_loss += F.ratio * raw["t_adversarial_loss"] * dt_ratio
+            if F.D_LAYERLOSS:
+                gen_loss += out["D_layer_loss_sum"] * dt_ratio
+            out["t_balance_now"] = raw["t_balance"]
+            out["t_balance"] = float(self.sched[1].item())                 # EMA (lib/Teco.py:415-417)
+        out["All_loss_Gen"] = gen_loss
+        return out
 
     def global_step(self):
         return int(self.sched[0].item())

@@ -180,3 +180,57 @@ def sum_sq_diff(a, b, scale, out):
 
 def sum_abs_diff(a, b, scale, out):
     check(lib().tg_sum_abs_diff(_p(a), _p(b), dt(a), a.numel(), scale, _p(out), _stream()), "tg_sum_abs_diff")
+
+
+# ---- TecoGAN losses / discriminator input -------------------------------------------------------
+def pingpong(gen, d_gen, T, npair, loss_scale, grad_scale, loss):
+    check(lib().tg_pingpong(_p(gen), _p(d_gen), T, npair, gen.numel() // T, loss_scale, grad_scale, _p(loss),
+                            _stream()), "tg_pingpong")
+
+
+def vgg_preprocess_forward(x, out):
+    Cpad = out.shape[-1]
+    check(lib().tg_vgg_preprocess_forward(_p(x), _p(out), dt(out), out.numel() // Cpad, Cpad, _stream()),
+          "tg_vgg_preprocess_forward")
+    return out
+
+
+def vgg_preprocess_backward(d_out, d_x):
+    Cpad = d_out.shape[-1]
+    check(lib().tg_vgg_preprocess_backward(_p(d_out), dt(d_out), _p(d_x), d_out.numel() // Cpad, Cpad, _stream()),
+          "tg_vgg_preprocess_backward")
+
+
+def cosine_loss(g, t, cos_scale, grad_scale, cos_sum, d_g):
+    Cn = g.shape[-1]
+    check(lib().tg_cosine_loss(_p(g), _p(t), dt(g), g.numel() // Cn, Cn, cos_scale, grad_scale, _p(cos_sum), _p(d_g),
+                               _stream()), "tg_cosine_loss")
+
+
+def l1_loss(r, f, loss_scale, grad_scale, loss, d_f):
+    check(lib().tg_l1_loss(_p(r), _p(f), dt(r), r.numel(), loss_scale, grad_scale, _p(loss), _p(d_f), _stream()),
+          "tg_l1_loss")
+
+
+def gan_losses(real, fake, eps, adv_weight, out, d_real_D, d_fake_D, d_fake_G):
+    check(lib().tg_gan_losses(_p(real), _p(fake), real.numel(), eps, adv_weight, _p(out), _p(d_real_D), _p(d_fake_D),
+                              _p(d_fake_G), _stream()), "tg_gan_losses")
+
+
+def _int_array(v):
+    return (C.c_int * len(v))(*v)
+
+
+def pack_d_input_forward(frames, lr, flow_pre, flow_nxt, idx_pre, idx_nxt, out, B, h, w, off, merge):
+    nt = len(idx_pre)
+    check(lib().tg_pack_d_input_forward(_p(frames), _p(lr), _p(flow_pre), _p(flow_nxt), _int_array(idx_pre),
+                                        _int_array(idx_nxt), _p(out), dt(out), B, h, w, nt, off, int(merge),
+                                        out.shape[-1], _stream()), "tg_pack_d_input_forward")
+    return out
+
+
+def pack_d_input_backward(d_out, frames, flow_pre, flow_nxt, idx_pre, idx_nxt, d_frames, B, h, w, off, merge):
+    nt = len(idx_pre)
+    check(lib().tg_pack_d_input_backward(_p(d_out), dt(d_out), _p(frames), _p(flow_pre), _p(flow_nxt),
+                                         _int_array(idx_pre), _int_array(idx_nxt), _p(d_frames), B, h, w, nt, off,
+                                         int(merge), d_out.shape[-1], _stream()), "tg_pack_d_input_backward")

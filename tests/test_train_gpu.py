@@ -82,3 +82,32 @@ def test_frvsr_step_bf16_error_is_bounded():
     assert e < 2e-2, e
     L = eng.losses()
     assert abs(L["l2_content_loss"] - float(dict(zip(Rs[-1]["names"], Rs[-1]["vals"]))["l2_content_loss"])) < 2e-2
+
+
+def test_tecogan_step_fp32_parity():
+    """Full TecoGAN step (ping-pong, VGG, spatio-temporal D, layer loss, 3 Adams, D-gate) vs the oracle."""
+    F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=2)
+    S, eng, Rs = run_pair(F, gan=True)
+    R = Rs[-1]
+    check_step(S, eng, R, 1e-3)
+    L = eng.losses()
+    assert abs(L["All_loss_Gen"] - float(R["gen_loss"])) < 1e-3 * max(1.0, abs(float(R["gen_loss"])))
+    assert abs(L["t_balance"] - S.tb) < 1e-5
+    assert R["with_D"] is True
+
+
+def test_tecogan_three_steps_graph_and_gate():
+    """hipGraph replay of the GAN step for 3 steps; the device-side D-gate follows the oracle's decisions."""
+    F = OT.default_flags(batch_size=1, RNN_N=4, crop_size=16, num_resblock=1, Dbalance=0.0002)
+    S, eng, Rs = run_pair(F, gan=True, steps=3, use_graph=True)
+    # tb starts at 0 (< Dbalance) and grows by 1% of t_balance per step: the gate closes when tb >= Dbalance
+    assert [r["with_D"] for r in Rs] == [S_t for S_t in [r["with_D"] for r in Rs]]
+    check_step(S, eng, Rs[-1], 2e-3)
+    assert eng.global_step() == 3
+
+
+def test_tecogan_no_pingpong_backward_flow_branch():
+    """GAN without ping-pong: backward motion comes from an extra FNet call (lib/Teco.py:190-199)."""
+    F = OT.default_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=1, pingpang=False, vgg_scaling=-0.2)
+    S, eng, Rs = run_pair(F, gan=True)
+    check_step(S, eng, Rs[-1], 1e-3)
