@@ -127,6 +127,6 @@ def test_tecogan_three_steps_graph_and_gate():
 
 def test_tecogan_no_pingpong_backward_flow_branch():
     """GAN without ping-pong: backward motion comes from an extra FNet call (lib/Teco.py:190-199)."""
-    F = OT.default_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=1, pingpang=False, vgg_scaling=-0.2)
+    F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=1, pingpang=False, vgg_scaling=-0.2)
     S, eng, Rs = run_pair(F, gan=True)
     check_step(S, eng, Rs[-1], 1e-3)
