@@ -159,6 +159,9 @@ int tg_concat2_pad(const float* a, int Ca, const float* b /*nullable*/, int Cb, 
 int tg_lincomb(const float* a, const float* b /*nullable*/, float* out, int64_t n, float alpha, float beta,
                int accumulate, void* stream);
 
+/* out = x*scale + shift: deprocess (lib/ops.py:19-22) with (0.5, 0.5), preprocess (lib/ops.py:13-16) with (2,-1). */
+int tg_affine(const float* x, float* out, int64_t n, float scale, float shift, void* stream);
+
 /* Device-side schedule (lib/Teco.py:95-99,415-417,425,439-440,493-494): advances global_step, the
  * lr decay, each optimiser's Adam bias correction and the EMA(0.99)/tf.cond D-gate; fills
  * hyper[k] = {lr_t, beta1, beta2, eps, gate, lr, 0, 0} for tg_adam_tf.  state layout: schedule.hip. */

@@ -442,6 +442,19 @@ extern "C" int tg_concat2_pad(const float* a, int Ca, const float* b, int Cb, vo
   TG_CHECK_LAUNCH();
 }
 
+// out = x * scale + shift  (deprocess (x+1)/2 of reference lib/ops.py:19-22 == x*0.5+0.5 bit for bit)
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                     float scale, float shift) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = x[e] * scale + shift;
+}
+
+extern "C" int tg_affine(const float* x, float* out, int64_t n, float scale, float shift, void* stream) {
+  TG_CHECK_ARG(x && out && n > 0, "bad argument");
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, ST(stream), x, out, n, scale, shift);
+  TG_CHECK_LAUNCH();
+}
+
 extern "C" int tg_lincomb(const float* a, const float* b, float* out, int64_t n, float alpha, float beta,
                           int accumulate, void* stream) {
   TG_CHECK_ARG(a && out && n > 0, "bad argument");

@@ -234,3 +234,8 @@ def pack_d_input_backward(d_out, frames, flow_pre, flow_nxt, idx_pre, idx_nxt, d
     check(lib().tg_pack_d_input_backward(_p(d_out), dt(d_out), _p(frames), _p(flow_pre), _p(flow_nxt),
                                          _int_array(idx_pre), _int_array(idx_nxt), _p(d_frames), B, h, w, nt, off,
                                          int(merge), d_out.shape[-1], _stream()), "tg_pack_d_input_backward")
+
+
+def affine(x, out, scale, shift):
+    check(lib().tg_affine(_p(x), _p(out), x.numel(), scale, shift, _stream()), "tg_affine")
+    return out
