@@ -262,7 +262,7 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   TG_CHECK_ARG(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->Cin > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0,
                "non-positive dimension");
   TG_CHECK_ARG(d->KH >= 1 && d->KH <= 11 && d->KW >= 1 && d->KW <= 11, "kernel size out of range");
-  TG_CHECK_ARG(d->stride >= 1 && d->stride <= 2, "stride must be 1 or 2");
+  TG_CHECK_ARG(d->stride >= 1 && d->stride <= 4, "stride must be 1..4");
   TG_CHECK_ARG(d->mode == 0 || d->mode == 1, "mode must be 0 (gather) or 1 (transposed)");
   TG_CHECK_ARG((d->in_dtype == TG_F32 || d->in_dtype == TG_BF16) && (d->out_dtype == TG_F32 || d->out_dtype == TG_BF16),
                "bad dtype");

@@ -57,7 +57,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     L = _lib.lib()
     assert L.tg_conv_forward(None, None, None, None, None, None, None, None) == -1
     assert b"null" in L.tg_last_error_string()
-    d = _lib.ConvDesc(1, 4, 4, 8, 4, 4, 8, 3, 3, 3, 1, 1, 0, 0, 0, 0, 0.0, 0, 0.0)     # stride 3 unsupported
+    d = _lib.ConvDesc(1, 4, 4, 8, 4, 4, 8, 3, 3, 5, 1, 1, 0, 0, 0, 0, 0.0, 0, 0.0)     # stride 5 unsupported
     assert L.tg_conv_forward(ctypes.byref(d), 1, 1, None, None, None, 1, None) == -1
 
 
