@@ -71,8 +71,12 @@ FLAG_TABLE = [
 ]
 
 
+EXTENSIONS = {"act_dtype": "bf16", "synthetic": False}       # flags of this implementation, not in the reference
+
+
 def defaults(**kw):
     f = {name: default for name, _, default, _ in FLAG_TABLE}
+    f.update(EXTENSIONS)
     unknown = set(kw) - set(f)
     if unknown:
         raise ValueError("unknown flag(s): %s" % sorted(unknown))
