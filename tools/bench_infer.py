@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Inference throughput of the recurrent step (BASELINE config 5: 480x270 -> 1920x1080)."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tecogan_amd.infer import InferenceEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--h", type=int, default=270); ap.add_argument("--w", type=int, default=480)
+ap.add_argument("--frames", type=int, default=60); ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--dtype", default="bf16"); ap.add_argument("--nres", type=int, default=16)
+a = ap.parse_args()
+tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+eng = InferenceEngine(a.nres, a.h, a.w, "cuda", tdt)
+frames = torch.rand(8, 1, a.h, a.w, 3, device="cuda")
+for i in range(a.warmup):
+    eng.step(frames[i % 8])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(a.frames):
+    eng.step(frames[i % 8])
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+gflop = 2 * (184.2 + 16.2) * (a.h * a.w) / (270 * 480) * (1 if a.nres == 16 else 0.7)
+print(json.dumps({"metric": "inference HR fps", "value": round(a.frames / dt, 2), "ms_per_frame": round(dt / a.frames * 1e3, 3),
+                  "shape": "%dx%d->%dx%d" % (a.w, a.h, 4 * a.w, 4 * a.h), "dtype": a.dtype,
+                  "approx_TFLOPs": round(gflop * a.frames / dt / 1e3, 2), "mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
