@@ -1,0 +1,267 @@
+// 3x3 stride-1 SAME convolution, halo-tile / weights-stationary variant (gfx950 MFMA).
+//
+// This is the workhorse of the path: every generator_F res-block conv, FNet, VGG-19 and the D input
+// conv of the reference (lib/frvsr.py:7-80, lib/ops.py:319-327, lib/Teco.py:48 via lib/ops.py:47-56)
+// and -- with the taps flipped -- all of their input gradients.
+//
+// Structure (one 256-thread workgroup = 4 waves, one workgroup per CU, persistent over tiles):
+//   * output tile = TH x 16 pixels x BN channels; the (TH+2) x 18 pixel input halo tile of one 128-byte
+//     channel chunk is staged ONCE in LDS and all 9 taps read their A fragments from it: HBM/L2 input
+//     traffic is (TH+2)*18/(TH*16) = 1.27x (TH=16) instead of 9x for a per-tap gather;
+//   * the 9 x BN weight panel of the chunk is staged in LDS; when Cin fits one chunk it is loaded once per
+//     workgroup and stays resident while the workgroup walks its tiles (weights-stationary);
+//   * the next stage's global loads are issued into registers before the MFMA block of the current stage
+//     (one wave per SIMD, ~250 VGPRs), so HBM latency overlaps the matrix work without a second LDS buffer;
+//   * rows of 16 consecutive pixels with a 144-byte pitch make every ds_read_b128 fragment read
+//     conflict-free; the epilogue (bias, activation, residual, act-grad mask) is the engine's.
+// fp32 uses v_mfma_f32_16x16x4_f32 (exact, K-permuted as in conv_igemm.hip), bf16 v_mfma_f32_16x16x32_bf16.
+#include "common.h"
+
+struct Conv3P {
+  const void* in;
+  const void* w;      // [9][Cout][Cin]
+  const float* bias;
+  const void* res;
+  const void* aux;
+  void* out;
+  int N, H, W, Cin, Cout;
+  int flip;           // 1: taps mirrored (input-gradient form)
+  int act;
+  float act_alpha;
+  int mask_act;
+  float mask_alpha;
+  int tiles_y, tiles_x, ntiles;
+};
+
+template <typename TIn, typename TOut, int TH, int BN>
+__global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
+  constexpr int EPV = 16 / (int)sizeof(TIn);
+  constexpr int BK = 8 * EPV;                       // channels per 128-byte chunk
+  constexpr int ROWB = 144;
+  constexpr int HALO_PIX = (TH + 2) * 18;
+  constexpr int A_ITEMS = HALO_PIX * 8, A_LOADS = (A_ITEMS + 255) / 256;
+  constexpr int B_ITEMS = 9 * BN * 8, B_LOADS = (B_ITEMS + 255) / 256;
+  constexpr int WAVES_M = TH >= 4 ? 4 : TH, WAVES_N = 4 / WAVES_M;
+  constexpr int TM = TH / WAVES_M, TN = (BN / 16) / WAVES_N;
+  constexpr bool F32 = sizeof(TIn) == 4;
+  static_assert(TM >= 1 && TN >= 1, "tile too small for 4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                          // [HALO_PIX][144]
+  unsigned char* Bs = smem + HALO_PIX * ROWB;        // [9*BN][144]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int nchunk = (p.Cin + BK - 1) / BK;
+  const bool b_stationary = nchunk == 1;
+
+  const TIn* __restrict__ gin = static_cast<const TIn*>(p.in);
+  const TIn* __restrict__ gw = static_cast<const TIn*>(p.w);
+  TOut* __restrict__ gout = static_cast<TOut*>(p.out);
+  const TOut* __restrict__ gres = static_cast<const TOut*>(p.res);
+  const TOut* __restrict__ gaux = static_cast<const TOut*>(p.aux);
+
+  uint4 ra[A_LOADS], rb[B_LOADS];
+
+  // stage = (tile, chunk); this workgroup owns tiles blockIdx.x, +gridDim.x, ...
+  auto load_stage = [&](int tile, int chunk, bool with_b) {
+    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+    const int y0 = ty * TH - 1, x0 = tx * 16 - 1;
+    const int c0 = chunk * BK;
+#pragma unroll
+    for (int k = 0; k < A_LOADS; ++k) {
+      const int item = tid + k * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (item < A_ITEMS) {
+        const int pix = item >> 3, ch = item & 7;
+        const int y = y0 + pix / 18, x = x0 + pix % 18;
+        const int c = c0 + ch * EPV;
+        if (y >= 0 && y < p.H && x >= 0 && x < p.W && c < p.Cin)
+          v = *reinterpret_cast<const uint4*>(gin + ((int64_t)(n * p.H + y) * p.W + x) * p.Cin + c);
+      }
+      ra[k] = v;
+    }
+    if (with_b) {
+#pragma unroll
+      for (int k = 0; k < B_LOADS; ++k) {
+        const int item = tid + k * 256;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (item < B_ITEMS) {
+          const int row = item >> 3, ch = item & 7;
+          const int tap = row / BN, co = n0 + row % BN;
+          const int c = c0 + ch * EPV;
+          const int wtap = p.flip ? 8 - tap : tap;
+          if (co < p.Cout && c < p.Cin)
+            v = *reinterpret_cast<const uint4*>(gw + ((int64_t)wtap * p.Cout + co) * p.Cin + c);
+        }
+        rb[k] = v;
+      }
+    }
+  };
+  auto store_stage = [&](bool with_b) {
+#pragma unroll
+    for (int k = 0; k < A_LOADS; ++k) {
+      const int item = tid + k * 256;
+      if (item < A_ITEMS) *reinterpret_cast<uint4*>(As + (item >> 3) * ROWB + (item & 7) * 16) = ra[k];
+    }
+    if (with_b) {
+#pragma unroll
+      for (int k = 0; k < B_LOADS; ++k) {
+        const int item = tid + k * 256;
+        if (item < B_ITEMS) *reinterpret_cast<uint4*>(Bs + (item >> 3) * ROWB + (item & 7) * 16) = rb[k];
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+
+  int tile = blockIdx.x;
+  if (tile >= p.ntiles) return;
+  int chunk = 0;
+  bool first = true;
+  load_stage(tile, 0, true);
+  while (tile < p.ntiles) {
+    const bool with_b = first || !b_stationary;
+    __syncthreads();                       // previous stage's fragment reads are done: LDS may be rewritten
+    store_stage(with_b);
+    __syncthreads();
+    // prefetch the next stage into registers (overlaps the MFMA block below)
+    int ntile = tile, nchunk_i = chunk + 1;
+    if (nchunk_i == nchunk) {
+      nchunk_i = 0;
+      ntile = tile + gridDim.x;
+    }
+    if (ntile < p.ntiles) load_stage(ntile, nchunk_i, !b_stationary);
+
+    if (chunk == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ry = wm * TM + i;
+          af[i] = *reinterpret_cast<const uint4*>(As + ((ry + kh) * 18 + frow + kw) * ROWB + kk * 64 + fg * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const uint4*>(Bs + (tap * BN + (wn * TN + j) * 16 + frow) * ROWB + kk * 64 + fg * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (F32) {
+              const float* a = reinterpret_cast<const float*>(&af[i]);
+              const float* b = reinterpret_cast<const float*>(&bfr[j]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[i]),
+                                                                  *reinterpret_cast<bf16x8*>(&bfr[j]), acc[i][j],
+                                                                  0, 0, 0);
+            }
+          }
+      }
+    }
+
+    if (chunk == nchunk - 1) {             // ---- fused epilogue for this tile ----
+      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 16 + frow;
+        if (col >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int y = ty * TH + wm * TM + i;
+          if (y >= p.H) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int x = tx * 16 + fg * 4 + r;
+            if (x >= p.W) continue;
+            const int64_t idx = ((int64_t)(n * p.H + y) * p.W + x) * p.Cout + col;
+            float v = acc[i][j][r] + bv;
+            v = act_fwd(v, p.act, p.act_alpha);
+            if (gres) v += Elem<TOut>::ld(gres + idx);
+            if (gaux) v *= act_grad_from_out(Elem<TOut>::ld(gaux + idx), p.mask_act, p.mask_alpha);
+            Elem<TOut>::st(gout + idx, v);
+          }
+        }
+      }
+    }
+    first = false;
+    tile = ntile;
+    chunk = nchunk_i;
+  }
+}
+
+template <typename TIn, typename TOut, int TH, int BN>
+static void launch3(Conv3P p, hipStream_t st) {
+  constexpr int LDS = ((TH + 2) * 18 + 9 * BN) * 144;
+  static bool attr_set = false;
+  auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN>;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  p.tiles_y = (p.H + TH - 1) / TH;
+  p.tiles_x = (p.W + 15) / 16;
+  p.ntiles = p.N * p.tiles_y * p.tiles_x;
+  const int nt = (p.Cout + BN - 1) / BN;
+  int gx = p.ntiles;
+  const int per = 256 / nt > 0 ? 256 / nt : 1;        // one workgroup per CU (LDS-bound residency)
+  if (gx > per) gx = per;
+  hipLaunchKernelGGL(kern, dim3(gx, nt), dim3(256), LDS, st, p);
+}
+
+template <typename TIn, typename TOut>
+static void launch3_typed(const Conv3P& p, hipStream_t st) {
+  const int64_t pix = (int64_t)p.N * p.H * p.W;
+  const int nt64 = (p.Cout + 63) / 64;
+  if (p.Cout <= 16) {
+    if (pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 16>(p, st);
+    else if (pix >= 8 * 16 * 256) launch3<TIn, TOut, 8, 16>(p, st);
+    else launch3<TIn, TOut, 4, 16>(p, st);
+  } else if (p.Cout <= 32) {
+    if (pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 32>(p, st);
+    else if (pix >= 8 * 16 * 256) launch3<TIn, TOut, 8, 32>(p, st);
+    else launch3<TIn, TOut, 4, 32>(p, st);
+  } else {
+    // pick the largest tile that still yields >= ~256 workgroups of work
+    if (pix * nt64 >= (int64_t)16 * 16 * 256) launch3<TIn, TOut, 16, 64>(p, st);
+    else if (pix * nt64 >= (int64_t)8 * 16 * 256) launch3<TIn, TOut, 8, 64>(p, st);
+    else if (pix * nt64 >= (int64_t)4 * 16 * 256) launch3<TIn, TOut, 4, 64>(p, st);
+    else launch3<TIn, TOut, 2, 64>(p, st);
+  }
+}
+
+// Returns 1 if the descriptor was handled by this kernel, 0 if the generic engine must take it.
+int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                   const void* aux, void* out, hipStream_t st) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1) return 0;
+  if (d->Hin != d->Hout || d->Win != d->Wout) return 0;
+  const int epv = d->in_dtype == TG_F32 ? 4 : 8;
+  if (d->Cin % epv != 0 || (((uintptr_t)in | (uintptr_t)weight) & 15)) return 0;
+  if (d->in_dtype == TG_F32 && d->out_dtype == TG_BF16) return 0;
+  Conv3P p;
+  p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
+  p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
+  p.flip = d->mode == 1;
+  p.act = d->act; p.act_alpha = d->act_alpha; p.mask_act = d->mask_act; p.mask_alpha = d->mask_alpha;
+  if (d->in_dtype == TG_F32) launch3_typed<float, float>(p, st);
+  else if (d->out_dtype == TG_BF16) launch3_typed<u16, u16>(p, st);
+  else launch3_typed<u16, float>(p, st);
+  return 1;
+}

@@ -19,6 +19,11 @@
 // four k's {4g..4g+3} of a 16-wide chunk (one ds_read_b128) and issue 4 MFMAs, j-th using
 // element j from both operands -- a bijection of k, so the sum is unchanged.
 #include "common.h"
+#include <stdlib.h>
+
+// conv3x3.hip: halo-tile kernel for 3x3 stride-1 SAME convolutions (returns 1 when it took the launch)
+int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                   const void* aux, void* out, hipStream_t st);
 
 struct ConvP {
   const void* in;
@@ -270,6 +275,9 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   TG_CHECK_ARG((int64_t)d->N * d->Hout * d->Wout * d->Cout < (1ll << 31) &&
                    (int64_t)d->N * d->Hin * d->Win < (1ll << 31),
                "tensor too large for 32-bit pixel indexing");
+  hipStream_t st0 = static_cast<hipStream_t>(stream);
+  static const bool use_tile3 = getenv("TG_NO_CONV3X3") == nullptr;      // A/B switch for profiling
+  if (use_tile3 && tg_conv3x3_try(d, in, weight, bias, res, aux, out, st0)) TG_CHECK_LAUNCH();
   ConvP p;
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin;

@@ -56,6 +56,13 @@ CONV_CASES = [
     (1, 12, 12, 128, 256, 3, 1),
     (1, 33, 35, 64, 64, 3, 1),
     (1, 6, 6, 51, 64, 3, 1),     # scalar (non-vector) channel path
+    # halo-tile 3x3 kernel (conv3x3.hip): persistent tile loop, partial edge tiles, every tile height
+    (1, 270, 250, 64, 64, 3, 1),   # TH=16, 272 tiles > 256 workgroups, weights stationary
+    (1, 130, 130, 128, 64, 3, 1),  # TH=4, multi-chunk (weights re-staged per chunk), persistent
+    (2, 64, 64, 64, 128, 3, 1),    # two output-channel tiles
+    (4, 32, 32, 64, 64, 3, 1),     # TH=2: the generator's training shape
+    (3, 128, 96, 32, 32, 3, 1),    # BN=32
+    (1, 128, 128, 64, 3, 3, 1),    # BN=16 (generator output conv)
 ]
 
 
