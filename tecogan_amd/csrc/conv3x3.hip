@@ -213,7 +213,7 @@ static void launch3(Conv3P p, hipStream_t st) {
   static bool attr_set = false;
   auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN>;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   p.tiles_y = (p.H + TH - 1) / TH;
