@@ -73,30 +73,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
     const int c0 = chunk * BK;
 #pragma unroll
     for (int k = 0; k < A_LOADS; ++k) {
-      const int item = tid + k * 256;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (item < A_ITEMS) {
-        const int pix = item >> 3, ch = item & 7;
-        const int y = y0 + pix / 18, x = x0 + pix % 18;
-        const int c = c0 + ch * EPV;
-        if (y >= 0 && y < p.H && x >= 0 && x < p.W && c < p.Cin)
-          v = *reinterpret_cast<const uint4*>(gin + ((int64_t)(n * p.H + y) * p.W + x) * p.Cin + c);
-      }
+      // Loads are UNCONDITIONAL from a clamped in-range address and zeroed by a select afterwards: a
+      // branch around each load makes hipcc wait vmcnt(0) per load and serialises the whole burst.
+      const int item = min(tid + k * 256, A_ITEMS - 1);
+      const int pix = item >> 3, ch = item & 7;
+      const int y = y0 + pix / 18, x = x0 + pix % 18;
+      const int c = c0 + ch * EPV;
+      const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W && c < p.Cin;
+      const int64_t off = ok ? ((int64_t)(n * p.H + y) * p.W + x) * p.Cin + c : 0;
+      uint4 v = *reinterpret_cast<const uint4*>(gin + off);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
       ra[k] = v;
     }
     if (with_b) {
 #pragma unroll
       for (int k = 0; k < B_LOADS; ++k) {
-        const int item = tid + k * 256;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (item < B_ITEMS) {
-          const int row = item >> 3, ch = item & 7;
-          const int tap = row / BN, co = n0 + row % BN;
-          const int c = c0 + ch * EPV;
-          const int wtap = p.flip ? 8 - tap : tap;
-          if (co < p.Cout && c < p.Cin)
-            v = *reinterpret_cast<const uint4*>(gw + ((int64_t)wtap * p.Cout + co) * p.Cin + c);
-        }
+        const int item = min(tid + k * 256, B_ITEMS - 1);
+        const int row = item >> 3, ch = item & 7;
+        const int tap = row / BN, co = n0 + row % BN;
+        const int c = c0 + ch * EPV;
+        const int wtap = p.flip ? 8 - tap : tap;
+        const bool ok = co < p.Cout && c < p.Cin;
+        const int64_t off = ok ? ((int64_t)wtap * p.Cout + co) * p.Cin + c : 0;
+        uint4 v = *reinterpret_cast<const uint4*>(gw + off);
+        if (!ok) v = make_uint4(0, 0, 0, 0);
         rb[k] = v;
       }
     }

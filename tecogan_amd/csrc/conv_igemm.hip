@@ -110,12 +110,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   int ikh = 0, ikw = 0, ic = 0;  // counters of the step being LOADED
 
   auto load_vec = [&](const TIn* base, int64_t off, int c, bool ok) -> uint4 {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (!ok || c >= p.Cin) return v;
-    if (p.vec) return *reinterpret_cast<const uint4*>(base + off);
+    ok = ok && c < p.Cin;
+    if (p.vec) {
+      // unconditional load from a clamped address + select: a branch per load would make hipcc wait
+      // vmcnt(0) after every load and serialise the panel fetch
+      uint4 v = *reinterpret_cast<const uint4*>(base + (ok ? off : 0));
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      return v;
+    }
     TIn tmp[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) tmp[e] = (c + e < p.Cin) ? base[off + e] : (TIn)0;
+    for (int e = 0; e < EPV; ++e) {
+      const bool oke = ok && (c + e < p.Cin);
+      const TIn t = base[oke ? off + e : 0];
+      tmp[e] = oke ? t : (TIn)0;
+    }
     return *reinterpret_cast<uint4*>(tmp);
   };
 
