@@ -16,6 +16,7 @@
 //     conflict-free; the epilogue (bias, activation, residual, act-grad mask) is the engine's.
 // fp32 uses v_mfma_f32_16x16x4_f32 (exact, K-permuted as in conv_igemm.hip), bf16 v_mfma_f32_16x16x32_bf16.
 #include "common.h"
+#include <type_traits>
 
 struct Conv3P {
   const void* in;
@@ -28,8 +29,8 @@ struct Conv3P {
   int flip;           // 1: taps mirrored (input-gradient form)
   int act;
   float act_alpha;
-  int mask_act;
-  float mask_alpha;
+  float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
+  float mslope;       // act-grad mask: aux > 0 ? 1 : mslope (ReLU 0, LeakyReLU alpha, none 1)
   int tiles_y, tiles_x, ntiles;
 };
 
@@ -65,37 +66,49 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
 
   uint4 ra[A_LOADS], rb[B_LOADS];
 
-  // stage = (tile, chunk); this workgroup owns tiles blockIdx.x, +gridDim.x, ...
+  // ---- per-thread load descriptors, computed ONCE (tile-independent): the per-stage address is then
+  //      scalar tile base + one v_add.  All offsets are 32-bit (tensors are < 2^31 elements).
+  int relA[A_LOADS], dydx[A_LOADS];
+#pragma unroll
+  for (int k = 0; k < A_LOADS; ++k) {
+    const int item = min(tid + k * 256, A_ITEMS - 1);
+    const int pix = item >> 3, ch = item & 7;
+    const int dy = pix / 18, dx = pix % 18;
+    relA[k] = (dy * p.W + dx) * p.Cin + ch * EPV;
+    dydx[k] = dy | (dx << 8) | ((ch * EPV) << 16);
+  }
+  int relB[B_LOADS];          // < 0: row beyond Cout (stays zero)
+#pragma unroll
+  for (int k = 0; k < B_LOADS; ++k) {
+    const int item = min(tid + k * 256, B_ITEMS - 1);
+    const int row = item >> 3, ch = item & 7;
+    const int tap = row / BN, co = n0 + row % BN;
+    const int wtap = p.flip ? 8 - tap : tap;
+    relB[k] = co < p.Cout ? (wtap * p.Cout + co) * p.Cin + ch * EPV : -1;
+  }
+
   auto load_stage = [&](int tile, int chunk, bool with_b) {
     const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
     const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
     const int y0 = ty * TH - 1, x0 = tx * 16 - 1;
     const int c0 = chunk * BK;
+    const int base = ((n * p.H + y0) * p.W + x0) * p.Cin + c0;          // wave-uniform
 #pragma unroll
     for (int k = 0; k < A_LOADS; ++k) {
       // Loads are UNCONDITIONAL from a clamped in-range address and zeroed by a select afterwards: a
       // branch around each load makes hipcc wait vmcnt(0) per load and serialises the whole burst.
-      const int item = min(tid + k * 256, A_ITEMS - 1);
-      const int pix = item >> 3, ch = item & 7;
-      const int y = y0 + pix / 18, x = x0 + pix % 18;
-      const int c = c0 + ch * EPV;
-      const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W && c < p.Cin;
-      const int64_t off = ok ? ((int64_t)(n * p.H + y) * p.W + x) * p.Cin + c : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(gin + off);
+      const int y = y0 + (dydx[k] & 255), x = x0 + ((dydx[k] >> 8) & 255), c = c0 + (dydx[k] >> 16);
+      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && c < p.Cin;
+      uint4 v = *reinterpret_cast<const uint4*>(gin + (ok ? base + relA[k] : 0));
       if (!ok) v = make_uint4(0, 0, 0, 0);
       ra[k] = v;
     }
     if (with_b) {
 #pragma unroll
       for (int k = 0; k < B_LOADS; ++k) {
-        const int item = min(tid + k * 256, B_ITEMS - 1);
-        const int row = item >> 3, ch = item & 7;
-        const int tap = row / BN, co = n0 + row % BN;
-        const int c = c0 + ch * EPV;
-        const int wtap = p.flip ? 8 - tap : tap;
-        const bool ok = co < p.Cout && c < p.Cin;
-        const int64_t off = ok ? ((int64_t)wtap * p.Cout + co) * p.Cin + c : 0;
-        uint4 v = *reinterpret_cast<const uint4*>(gw + off);
+        const int c = c0 + (tid & 7) * EPV;
+        const bool ok = relB[k] >= 0 && c < p.Cin;
+        uint4 v = *reinterpret_cast<const uint4*>(gw + (ok ? relB[k] + c0 : 0));
         if (!ok) v = make_uint4(0, 0, 0, 0);
         rb[k] = v;
       }
@@ -115,6 +128,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
       }
     }
   };
+
+  // fragment bases: lane part + wave part once; every (tap, kk, tile) offset below is a compile-time constant
+  const unsigned char* Afrag = As + (wm * TM * 18 + frow) * ROWB + fg * 16;
+  const unsigned char* Bfrag = Bs + (wn * TN * 16 + frow) * ROWB + fg * 16;
+  const int col0 = n0 + wn * TN * 16 + frow;
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = (p.bias && col0 + j * 16 < p.Cout) ? p.bias[col0 + j * 16] : 0.f;
 
   f32x4 acc[TM][TN];
 
@@ -149,13 +170,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
       for (int kk = 0; kk < 2; ++kk) {
         uint4 af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int ry = wm * TM + i;
-          af[i] = *reinterpret_cast<const uint4*>(As + ((ry + kh) * 18 + frow + kw) * ROWB + kk * 64 + fg * 16);
-        }
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const uint4*>(Afrag + ((i + kh) * 18 + kw) * ROWB + kk * 64);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bfr[j] = *reinterpret_cast<const uint4*>(Bs + (tap * BN + (wn * TN + j) * 16 + frow) * ROWB + kk * 64 + fg * 16);
+          bfr[j] = *reinterpret_cast<const uint4*>(Bfrag + (tap * BN + j * 16) * ROWB + kk * 64);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -176,30 +195,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
     }
 
     if (chunk == nchunk - 1) {             // ---- fused epilogue for this tile ----
+      // 32-bit offsets hoisted per pixel.  none/ReLU/LeakyReLU are the branch-free max(v, v*slope); the rare
+      // tanh/sigmoid layers and the edge tiles (partial rows/columns/channels) take separate, uniformly
+      // selected copies so the common path carries no per-element branches or exec-mask updates.
       const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
       const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 16 + frow;
-        if (col >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+      const int ybase = ty * TH + wm * TM, xbase = tx * 16 + fg * 4;
+      const int pix0 = ((n * p.H + ybase) * p.W + xbase) * p.Cout + col0;
+      const bool has_res = gres != nullptr, has_aux = gaux != nullptr;
+      const bool interior = (ty + 1) * TH <= p.H && (tx + 1) * 16 <= p.W && n0 + BN <= p.Cout;
+      auto epilogue = [&](auto check_tag, auto slow_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value, SLOW = decltype(slow_tag)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int y = ty * TH + wm * TM + i;
-          if (y >= p.H) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int x = tx * 16 + fg * 4 + r;
-            if (x >= p.W) continue;
-            const int64_t idx = ((int64_t)(n * p.H + y) * p.W + x) * p.Cout + col;
-            float v = acc[i][j][r] + bv;
-            v = act_fwd(v, p.act, p.act_alpha);
-            if (gres) v += Elem<TOut>::ld(gres + idx);
-            if (gaux) v *= act_grad_from_out(Elem<TOut>::ld(gaux + idx), p.mask_act, p.mask_alpha);
-            Elem<TOut>::st(gout + idx, v);
+            const int off = pix0 + (i * p.W + r) * p.Cout;
+            const bool pok = !CHECK || (ybase + i < p.H && xbase + r < p.W);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (CHECK && !(pok && col0 + j * 16 < p.Cout)) continue;
+              const int idx = off + j * 16;
+              float v = acc[i][j][r] + bv[j];
+              if constexpr (SLOW) v = act_fwd(v, p.act, p.act_alpha);
+              else v = fmaxf(v, v * p.nslope);
+              if (has_res) v += Elem<TOut>::ld(gres + idx);
+              if (has_aux) v *= Elem<TOut>::ld(gaux + idx) > 0.f ? 1.f : p.mslope;
+              Elem<TOut>::st(gout + idx, v);
+            }
           }
         }
-      }
+      };
+      if (p.act >= TG_ACT_TANH) epilogue(std::true_type{}, std::true_type{});
+      else if (interior) epilogue(std::false_type{}, std::false_type{});
+      else epilogue(std::true_type{}, std::false_type{});
     }
     first = false;
     tile = ntile;
@@ -259,7 +288,10 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
   p.flip = d->mode == 1;
-  p.act = d->act; p.act_alpha = d->act_alpha; p.mask_act = d->mask_act; p.mask_alpha = d->mask_alpha;
+  if (aux && d->mask_act != TG_ACT_RELU && d->mask_act != TG_ACT_LRELU) return 0;   // generic engine handles others
+  p.act = d->act; p.act_alpha = d->act_alpha;
+  p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
+  p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   if (d->in_dtype == TG_F32) launch3_typed<float, float>(p, st);
   else if (d->out_dtype == TG_BF16) launch3_typed<u16, u16>(p, st);
   else launch3_typed<u16, float>(p, st);
