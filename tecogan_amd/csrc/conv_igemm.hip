@@ -20,6 +20,7 @@
 // element j from both operands -- a bijection of k, so the sum is unchanged.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // conv3x3.hip: halo-tile kernel for 3x3 stride-1 SAME convolutions (returns 1 when it took the launch)
 int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
@@ -38,6 +39,7 @@ struct ConvP {
   int mask_act;
   float mask_alpha;
   int vec;  // Cin % (16B worth) == 0 -> 16-byte loads
+  float nslope, mslope;  // act(v) = max(v, v*nslope); mask = aux > 0 ? 1 : mslope
 };
 
 template <typename TIn, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN>
@@ -220,30 +222,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 
   // ---- fused epilogue -------------------------------------------------------
+  // 32-bit offsets; none/ReLU/LeakyReLU as the branch-free max(v, v*slope); tanh/sigmoid and partial tiles
+  // take separate uniformly-selected copies (no per-element branches on the common path).
   TOut* __restrict__ gout = static_cast<TOut*>(p.out);
   const TOut* __restrict__ gres = static_cast<const TOut*>(p.res);
   const TOut* __restrict__ gaux = static_cast<const TOut*>(p.aux);
+  const bool has_res = gres != nullptr, has_aux = gaux != nullptr;
+  const int col0 = n0 + wn * TN * 16 + frow;
+  float bv[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 16 + frow;
-    if (col >= p.Cout) continue;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+  for (int j = 0; j < TN; ++j) bv[j] = (p.bias && col0 + j * 16 < p.Cout) ? p.bias[col0 + j * 16] : 0.f;
+  auto epilogue = [&](auto check_tag, auto slow_tag) {
+    constexpr bool CHECK = decltype(check_tag)::value, SLOW = decltype(slow_tag)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = (wm * TM + i) * 16 + fg * 4 + r;
-        const int pix = out_pix[row];
-        if (pix < 0) continue;
-        const int64_t idx = (int64_t)pix * p.Cout + col;
-        float v = acc[i][j][r] + bv;
-        v = act_fwd(v, p.act, p.act_alpha);
-        if (gres) v += Elem<TOut>::ld(gres + idx);
-        if (gaux) v *= act_grad_from_out(Elem<TOut>::ld(gaux + idx), p.mask_act, p.mask_alpha);
-        Elem<TOut>::st(gout + idx, v);
+        const int pix = out_pix[(wm * TM + i) * 16 + fg * 4 + r];
+        if (CHECK && pix < 0) continue;
+        const int off = pix * p.Cout + col0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (CHECK && col0 + j * 16 >= p.Cout) continue;
+          const int idx = off + j * 16;
+          float v = acc[i][j][r] + bv[j];
+          if constexpr (SLOW) v = act_fwd(v, p.act, p.act_alpha);
+          else v = fmaxf(v, v * p.nslope);
+          if (has_res) v += Elem<TOut>::ld(gres + idx);
+          if (has_aux) {
+            if constexpr (SLOW) v *= act_grad_from_out(Elem<TOut>::ld(gaux + idx), p.mask_act, p.mask_alpha);
+            else v *= Elem<TOut>::ld(gaux + idx) > 0.f ? 1.f : p.mslope;
+          }
+          Elem<TOut>::st(gout + idx, v);
+        }
       }
     }
-  }
+  };
+  const bool slow = p.act >= TG_ACT_TANH || (has_aux && p.mask_act != TG_ACT_RELU && p.mask_act != TG_ACT_LRELU);
+  if (slow) epilogue(std::true_type{}, std::true_type{});
+  else if (m0 + BM <= Mq && n0 + BN <= p.Cout) epilogue(std::false_type{}, std::false_type{});
+  else epilogue(std::true_type{}, std::false_type{});
 }
 
 template <typename TIn, typename TOut, int WM, int WN, int TM, int TN>
@@ -293,6 +311,8 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l; p.mode = d->mode;
   p.act = d->act; p.act_alpha = d->act_alpha; p.mask_act = d->mask_act; p.mask_alpha = d->mask_alpha;
+  p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
+  p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   const int epv = d->in_dtype == TG_F32 ? 4 : 8;
   p.vec = (d->Cin % epv == 0) && (((uintptr_t)in | (uintptr_t)weight) % 16 == 0);
   int nphase = 1, mq_max = d->N * d->Hout * d->Wout;
