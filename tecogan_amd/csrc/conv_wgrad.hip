@@ -22,6 +22,19 @@ struct WgradP {
   int M, chunk;     // total output pixels, pixels per block (multiple of 32)
   int ytiles;
   int ldx, ldy;     // channel strides of X / Y in memory (>= Cx / Cy: zero-padded buffers)
+  int vecx, vecy;   // 4-element vector loads allowed (stride % 4 == 0 and 16/8-byte aligned base)
+};
+
+template <typename T> struct LoadVec4;
+template <> struct LoadVec4<float> {
+  static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+};
+template <> struct LoadVec4<u16> {
+  static __device__ __forceinline__ float4 ld(const u16* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  }
 };
 
 template <typename TX, typename TY>
@@ -56,37 +69,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 
   for (int mb = mbeg; mb < mend; mb += 32) {
     // ---- stage 32 pixels x 64 channels of X (gathered at this tap) and Y -------------
+    // One vector load per item from a clamped address, zeroed by select (no branch around the load: hipcc
+    // would otherwise wait vmcnt(0) per load); the scalar path only serves channel tails / odd strides.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = srow + h * 16;
-      const int m = mb + r;
-      float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx;
-      if (m < mend) {
-        const int ox = m % p.Wy, t = m / p.Wy;
-        const int oy = t % p.Hy, n = t / p.Hy;
-        const int iy = oy * p.s - p.pt + kh, ix = ox * p.s - p.pl + kw;
-        const int cx = cx0 + sgrp * 4, cy = cy0 + sgrp * 4;
-        if (iy >= 0 && iy < p.Hx && ix >= 0 && ix < p.Wx && cx < p.Cx) {
-          const TX* px = gx + ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.ldx + cx;
-          if (cx + 3 < p.Cx) {
-            vx = make_float4(Elem<TX>::ld(px), Elem<TX>::ld(px + 1), Elem<TX>::ld(px + 2), Elem<TX>::ld(px + 3));
-          } else {
-            vx.x = Elem<TX>::ld(px);
-            if (cx + 1 < p.Cx) vx.y = Elem<TX>::ld(px + 1);
-            if (cx + 2 < p.Cx) vx.z = Elem<TX>::ld(px + 2);
-          }
-        }
-        if (cy < p.Cy) {
-          const TY* py = gy + (int64_t)m * p.ldy + cy;
-          if (cy + 3 < p.Cy) {
-            vy = make_float4(Elem<TY>::ld(py), Elem<TY>::ld(py + 1), Elem<TY>::ld(py + 2), Elem<TY>::ld(py + 3));
-          } else {
-            vy.x = Elem<TY>::ld(py);
-            if (cy + 1 < p.Cy) vy.y = Elem<TY>::ld(py + 1);
-            if (cy + 2 < p.Cy) vy.z = Elem<TY>::ld(py + 2);
-          }
-        }
+      const int m = min(mb + r, mend - 1);
+      const bool mok = mb + r < mend;
+      const int ox = m % p.Wy, t = m / p.Wy;
+      const int oy = t % p.Hy, n = t / p.Hy;
+      const int iy = oy * p.s - p.pt + kh, ix = ox * p.s - p.pl + kw;
+      const int cx = cx0 + sgrp * 4, cy = cy0 + sgrp * 4;
+      const bool xok = mok && iy >= 0 && iy < p.Hx && ix >= 0 && ix < p.Wx && cx < p.Cx;
+      const bool yok = mok && cy < p.Cy;
+      const int64_t xoff = xok ? ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.ldx + cx : 0;
+      const int64_t yoff = yok ? (int64_t)m * p.ldy + cy : 0;
+      float4 vx, vy;
+      if (p.vecx && cx + 3 < p.Cx) {
+        vx = LoadVec4<TX>::ld(gx + xoff);
+      } else {
+        const int nx = xok ? min(p.Cx - cx, 4) : 0;
+        vx.x = nx > 0 ? Elem<TX>::ld(gx + xoff) : 0.f;
+        vx.y = nx > 1 ? Elem<TX>::ld(gx + xoff + 1) : 0.f;
+        vx.z = nx > 2 ? Elem<TX>::ld(gx + xoff + 2) : 0.f;
+        vx.w = nx > 3 ? Elem<TX>::ld(gx + xoff + 3) : 0.f;
       }
+      if (p.vecy && cy + 3 < p.Cy) {
+        vy = LoadVec4<TY>::ld(gy + yoff);
+      } else {
+        const int ny = yok ? min(p.Cy - cy, 4) : 0;
+        vy.x = ny > 0 ? Elem<TY>::ld(gy + yoff) : 0.f;
+        vy.y = ny > 1 ? Elem<TY>::ld(gy + yoff + 1) : 0.f;
+        vy.z = ny > 2 ? Elem<TY>::ld(gy + yoff + 2) : 0.f;
+        vy.w = ny > 3 ? Elem<TY>::ld(gy + yoff + 3) : 0.f;
+      }
+      if (!xok) vx = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!yok) vy = make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(&Xs[r * PITCH + sgrp * 4]) = vx;
       *reinterpret_cast<float4*>(&Ys[r * PITCH + sgrp * 4]) = vy;
     }
@@ -146,6 +164,8 @@ extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, 
   p.ldx = ldx > 0 ? ldx : d->Cin;
   p.ldy = ldy > 0 ? ldy : d->Cout;
   TG_CHECK_ARG(p.ldx >= d->Cin && p.ldy >= d->Cout, "channel stride smaller than channel count");
+  p.vecx = p.ldx % 4 == 0 && ((uintptr_t)x % 16 == 0);
+  p.vecy = p.ldy % 4 == 0 && ((uintptr_t)y % 16 == 0);
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;

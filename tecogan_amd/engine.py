@@ -149,12 +149,10 @@ class TrainEngine:
         # ---- recurrent generator (lib/Teco.py:125-155) ------------------------------------------------
         gen = torch.empty(T, B, H, H, 3, device=self.dev)
         flow_t = flow.view(T - 1, B, h, h, 2)
-        saved = []
+        seq = self.G.begin_sequence(T, B, h, h, self.dev)
         for t in range(T):
-            x_in = torch.empty(B, h, h, GEN_CPAD, device=self.dev, dtype=self.act_dtype)
-            K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], x_in, 0.5, 0.5)
-            _, sv = self.G.forward(x_in, out=gen[t])
-            saved.append(sv)
+            K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], seq["x_in"][t], 0.5, 0.5)
+            self.G.forward_t(t, gen[t])
         self.gen = gen
         # ---- generator losses seeded into d_gen -------------------------------------------------------
         nhr = float(T * B * H * H)
@@ -169,10 +167,10 @@ class TrainEngine:
         # ---- backward through the recurrence ------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
         for t in range(T - 1, -1, -1):
-            dx = self.G.backward(saved[t], d_gen[t], need_dx=t > 0)
-            saved[t] = None
+            dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
+        self.G.wgrad_sequence()             # shared weights: one wgrad per layer over all T*B frames
         self.Fn.backward(fsaved, d_flow)
 
     def _program_update(self):

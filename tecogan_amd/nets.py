@@ -26,7 +26,7 @@ def _empty(shape, dtype, like):
 # --------------------------------------------------------------------------------------------------
 # layer primitives
 # --------------------------------------------------------------------------------------------------
-def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None):
+def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None, out=None):
     """slim.conv2d SAME (reference lib/ops.py:47-56) + fused epilogue.  x [N,H,W,Cin_pad]."""
     e = ps.entries[wname]
     N, H, W, Cp = x.shape
@@ -34,13 +34,14 @@ def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, o
     k = e["k"]
     Ho, pt = K.same_pad(H, k, stride)
     Wo, pl = K.same_pad(W, k, stride)
-    out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
+    if out is None:
+        out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
     d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha)
     K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
     return out
 
 
-def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=ACT_NONE, mask_alpha=0.0):
+def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, out=None):
     """Input gradient of conv_fwd: transposed mode over the natural (HWIO) copy.  -> [N,H,W,Cin_pad]."""
     e = ps.entries[wname]
     N, Ho, Wo, Co = dy.shape
@@ -48,7 +49,7 @@ def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=A
     k = e["k"]
     _, pt = K.same_pad(H, k, stride)
     _, pl = K.same_pad(W, k, stride)
-    dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy)
+    dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, Ho, Wo, Co, H, W, e["Apad"], k, k, stride, pt, pl, 1, K.dt(dy), K.dt(dx), 0, 0.0,
                     mask_act, mask_alpha)
     K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)
@@ -67,22 +68,23 @@ def conv_wgrad(ps, wname, bname, x, dy, stride=1):
     K.conv_wgrad(d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, ldx=Cp, ldy=Co)
 
 
-def deconv_fwd(ps, wname, bname, x, act=ACT_NONE, alpha=0.0):
+def deconv_fwd(ps, wname, bname, x, act=ACT_NONE, alpha=0.0, out=None):
     """slim.conv2d_transpose k3 s2 SAME (reference lib/ops.py:35-44, [TF1] A.2): transposed mode, pad 0."""
     e = ps.entries[wname]                      # TF layout [kh,kw,Cout,Cin] -> A = Cout, B = Cin
     N, H, W, Ci = x.shape
     k = e["k"]
-    out = _empty((N, 2 * H, 2 * W, e["A"]), ps.act_dtype, x)
+    if out is None:
+        out = _empty((N, 2 * H, 2 * W, e["A"]), ps.act_dtype, x)
     d = K.conv_desc(N, H, W, Ci, 2 * H, 2 * W, e["A"], k, k, 2, 0, 0, 1, K.dt(x), K.dt(out), act, alpha)
     K.conv_forward(d, x, ps.packed(wname, False), ps.view(bname), None, None, out)
     return out
 
 
-def deconv_bwd_data(ps, wname, dy, aux=None, mask_act=ACT_NONE, mask_alpha=0.0):
+def deconv_bwd_data(ps, wname, dy, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, out=None):
     e = ps.entries[wname]
     N, H2, W2, Co = dy.shape
     k = e["k"]
-    dx = _empty((N, H2 // 2, W2 // 2, e["B"]), ps.act_dtype, dy)
+    dx = _empty((N, H2 // 2, W2 // 2, e["B"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, H2, W2, Co, H2 // 2, W2 // 2, e["B"], k, k, 2, 0, 0, 0, K.dt(dy), K.dt(dx), 0, 0.0,
                     mask_act, mask_alpha)
     K.conv_forward(d, dy, ps.packed(wname, True), None, None, aux, dx)
@@ -106,59 +108,120 @@ GEN_CPAD = pad8(51)
 
 
 class Generator:
+    """generator_F.  Two ways to run it:
+      * `forward(x_in)`                     : stateless (inference / API calls), nothing kept;
+      * `begin_sequence` + `forward_t` / `backward_t` + `wgrad_sequence` : the training recurrence.  Every layer's
+        activations and output-gradients of all T frames live in frame-major `[T*B, ...]` buffers, the per-frame
+        backward only runs the (sequential) bwd_data chain, and the weight gradients -- the weights are shared by
+        all frames -- are computed ONCE per layer over the whole sequence afterwards: T x fewer launches and
+        T x fewer atomics than per-frame wgrad, and off the critical path of the recurrence."""
     P = "generator/generator_unit/"
 
     def __init__(self, ps, num_resblock):
         self.ps, self.nres = ps, num_resblock
+        self.seq = None
 
-    def forward(self, x_in, keep=True, out=None):
+    # ---- stateless forward -----------------------------------------------------------------------
+    def forward(self, x_in, keep=False, out=None):
         """x_in [B,h,w,56] (LR frame | s2d(warped prev HR) | 0-pad) -> HR frame [B,4h,4w,3] fp32 in [-1,1]."""
+        assert not keep, "training uses begin_sequence/forward_t"
         ps, p = self.ps, self.P
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU)
-        acts = [a]
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU)
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a)
-            acts += [r, a]
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
         t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU)
         t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU)
         c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1,
                      out_dtype=_F32)
         out = K.bicubic_add_preprocess(c, x_in, torch.empty_like(c) if out is None else out)  # (c+bicubic(LR))*2-1
-        saved = (x_in, acts, t1, t2) if keep else None
-        return out, saved
+        return out, None
 
-    def backward(self, saved, d_out, need_dx=True):
-        """d_out: gradient w.r.t. the HR frame (fp32).  Accumulates weight gradients; returns d x_in or None."""
-        ps, p = self.ps, self.P
-        x_in, acts, t1, t2 = saved
-        h, w = x_in.shape[1], x_in.shape[2]
-        dc = K.act_backward(d_out, None, _empty(d_out.shape, ps.act_dtype, d_out), scale=2.0)   # d/dc of (.)*2-1
-        wn, bn = p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases"
-        conv_wgrad(ps, wn, bn, t2, dc)
-        g = conv_bwd_data(ps, wn, dc, (4 * h, 4 * w), 1, aux=t2, mask_act=ACT_RELU)            # d pre-ReLU of tran2
+    # ---- training recurrence -----------------------------------------------------------------------
+    def begin_sequence(self, T, B, h, w, dev):
+        """Allocate the frame-major activation / gradient buffers of one training step."""
+        dt, n = self.ps.act_dtype, self.nres
+
+        def buf(hh, ww, c, dtype=None):
+            return torch.empty(T, B, hh, ww, c, device=dev, dtype=dtype or dt)
+
+        q = dict(T=T, B=B, h=h, w=w)
+        q["x_in"] = buf(h, w, GEN_CPAD)
+        q["a"] = [buf(h, w, 64) for _ in range(n + 1)]          # a[0] = relu(input conv), a[i] = block i output
+        q["r"] = [None] + [buf(h, w, 64) for _ in range(n)]     # r[i] = relu(conv_1 of block i)
+        q["t1"], q["t2"] = buf(2 * h, 2 * w, 64), buf(4 * h, 4 * w, 64)
+        q["c"] = torch.empty(B, 4 * h, 4 * w, 3, device=dev)    # scratch (per frame)
+        # gradients w.r.t. each conv's pre-activation output
+        q["g_in"] = buf(h, w, 64)
+        q["g_c1"] = [None] + [buf(h, w, 64) for _ in range(n)]
+        q["g_c2"] = [None] + [buf(h, w, 64) for _ in range(n)]
+        q["g_t1"], q["g_t2"] = buf(2 * h, 2 * w, 64), buf(4 * h, 4 * w, 64)
+        q["g_out"] = buf(4 * h, 4 * w, 3)
+        q["dx_in"] = torch.empty(B, h, w, GEN_CPAD, device=dev, dtype=dt)
+        self.seq = q
+        return q
+
+    def forward_t(self, t, out):
+        """Frame t: reads seq['x_in'][t] (filled by the warp kernel), writes the HR frame into `out`."""
+        ps, p, q = self.ps, self.P, self.seq
+        x_in = q["x_in"][t]
+        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
+                     out=q["a"][0][t])
+        for i in range(1, self.nres + 1):
+            s = p + "resblock_%d/" % i
+            r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t])
+            a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
+                         out=q["a"][i][t])
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
-        deconv_wgrad(ps, s % 2 + "weights", s % 2 + "biases", t1, g)
-        g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=t1, mask_act=ACT_RELU)               # d pre-ReLU of tran1
-        a_last = acts[-1]
-        deconv_wgrad(ps, s % 1 + "weights", s % 1 + "biases", a_last, g)
-        g = deconv_bwd_data(ps, s % 1 + "weights", g)                                          # d a_N
-        for i in range(self.nres, 0, -1):
+        t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU, out=q["t1"][t])
+        t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU, out=q["t2"][t])
+        c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1, out=q["c"])
+        return K.bicubic_add_preprocess(c, x_in, out)
+
+    def backward_t(self, t, d_out, need_dx=True):
+        """bwd_data chain of frame t (no weight gradients here).  Returns d x_in [B,h,w,56] or None."""
+        ps, p, q, n = self.ps, self.P, self.seq, self.nres
+        h, w = q["h"], q["w"]
+        dc = K.act_backward(d_out, None, q["g_out"][t], scale=2.0)                             # d/dc of (.)*2-1
+        g = conv_bwd_data(ps, p + "output_stage/conv/Conv/weights", dc, (4 * h, 4 * w), 1, aux=q["t2"][t],
+                          mask_act=ACT_RELU, out=q["g_t2"][t])
+        s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
+        g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=q["t1"][t], mask_act=ACT_RELU, out=q["g_t1"][t])
+        g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t])
+        if n == 0:
+            g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
+        for i in range(n, 0, -1):
             sc = p + "resblock_%d/" % i
-            a_prev, r = acts[2 * i - 2], acts[2 * i - 1]
-            conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", r, g)
-            dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=r, mask_act=ACT_RELU)
-            conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", a_prev, dr)
-            # d a_prev = bwd(conv_1)(dr) + skip gradient; the first block's input is itself a ReLU output
+            dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
+                               out=q["g_c1"][i][t])
+            # d a_{i-1} = bwd(conv_1)(dr) + skip gradient; block 1's input is itself a ReLU output (masked here)
             g = conv_bwd_data(ps, sc + "conv_1/Conv/weights", dr, (h, w), 1, res=g,
-                              aux=a_prev if i == 1 else None, mask_act=ACT_RELU if i == 1 else ACT_NONE)
-        if self.nres == 0:
-            g = K.act_backward(g, acts[0], torch.empty_like(g), ACT_RELU)
-        wn, bn = p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases"
-        conv_wgrad(ps, wn, bn, x_in, g)
-        return conv_bwd_data(ps, wn, g, (h, w), 1) if need_dx else None
+                              aux=q["a"][0][t] if i == 1 else None, mask_act=ACT_RELU if i == 1 else ACT_NONE,
+                              out=q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t])
+        if not need_dx:
+            return None
+        return conv_bwd_data(ps, p + "input_stage/conv/Conv/weights", g, (h, w), 1, out=q["dx_in"])
+
+    def wgrad_sequence(self):
+        """All weight / bias gradients of the step: one launch per layer over the T*B frames."""
+        ps, p, q, n = self.ps, self.P, self.seq, self.nres
+
+        def flat(x):
+            return x.view(-1, *x.shape[2:])
+
+        conv_wgrad(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", flat(q["x_in"]),
+                   flat(q["g_in"]))
+        for i in range(1, n + 1):
+            sc = p + "resblock_%d/" % i
+            conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", flat(q["a"][i - 1]), flat(q["g_c1"][i]))
+            conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", flat(q["r"][i]), flat(q["g_c2"][i]))
+        s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
+        deconv_wgrad(ps, s % 1 + "weights", s % 1 + "biases", flat(q["a"][n]), flat(q["g_t1"]))
+        deconv_wgrad(ps, s % 2 + "weights", s % 2 + "biases", flat(q["t1"]), flat(q["g_t2"]))
+        conv_wgrad(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", flat(q["t2"]),
+                   flat(q["g_out"]))
 
 
 # --------------------------------------------------------------------------------------------------
