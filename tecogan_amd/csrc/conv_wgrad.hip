@@ -12,6 +12,10 @@
 // (weight gradients are accumulated in full fp32 products; the flat fp32 gradient buffer is also
 // the RCCL all-reduce buffer).  grid = (taps, Cx/64 * Cy/64 tiles, pixel chunks).
 #include "common.h"
+#include <stdlib.h>
+
+int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx, const void* y, int y_dtype, int ldy,
+                      float* dw, float* dbias, hipStream_t st);
 
 struct WgradP {
   const void* x;
@@ -166,6 +170,8 @@ extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, 
   TG_CHECK_ARG(p.ldx >= d->Cin && p.ldy >= d->Cout, "channel stride smaller than channel count");
   p.vecx = p.ldx % 4 == 0 && ((uintptr_t)x % 16 == 0);
   p.vecy = p.ldy % 4 == 0 && ((uintptr_t)y % 16 == 0);
+  if (tg_wgrad_bf16_try(d, x, x_dtype, p.ldx, y, y_dtype, p.ldy, dw, dbias, static_cast<hipStream_t>(stream)))
+    TG_CHECK_LAUNCH();
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
@@ -230,4 +236,157 @@ extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* o
   if (dtype == TG_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, C, out);
   else hipLaunchKernelGGL((colsum_kernel<u16>), grid, dim3(256), 0, st, (const u16*)x, rows, C, out);
   TG_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA weight gradient (throughput mode: both operands bf16, 16-byte aligned channel strides).
+// dW[tap][cx][cy] += sum_pix X[pix@tap][cx] * Y[pix][cy] with v_mfma_f32_16x16x32_bf16: the reduction index
+// (pixels) must be the contiguous one inside a fragment, the opposite of NHWC.  Each thread therefore loads one
+// pixel PAIR x 8 channels (two 16-byte loads) and writes 8 packed {pixel p, pixel p+1} dwords into a transposed
+// LDS panel Xt[channel][64 pixels]; fragments are then two ds_read_b64 per 8 pixels.  Panel pitch 136 B keeps the
+// transposing writes conflict-free (8 rows * 34 dwords = 16 mod 32).  Waves 0-1 stage X, waves 2-3 stage Y.
+// K-step = 64 pixels; each wave owns a 32x32 quadrant of the 64x64 (cx, cy) tile; fp32 accumulate; split-K over
+// pixel chunks with fp32 atomics into the flat gradient buffer.
+struct WgradBP {
+  const u16* x;
+  const u16* y;
+  float* dw;
+  float* dbias;
+  int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
+  int M, chunk, ytiles, ldx, ldy;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
+  constexpr int ROWB = 136;                       // bytes per channel row: 64 pixels * 2 B + 8 pad
+  __shared__ __attribute__((aligned(16))) unsigned char Xt[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Yt[64 * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tap = blockIdx.x, kh = tap / p.KW, kw = tap % p.KW;
+  const int xt = blockIdx.y / p.ytiles, yt = blockIdx.y % p.ytiles;
+  const int cx0 = xt * 64, cy0 = yt * 64;
+  const int mbeg = blockIdx.z * p.chunk, mend = min(mbeg + p.chunk, p.M);
+  const bool do_bias = p.dbias != nullptr && tap == 0 && xt == 0;
+  const int frow = lane & 15, fg = lane >> 4;
+  // staging role: threads 0..127 -> X, 128..255 -> Y; item = (pixel pair 0..31, channel octet 0..7)... 256 items each,
+  // two items per thread (pairs pp and pp+16)
+  const bool stage_x = tid < 128;
+  const int st = tid & 127, oct = st >> 4, pp0 = st & 15;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  for (int mb = mbeg; mb < mend; mb += 64) {
+    uint4 v[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int m_raw = mb + (pp0 + h * 16) * 2 + q;
+        const int m = min(m_raw, mend - 1);
+        bool ok = m_raw < mend;
+        int64_t off;
+        if (stage_x) {
+          const int ox = m % p.Wy, t = m / p.Wy;
+          const int oy = t % p.Hy, n = t / p.Hy;
+          const int iy = oy * p.s - p.pt + kh, ix = ox * p.s - p.pl + kw;
+          const int c = cx0 + oct * 8;
+          ok = ok && iy >= 0 && iy < p.Hx && ix >= 0 && ix < p.Wx && c < p.ldx;
+          off = ok ? ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.ldx + c : 0;
+        } else {
+          const int c = cy0 + oct * 8;
+          ok = ok && c < p.ldy;
+          off = ok ? (int64_t)m * p.ldy + c : 0;
+        }
+        uint4 t4 = *reinterpret_cast<const uint4*>((stage_x ? p.x : p.y) + off);   // unconditional + select
+        if (!ok) t4 = make_uint4(0, 0, 0, 0);
+        v[h][q] = t4;
+      }
+    }
+    unsigned char* panel = stage_x ? Xt : Yt;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[h][0]);   // pixel 2pp   : channels 8*oct .. +7
+      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[h][1]);   // pixel 2pp+1
+      const int pp = pp0 + h * 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // channels 2e, 2e+1 of the octet: {lo = pixel 2pp, hi = pixel 2pp+1}
+        const uint32_t c0 = (a[e] & 0xffffu) | (b[e] << 16);
+        const uint32_t c1 = (a[e] >> 16) | (b[e] & 0xffff0000u);
+        *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e) * ROWB + pp * 4) = c0;
+        *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e + 1) * ROWB + pp * 4) = c1;
+      }
+    }
+    __syncthreads();
+    if (do_bias && tid < 64) {
+      const uint32_t* row = reinterpret_cast<const uint32_t*>(Yt + tid * ROWB);
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) bsum += __uint_as_float(row[k] << 16) + __uint_as_float(row[k] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {                 // 2 x 32 pixels
+      bf16x8 af[2], bfm[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* r = Xt + (wm * 32 + i * 16 + frow) * ROWB + kk * 64 + fg * 16;
+        uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 8);
+        uint4 w4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        af[i] = *reinterpret_cast<bf16x8*>(&w4);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned char* r = Yt + (wn * 32 + j * 16 + frow) * ROWB + kk * 64 + fg * 16;
+        uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 8);
+        uint4 w4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        bfm[j] = *reinterpret_cast<bf16x8*>(&w4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfm[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* __restrict__ dw = p.dw + (int64_t)tap * p.Cx * p.Cy;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cx = cx0 + wm * 32 + i * 16 + fg * 4 + r;
+        const int cy = cy0 + wn * 32 + j * 16 + frow;
+        if (cx < p.Cx && cy < p.Cy) unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[i][j][r]);
+      }
+  if (do_bias && tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, bsum);
+}
+
+// returns 1 if launched
+int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx, const void* y, int y_dtype, int ldy,
+                      float* dw, float* dbias, hipStream_t st) {
+  static const bool enabled = getenv("TG_NO_WGRAD_BF16") == nullptr;
+  if (!enabled || x_dtype != TG_BF16 || y_dtype != TG_BF16) return 0;
+  if (ldx % 8 || ldy % 8 || (((uintptr_t)x | (uintptr_t)y) & 15)) return 0;
+  WgradBP p;
+  p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;
+  p.N = d->N; p.Hx = d->Hin; p.Wx = d->Win; p.Cx = d->Cin; p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.M = d->N * d->Hout * d->Wout; p.ldx = ldx; p.ldy = ldy;
+  const int xtiles = (p.Cx + 63) / 64;
+  p.ytiles = (p.Cy + 63) / 64;
+  const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
+  int ksplit = (512 + base_blocks - 1) / base_blocks;               // ~512 workgroups: atomics stay < 2.1 M
+  const int max_split = (p.M + 127) / 128;
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
+  ksplit = (p.M + p.chunk - 1) / p.chunk;
+  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(d->KH * d->KW, xtiles * p.ytiles, ksplit), dim3(256), 0, st, p);
+  return 1;
 }

@@ -385,3 +385,39 @@ def test_pack_weights():
         assert torch.equal(dst[:9 * 8 * 16], ref0) and torch.equal(dst[9 * 8 * 16:], ref1)
         K.pack_weights(flat, dst, tab, 2, False)
         assert torch.equal(dst, flat.to(dtype))
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 3, 1), (1, 9, 11, 32, 128, 4, 2), (3, 7, 5, 128, 64, 3, 1),
+                                  (40, 32, 32, 64, 64, 3, 1), (2, 16, 16, 256, 8, 1, 1)])
+def test_wgrad_bf16_mfma_path(case):
+    """bf16-MFMA weight gradient (transposed LDS staging) vs autograd on the same bf16-rounded operands."""
+    N, H, W, Cin, Cout, k, s = case
+    x = rnd(N, H, W, Cin, seed=1).bfloat16()
+    Ho, pt = K.same_pad(H, k, s)
+    Wo, pl = K.same_pad(W, k, s)
+    gy = rnd(N, Ho, Wo, Cout, seed=5).bfloat16()
+    xr = x.float().requires_grad_()
+    w = torch.zeros(k, k, Cin, Cout, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    O.conv2(xr, w, b, s).backward(gy.float())
+    d = K.conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 0, TG_BF16, TG_BF16)
+    dw = torch.zeros(k, k, Cin, Cout, device=DEV)
+    db = torch.zeros(Cout, device=DEV)
+    K.conv_wgrad(d, x.to(DEV), gy.to(DEV), dw, db)
+    close(dw, w.grad, 3e-4, "bf16 wgrad %s" % (case,))
+    close(db, b.grad, 3e-4, "bf16 bgrad %s" % (case,))
+
+
+def test_wgrad_bf16_padded_channel_stride():
+    """First-layer case: 51 logical input channels stored with stride 56 (zero pad) -> dW is [3,3,51,64]."""
+    N, H, W = 2, 8, 8
+    x51 = rnd(N, H, W, 51, seed=1).bfloat16()
+    x56 = torch.cat((x51, torch.zeros(N, H, W, 5, dtype=torch.bfloat16)), -1).contiguous()
+    gy = rnd(N, H, W, 64, seed=5).bfloat16()
+    xr = x51.float().requires_grad_()
+    w = torch.zeros(3, 3, 51, 64, requires_grad=True)
+    O.conv2(xr, w, None, 1).backward(gy.float())
+    d = K.conv_desc(N, H, W, 51, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16)
+    dw = torch.zeros(3, 3, 51, 64, device=DEV)
+    K.conv_wgrad(d, x56.to(DEV), gy.to(DEV), dw, None, ldx=56, ldy=64)
+    close(dw, w.grad, 3e-4, "padded-stride bf16 wgrad")
