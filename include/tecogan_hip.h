@@ -90,9 +90,9 @@ int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, int ldx /*c
 /* out[c] += sum over rows of x[rows][C]  (bias gradient helper) */
 int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream);
 
-/* Weight re-layout for `count` tensors described by the device table `tab` (6 x int64 per tensor:
- * src offset, dst offset (elements), taps, A, B, Apad).  src is [tap][A][B] fp32;
- * transpose=1: dst[tap][b][a_pad] ; transpose=0: dst[tap][a_pad][b] ; rows a >= A are zero
+/* Weight re-layout for `count` tensors described by the device table `tab` (7 x int64 per tensor:
+ * src offset, dst offset (elements), taps, A, B, Apad, Bpad).  src is [tap][A][B] fp32;
+ * transpose=1: dst[tap][b][a_pad] ; transpose=0: dst[tap][a_pad][b_pad] ; rows a >= A / columns b >= B are zero
  * (channel padding of the first layers: 51->56, 6->8, 27->32, 3->8). */
 int tg_pack_weights(const float* src_base, void* dst_base, int dst_dtype, const int64_t* tab,
                     int count, int transpose, void* stream);
@@ -153,7 +153,7 @@ int tg_act_backward(const void* d_out, const void* y /*nullable*/, void* d_in, i
 /* out[pix][0:Ca] = a ; [Ca:Ca+Cb] = b ; [Ca+Cb:Cpad] = 0  -- tf.concat of lib/Teco.py:108, main.py:209
  * (fnet input) and the channel padding of first-layer inputs. */
 int tg_concat2_pad(const float* a, int Ca, const float* b /*nullable*/, int Cb, void* out, int out_dtype, int Cpad,
-                   int64_t npix, void* stream);
+                   int64_t npix, float scale /*applied to every value*/, void* stream);
 
 /* out (=|+=) alpha*a + beta*b   (loss-gradient seeds: lib/Teco.py:320-331) */
 int tg_lincomb(const float* a, const float* b /*nullable*/, float* out, int64_t n, float alpha, float beta,

@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const TI* __restrict__ d_o
 // out[pix][0:Ca] = a, [Ca:Ca+Cb] = b, rest 0  (builds the zero-padded NHWC inputs of the first convs)
 template <typename TO>
 __global__ __launch_bounds__(256) void concat2_pad_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b,
-                                                          int Cb, TO* __restrict__ out, int Cpad, int64_t npix) {
+                                                          int Cb, TO* __restrict__ out, int Cpad, int64_t npix,
+                                                          float scale) {
   const int64_t n = npix * Cpad;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % Cpad);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void concat2_pad_kernel(const float* __restric
     float v = 0.f;
     if (c < Ca) v = a[pix * Ca + c];
     else if (c < Ca + Cb) v = b[pix * Cb + c - Ca];
-    Elem<TO>::st(out + e, v);
+    Elem<TO>::st(out + e, v * scale);
   }
 }
 
@@ -326,9 +327,10 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
 template <typename TD>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src, TD* __restrict__ dst,
                                                            const int64_t* __restrict__ tab, int transpose) {
-  const int64_t* t = tab + (int64_t)blockIdx.y * 6;
+  const int64_t* t = tab + (int64_t)blockIdx.y * 7;
   const int64_t so = t[0], dof = t[1], taps = t[2];
-  const int A = (int)t[3], Bd = (int)t[4], Ap = (int)t[5];   // src [tap][A][B]; A zero-padded to Ap in dst
+  const int A = (int)t[3], Bs = (int)t[4], Ap = (int)t[5];   // src [tap][A][B]; A zero-padded to Ap in dst
+  const int Bd = transpose ? Bs : (int)t[6];                   // natural copy: B zero-padded to Bp as well
   const int64_t n = taps * Ap * Bd;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     int a, b;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
       a = (int)(r % Ap);
       tap = r / Ap;
     }
-    Elem<TD>::st(dst + dof + e, a < A ? src[so + (tap * A + a) * Bd + b] : 0.f);
+    Elem<TD>::st(dst + dof + e, (a < A && b < Bs) ? src[so + (tap * A + a) * Bs + b] : 0.f);
   }
 }
 
@@ -433,11 +435,11 @@ extern "C" int tg_act_backward(const void* d_out, const void* y, void* d_in, int
 }
 
 extern "C" int tg_concat2_pad(const float* a, int Ca, const float* b, int Cb, void* out, int out_dtype, int Cpad,
-                              int64_t npix, void* stream) {
+                              int64_t npix, float scale, void* stream) {
   TG_CHECK_ARG(a && out && Ca > 0 && Cb >= 0 && (b || Cb == 0) && Cpad >= Ca + Cb && npix > 0, "bad argument");
   dim3 grid(grid_1d(npix * Cpad, 256));
-  if (out_dtype == TG_F32) hipLaunchKernelGGL((concat2_pad_kernel<float>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (float*)out, Cpad, npix);
-  else if (out_dtype == TG_BF16) hipLaunchKernelGGL((concat2_pad_kernel<u16>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (u16*)out, Cpad, npix);
+  if (out_dtype == TG_F32) hipLaunchKernelGGL((concat2_pad_kernel<float>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (float*)out, Cpad, npix, scale);
+  else if (out_dtype == TG_BF16) hipLaunchKernelGGL((concat2_pad_kernel<u16>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (u16*)out, Cpad, npix, scale);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }

@@ -37,7 +37,8 @@ class TrainEngine:
         specs["fnet"] = fnet_spec()
         if gan:
             specs["tdiscriminator"] = discriminator_spec()
-        self.ps = ParamStore(specs, self.dev, act_dtype)
+        self.ps = ParamStore(specs, self.dev, act_dtype,
+                             bpad=("generator/generator_unit/output_stage/conv/Conv/weights",))
         vals = OrderedDict()
         vals.update(init_values(specs["generator"], seed))
         vals.update(init_values(specs["fnet"], seed + 1))

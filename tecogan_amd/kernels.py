@@ -139,9 +139,9 @@ def act_backward(d_out, y, d_in, act=0, alpha=0.0, scale=1.0):
     return d_in
 
 
-def concat2_pad(a, b, out):
+def concat2_pad(a, b, out, scale=1.0):
     Ca, Cb, Cpad = a.shape[-1], (b.shape[-1] if b is not None else 0), out.shape[-1]
-    check(lib().tg_concat2_pad(_p(a), Ca, _p(b), Cb, _p(out), dt(out), Cpad, out.numel() // Cpad, _stream()),
+    check(lib().tg_concat2_pad(_p(a), Ca, _p(b), Cb, _p(out), dt(out), Cpad, out.numel() // Cpad, scale, _stream()),
           "tg_concat2_pad")
     return out
 

@@ -64,7 +64,7 @@ def conv_wgrad(ps, wname, bname, x, dy, stride=1):
     k = e["k"]
     _, pt = K.same_pad(H, k, stride)
     _, pl = K.same_pad(W, k, stride)
-    d = K.conv_desc(N, H, W, e["A"], Ho, Wo, Co, k, k, stride, pt, pl, 0, 0, 0)
+    d = K.conv_desc(N, H, W, e["A"], Ho, Wo, e["B"], k, k, stride, pt, pl, 0, 0, 0)     # logical channel counts
     K.conv_wgrad(d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, ldx=Cp, ldy=Co)
 
 
@@ -158,7 +158,7 @@ class Generator:
         q["g_c1"] = [None] + [buf(h, w, 64) for _ in range(n)]
         q["g_c2"] = [None] + [buf(h, w, 64) for _ in range(n)]
         q["g_t1"], q["g_t2"] = buf(2 * h, 2 * w, 64), buf(4 * h, 4 * w, 64)
-        q["g_out"] = buf(4 * h, 4 * w, 3)
+        q["g_out"] = buf(4 * h, 4 * w, 8)                       # 3 real channels, zero-padded: 16-B rows for the MFMA paths
         q["dx_in"] = torch.empty(B, h, w, GEN_CPAD, device=dev, dtype=dt)
         self.seq = q
         return q
@@ -184,7 +184,7 @@ class Generator:
         """bwd_data chain of frame t (no weight gradients here).  Returns d x_in [B,h,w,56] or None."""
         ps, p, q, n = self.ps, self.P, self.seq, self.nres
         h, w = q["h"], q["w"]
-        dc = K.act_backward(d_out, None, q["g_out"][t], scale=2.0)                             # d/dc of (.)*2-1
+        dc = K.concat2_pad(d_out, None, q["g_out"][t], scale=2.0)                              # d/dc of (.)*2-1
         g = conv_bwd_data(ps, p + "output_stage/conv/Conv/weights", dc, (4 * h, 4 * w), 1, aux=q["t2"][t],
                           mask_act=ACT_RELU, out=q["g_t2"][t])
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"

@@ -113,7 +113,9 @@ def init_values(spec, seed, he_normal=False):
 class ParamStore:
     """One flat fp32 buffer + compute copies.  `specs`: OrderedDict scope -> OrderedDict(name -> shape)."""
 
-    def __init__(self, specs, device, act_dtype=torch.float32, trainable=True):
+    def __init__(self, specs, device, act_dtype=torch.float32, trainable=True, bpad=()):
+        """bpad: names of weights whose OUTPUT channels are also padded to a multiple of 8 in the natural copy
+        (layers whose output-gradient is kept channel-padded, e.g. the 3-channel generator output conv)."""
         self.device, self.act_dtype, self.trainable = device, act_dtype, trainable
         self.entries = OrderedDict()
         self.scope_range = OrderedDict()
@@ -130,9 +132,10 @@ class ParamStore:
                     shp = shape if len(shape) == 4 else (1, 1) + tuple(shape)
                     taps, A, Bd = shp[0] * shp[1], shp[2], shp[3]
                     Ap = pad8(A)
-                    e.update(packed=poff, taps=taps, A=A, B=Bd, Apad=Ap, k=shp[0])
-                    rows.append([off, poff, taps, A, Bd, Ap])
-                    poff += (taps * Ap * Bd + 7) // 8 * 8          # keep every packed tensor 16-B aligned
+                    Bp = pad8(Bd) if name in bpad else Bd
+                    e.update(packed=poff, taps=taps, A=A, B=Bd, Apad=Ap, Bpad=Bp, k=shp[0])
+                    rows.append([off, poff, taps, A, Bd, Ap, Bp])
+                    poff += (taps * Ap * Bp + 7) // 8 * 8          # keep every packed tensor 16-B aligned
                 self.entries[name] = e
                 off += n
             off = (off + 3) // 4 * 4                               # 16-B aligned scope boundaries
@@ -158,9 +161,9 @@ class ParamStore:
         return self.view(name, self.grad)
 
     def packed(self, name, transposed):
-        """Compute copy of a weight: [tap][B][Apad] if transposed else [tap][Apad][B] (flat view)."""
+        """Compute copy of a weight: [tap][B][Apad] if transposed else [tap][Apad][Bpad] (flat view)."""
         e = self.entries[name]
-        n = e["taps"] * e["Apad"] * e["B"]
+        n = e["taps"] * e["Apad"] * (e["B"] if transposed else e["Bpad"])
         return (self.wT if transposed else self.wN)[e["packed"]:e["packed"] + n]
 
     def scope_slice(self, scope, buf):

@@ -375,7 +375,7 @@ def test_act_backward_and_reductions():
 
 def test_pack_weights():
     flat = rnd(9 * 8 * 16 + 16 * 4, seed=1).to(DEV)
-    tab = torch.tensor([[0, 0, 9, 8, 16, 8], [9 * 8 * 16, 9 * 8 * 16, 1, 16, 4, 16]], dtype=torch.int64,
+    tab = torch.tensor([[0, 0, 9, 8, 16, 8, 16], [9 * 8 * 16, 9 * 8 * 16, 1, 16, 4, 16, 4]], dtype=torch.int64,
                        device=DEV)
     for dtype in (torch.float32, torch.bfloat16):
         dst = torch.empty(flat.numel(), device=DEV, dtype=dtype)
