@@ -17,6 +17,7 @@
 // fp32 uses v_mfma_f32_16x16x4_f32 (exact, K-permuted as in conv_igemm.hip), bf16 v_mfma_f32_16x16x32_bf16.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 struct Conv3P {
   const void* in;
@@ -259,6 +260,19 @@ template <typename TIn, typename TOut>
 static void launch3_typed(const Conv3P& p, hipStream_t st) {
   const int64_t pix = (int64_t)p.N * p.H * p.W;
   const int nt64 = (p.Cout + 63) / 64;
+  static const char* force = getenv("TG_C3_FORCE");       // experiment switch: "TH,BN" e.g. "4,32"
+  if (force && p.Cout > 32) {
+    int th = 0, bn = 0;
+    if (sscanf(force, "%d,%d", &th, &bn) == 2) {
+      if (th == 2 && bn == 64) return launch3<TIn, TOut, 2, 64>(p, st);
+      if (th == 4 && bn == 64) return launch3<TIn, TOut, 4, 64>(p, st);
+      if (th == 8 && bn == 64) return launch3<TIn, TOut, 8, 64>(p, st);
+      if (th == 16 && bn == 64) return launch3<TIn, TOut, 16, 64>(p, st);
+      if (th == 4 && bn == 32) return launch3<TIn, TOut, 4, 32>(p, st);
+      if (th == 8 && bn == 32) return launch3<TIn, TOut, 8, 32>(p, st);
+      if (th == 16 && bn == 32) return launch3<TIn, TOut, 16, 32>(p, st);
+    }
+  }
   if (p.Cout <= 16) {
     if (pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 16>(p, st);
     else if (pix >= 8 * 16 * 256) launch3<TIn, TOut, 8, 16>(p, st);
