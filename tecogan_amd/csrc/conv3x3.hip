@@ -281,12 +281,19 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
     if (pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 32>(p, st);
     else if (pix >= 8 * 16 * 256) launch3<TIn, TOut, 8, 32>(p, st);
     else launch3<TIn, TOut, 4, 32>(p, st);
-  } else {
-    // pick the largest tile that still yields >= ~256 workgroups of work
+  } else if (p.Cin * (int)sizeof(TIn) > 128) {
+    // multi-chunk (Cin > one 128-B chunk): the weight panel is re-staged per (tile, chunk) -> largest pixel tile
     if (pix * nt64 >= (int64_t)16 * 16 * 256) launch3<TIn, TOut, 16, 64>(p, st);
     else if (pix * nt64 >= (int64_t)8 * 16 * 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (pix * nt64 >= (int64_t)4 * 16 * 256) launch3<TIn, TOut, 4, 64>(p, st);
     else launch3<TIn, TOut, 2, 64>(p, st);
+  } else {
+    // single chunk, weights stationary: 32-channel tiles double the workgroup count and halve the weight panel
+    // each one stages -- measured faster below ~0.25 M pixels (tools/mb_conv.py, profiles/r01c)
+    if (pix >= 262144) launch3<TIn, TOut, 16, 64>(p, st);
+    else if (pix >= 32768) launch3<TIn, TOut, 16, 32>(p, st);
+    else if (pix >= 8192) launch3<TIn, TOut, 8, 32>(p, st);
+    else launch3<TIn, TOut, 4, 32>(p, st);
   }
 }
 

@@ -71,6 +71,7 @@ class TrainEngine:
         self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
         self.host_step = 0
         self.gen = None
+        self.side_stream = torch.cuda.Stream(device=self.dev)
 
     # ------------------------------------------------------------------------------------------
     def set_batch(self, r_inputs, r_targets):
@@ -167,12 +168,24 @@ class TrainEngine:
             self._gan(gen, hr_seq, lr_seq, flow_t, d_gen)
         # ---- backward through the recurrence ------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
+        # The BPTT chain is strictly sequential and each of its launches fills at most half the chip; the
+        # weight gradients (shared weights: one launch per layer over many frames) and the FNet backward are
+        # independent of it, so they run on a side stream (parallel branches of the captured hipGraph).
+        side, main = self.side_stream, torch.cuda.current_stream()
+        half = T // 2
         for t in range(T - 1, -1, -1):
             dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
-        self.G.wgrad_sequence()             # shared weights: one wgrad per layer over all T*B frames
+            if t == half and half > 0:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.G.wgrad_sequence(half, T)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.G.wgrad_sequence(0, half if half > 0 else T)
         self.Fn.backward(fsaved, d_flow)
+        main.wait_stream(side)
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""

@@ -204,12 +204,16 @@ class Generator:
             return None
         return conv_bwd_data(ps, p + "input_stage/conv/Conv/weights", g, (h, w), 1, out=q["dx_in"])
 
-    def wgrad_sequence(self):
-        """All weight / bias gradients of the step: one launch per layer over the T*B frames."""
+    def wgrad_sequence(self, t0=0, t1=None):
+        """Weight / bias gradients of frames [t0, t1): one launch per layer over the (t1-t0)*B frames."""
         ps, p, q, n = self.ps, self.P, self.seq, self.nres
+        t1 = q["T"] if t1 is None else t1
+        if t1 <= t0:
+            return
 
         def flat(x):
-            return x.view(-1, *x.shape[2:])
+            x = x[t0:t1]
+            return x.reshape(-1, *x.shape[2:])
 
         conv_wgrad(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", flat(q["x_in"]),
                    flat(q["g_in"]))
