@@ -8,6 +8,7 @@ and each flow slab is a contiguous `[B, ...]` block.  Semantics that differ from
 purpose: all gradients are taken from the pre-update weights, then D (gate permitting), G and FNet
 are applied (the TF1 graph has an ordering race there).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -171,7 +172,8 @@ class TrainEngine:
         # The BPTT chain is strictly sequential and each of its launches fills at most half the chip; the
         # weight gradients (shared weights: one launch per layer over many frames) and the FNet backward are
         # independent of it, so they run on a side stream (parallel branches of the captured hipGraph).
-        side, main = self.side_stream, torch.cuda.current_stream()
+        main = torch.cuda.current_stream()
+        side = main if os.environ.get("TG_NO_OVERLAP") else self.side_stream      # A/B switch
         half = T // 2
         for t in range(T - 1, -1, -1):
             dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
