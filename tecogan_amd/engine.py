@@ -173,21 +173,26 @@ class TrainEngine:
         # weight gradients (shared weights: one launch per layer over many frames) and the FNet backward are
         # independent of it, so they run on a side stream (parallel branches of the captured hipGraph).
         main = torch.cuda.current_stream()
-        side = main if os.environ.get("TG_NO_OVERLAP") else self.side_stream      # A/B switch
+        # measured on MI355X (profiles/r01c): the parallel branches slow the latency-critical chain more than they hide
+        # (6.16 vs 6.00 ms FRVSR, 26.8 vs 25.8 ms TecoGAN), so the overlap is opt-in: TG_OVERLAP=1
+        side = self.side_stream if os.environ.get("TG_OVERLAP") else main
         half = T // 2
         for t in range(T - 1, -1, -1):
             dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
             if t == half and half > 0:
-                side.wait_stream(main)
+                if side is not main:
+                    side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self.G.wgrad_sequence(half, T)
-        side.wait_stream(main)
+        if side is not main:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
             self.G.wgrad_sequence(0, half if half > 0 else T)
         self.Fn.backward(fsaved, d_flow)
-        main.wait_stream(side)
+        if side is not main:
+            main.wait_stream(side)
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""
