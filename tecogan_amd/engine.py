@@ -181,15 +181,14 @@ class TrainEngine:
             dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
-            if t == half and half > 0:
-                if side is not main:
-                    side.wait_stream(main)
+            if t == half and half > 0 and side is not main:
+                side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self.G.wgrad_sequence(half, T)
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            self.G.wgrad_sequence(0, half if half > 0 else T)
+            self.G.wgrad_sequence(0, half if (half > 0 and side is not main) else T)
         self.Fn.backward(fsaved, d_flow)
         if side is not main:
             main.wait_stream(side)
