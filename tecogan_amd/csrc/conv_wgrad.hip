@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  for (int mb = mbeg; mb < mend; mb += 64) {
-    uint4 v[2][2];
+  uint4 v[2][2];
+  auto load_block = [&](int mb) {      // unconditional loads (clamped address) + select; issued one block ahead
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -302,11 +302,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
           ok = ok && c < p.ldy;
           off = ok ? (int64_t)m * p.ldy + c : 0;
         }
-        uint4 t4 = *reinterpret_cast<const uint4*>((stage_x ? p.x : p.y) + off);   // unconditional + select
+        uint4 t4 = *reinterpret_cast<const uint4*>((stage_x ? p.x : p.y) + off);
         if (!ok) t4 = make_uint4(0, 0, 0, 0);
         v[h][q] = t4;
       }
     }
+  };
+  load_block(mbeg);
+  for (int mb = mbeg; mb < mend; mb += 64) {
     unsigned char* panel = stage_x ? Xt : Yt;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -323,6 +326,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
       }
     }
     __syncthreads();
+    if (mb + 64 < mend) load_block(mb + 64);          // in flight during the MFMAs below
     if (do_bias && tid < 64) {
       const uint32_t* row = reinterpret_cast<const uint32_t*>(Yt + tid * ROWB);
 #pragma unroll 8
