@@ -385,7 +385,7 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
-  static const int target = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 512;
+  static const int target = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 1024;   // measured sweet spot (128..4096 swept, profiles/r01c)
   int ksplit = (target + base_blocks - 1) / base_blocks;           // workgroup target: trades parallelism vs atomics
   const int max_split = (p.M + 127) / 128;
   if (ksplit > max_split) ksplit = max_split;
