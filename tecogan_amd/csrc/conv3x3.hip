@@ -269,6 +269,9 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
       if (th == 8 && bn == 64) return launch3<TIn, TOut, 8, 64>(p, st);
       if (th == 16 && bn == 64) return launch3<TIn, TOut, 16, 64>(p, st);
       if (th == 4 && bn == 32) return launch3<TIn, TOut, 4, 32>(p, st);
+      if (th == 2 && bn == 32) return launch3<TIn, TOut, 2, 32>(p, st);
+      if (th == 4 && bn == 16) return launch3<TIn, TOut, 4, 16>(p, st);
+      if (th == 8 && bn == 16) return launch3<TIn, TOut, 8, 16>(p, st);
       if (th == 8 && bn == 32) return launch3<TIn, TOut, 8, 32>(p, st);
       if (th == 16 && bn == 32) return launch3<TIn, TOut, 16, 32>(p, st);
     }
