@@ -291,12 +291,18 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
     else if (pix * nt64 >= (int64_t)4 * 16 * 256) launch3<TIn, TOut, 4, 64>(p, st);
     else launch3<TIn, TOut, 2, 64>(p, st);
   } else {
-    // single chunk, weights stationary: 32-channel tiles double the workgroup count and halve the weight panel
-    // each one stages -- measured faster below ~0.25 M pixels (tools/mb_conv.py, profiles/r01c)
-    if (pix >= 262144) launch3<TIn, TOut, 16, 64>(p, st);
-    else if (pix >= 32768) launch3<TIn, TOut, 16, 32>(p, st);
-    else if (pix >= 8192) launch3<TIn, TOut, 8, 32>(p, st);
-    else launch3<TIn, TOut, 4, 32>(p, st);
+    // single chunk, weights stationary: the largest tile that still gives every CU a workgroup.  Narrow
+    // channel tiles (BN 32/16) shrink the weight panel each workgroup stages and were measured faster in situ
+    // for the small recurrent-chain shapes (FRVSR step 6.10 -> 5.61 ms with <4,16>; profiles/r01c).
+    auto blocks = [&](int th, int bn) {
+      return (int64_t)p.N * ((p.H + th - 1) / th) * ((p.W + 15) / 16) * ((p.Cout + bn - 1) / bn);
+    };
+    if (blocks(16, 64) >= 256) launch3<TIn, TOut, 16, 64>(p, st);
+    else if (blocks(16, 32) >= 256) launch3<TIn, TOut, 16, 32>(p, st);
+    else if (blocks(8, 32) >= 256) launch3<TIn, TOut, 8, 32>(p, st);
+    else if (blocks(8, 16) >= 256) launch3<TIn, TOut, 8, 16>(p, st);
+    else if (blocks(4, 32) >= 256) launch3<TIn, TOut, 4, 32>(p, st);
+    else launch3<TIn, TOut, 4, 16>(p, st);
   }
 }
 
