@@ -108,13 +108,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    ndev = torch.cuda.device_count()
+    if world > 1 and local >= ndev and os.environ.get("TG_DIST_BACKEND", "nccl") != "nccl":
+        local = local % ndev                                     # plumbing test: several ranks share one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("TG_DIST_BACKEND", "nccl")     # "nccl" == RCCL; gloo only for 1-GPU plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
     from tecogan_amd.engine import TrainEngine
     F = make_flags(a.config)
