@@ -35,7 +35,9 @@ struct Conv3P {
   int tiles_y, tiles_x, ntiles;
 };
 
-template <typename TIn, typename TOut, int TH, int BN>
+// ABL: profiling-only ablation bits (1 = skip epilogue stores, 2 = skip the MFMA block, 4 = skip reloads of later
+// stages, 8 = skip LDS staging writes of later stages); the product always launches ABL = 0.
+template <typename TIn, typename TOut, int TH, int BN, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   constexpr int EPV = 16 / (int)sizeof(TIn);
   constexpr int BK = 8 * EPV;                       // channels per 128-byte chunk
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   while (tile < p.ntiles) {
     const bool with_b = first || !b_stationary;
     __syncthreads();                       // previous stage's fragment reads are done: LDS may be rewritten
-    store_stage(with_b);
+    if (!(ABL & 8) || first) store_stage(with_b);
     __syncthreads();
     // prefetch the next stage into registers (overlaps the MFMA block below)
     int ntile = tile, nchunk_i = chunk + 1;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
       nchunk_i = 0;
       ntile = tile + gridDim.x;
     }
-    if (ntile < p.ntiles) load_stage(ntile, nchunk_i, !b_stationary);
+    if (ntile < p.ntiles && !(ABL & 4)) load_stage(ntile, nchunk_i, !b_stationary);
 
     if (chunk == 0) {
 #pragma unroll
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (!(ABL & 2))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap % 3;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
               else v = fmaxf(v, v * p.nslope);
               if (has_res) v += Elem<TOut>::ld(gres + idx);
               if (has_aux) v *= Elem<TOut>::ld(gaux + idx) > 0.f ? 1.f : p.mslope;
-              Elem<TOut>::st(gout + idx, v);
+              if (ABL & 1) { asm volatile("" ::"v"(v)); } else Elem<TOut>::st(gout + idx, v);
             }
           }
         }
@@ -237,11 +240,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   }
 }
 
-template <typename TIn, typename TOut, int TH, int BN>
+template <typename TIn, typename TOut, int TH, int BN, int ABL = 0>
 static void launch3(Conv3P p, hipStream_t st) {
   constexpr int LDS = ((TH + 2) * 18 + 9 * BN) * 144;
   static bool attr_set = false;
-  auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN>;
+  auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN, ABL>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
@@ -267,7 +270,22 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
       if (th == 2 && bn == 64) return launch3<TIn, TOut, 2, 64>(p, st);
       if (th == 4 && bn == 64) return launch3<TIn, TOut, 4, 64>(p, st);
       if (th == 8 && bn == 64) return launch3<TIn, TOut, 8, 64>(p, st);
-      if (th == 16 && bn == 64) return launch3<TIn, TOut, 16, 64>(p, st);
+      if (th == 16 && bn == 64) {
+        static const int abl = getenv("TG_C3_ABL") ? atoi(getenv("TG_C3_ABL")) : 0;
+        if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
+          switch (abl) {
+            case 1: return launch3<TIn, TOut, 16, 64, 1>(p, st);
+            case 2: return launch3<TIn, TOut, 16, 64, 2>(p, st);
+            case 3: return launch3<TIn, TOut, 16, 64, 3>(p, st);
+            case 4: return launch3<TIn, TOut, 16, 64, 4>(p, st);
+            case 12: return launch3<TIn, TOut, 16, 64, 12>(p, st);
+            case 14: return launch3<TIn, TOut, 16, 64, 14>(p, st);
+            case 15: return launch3<TIn, TOut, 16, 64, 15>(p, st);
+            default: break;
+          }
+        }
+        return launch3<TIn, TOut, 16, 64>(p, st);
+      }
       if (th == 4 && bn == 32) return launch3<TIn, TOut, 4, 32>(p, st);
       if (th == 2 && bn == 32) return launch3<TIn, TOut, 2, 32>(p, st);
       if (th == 4 && bn == 16) return launch3<TIn, TOut, 4, 16>(p, st);
