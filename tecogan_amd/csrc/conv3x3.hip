@@ -199,40 +199,91 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
     }
 
     if (chunk == nchunk - 1) {             // ---- fused epilogue for this tile ----
-      // 32-bit offsets hoisted per pixel.  none/ReLU/LeakyReLU are the branch-free max(v, v*slope); the rare
-      // tanh/sigmoid layers and the edge tiles (partial rows/columns/channels) take separate, uniformly
-      // selected copies so the common path carries no per-element branches or exec-mask updates.
       const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
       const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-      const int ybase = ty * TH + wm * TM, xbase = tx * 16 + fg * 4;
-      const int pix0 = ((n * p.H + ybase) * p.W + xbase) * p.Cout + col0;
       const bool has_res = gres != nullptr, has_aux = gaux != nullptr;
-      const bool interior = (ty + 1) * TH <= p.H && (tx + 1) * 16 <= p.W && n0 + BN <= p.Cout;
-      auto epilogue = [&](auto check_tag, auto slow_tag) {
-        constexpr bool CHECK = decltype(check_tag)::value, SLOW = decltype(slow_tag)::value;
+      constexpr bool LDS_EPI = sizeof(TOut) == 2;      // bf16 outputs: stage through LDS, 16-byte global rows
+      if (LDS_EPI && (p.Cout & 7) == 0) {
+        // Phase 1: bias + activation in fp32 registers, bf16 tile into the (now idle) halo region of LDS.
+        // Phase 2: every thread moves 16-byte rows: residual / mask operands arrive as vector loads and the
+        // result leaves as one dwordx4 store per 8 channels (the per-lane 2-byte stores of the direct epilogue
+        // cost 10 of 27 us at [1,270,480,64->64]: store-issue bound, tools ablation TG_C3_ABL).
+        __syncthreads();                   // all waves are done reading the halo tile
+        u16* stage = reinterpret_cast<u16*>(As);
+        constexpr int SP = 72;             // u16 per staged pixel row: 64 channels + 8 pad (144 B)
+        const bool slow = p.act >= TG_ACT_TANH;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int off = pix0 + (i * p.W + r) * p.Cout;
-            const bool pok = !CHECK || (ybase + i < p.H && xbase + r < p.W);
+            const int pl = ((wm * TM + i) * 16 + fg * 4 + r) * SP + wn * TN * 16 + frow;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              if (CHECK && !(pok && col0 + j * 16 < p.Cout)) continue;
-              const int idx = off + j * 16;
               float v = acc[i][j][r] + bv[j];
-              if constexpr (SLOW) v = act_fwd(v, p.act, p.act_alpha);
-              else v = fmaxf(v, v * p.nslope);
-              if (has_res) v += Elem<TOut>::ld(gres + idx);
-              if (has_aux) v *= Elem<TOut>::ld(gaux + idx) > 0.f ? 1.f : p.mslope;
-              if (ABL & 1) { asm volatile("" ::"v"(v)); } else Elem<TOut>::st(gout + idx, v);
+              v = slow ? act_fwd(v, p.act, p.act_alpha) : fmaxf(v, v * p.nslope);
+              stage[pl + j * 16] = f2bf(v);
             }
           }
+        __syncthreads();
+        constexpr int VPP = BN / 8;        // 16-byte vectors per pixel
+        constexpr int NV = TH * 16 * VPP;
+        const int y0 = ty * TH, x0 = tx * 16;
+        for (int it = tid; it < NV; it += 256) {
+          const int pl = it / VPP, cv = it % VPP;
+          const int y = y0 + pl / 16, x = x0 + pl % 16, c = n0 + cv * 8;
+          if (ABL & 1) continue;
+          if (y >= p.H || x >= p.W || c >= p.Cout) continue;
+          uint4 o = *reinterpret_cast<const uint4*>(stage + pl * SP + cv * 8);
+          const int idx = ((n * p.H + y) * p.W + x) * p.Cout + c;
+          if (has_res || has_aux) {
+            uint4 rr = make_uint4(0, 0, 0, 0), aa = rr;
+            if (has_res) rr = *reinterpret_cast<const uint4*>(gres + idx);
+            if (has_aux) aa = *reinterpret_cast<const uint4*>(gaux + idx);
+            u16* ov = reinterpret_cast<u16*>(&o);
+            const u16* rv = reinterpret_cast<const u16*>(&rr);
+            const u16* av = reinterpret_cast<const u16*>(&aa);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = bf2f(ov[e]);
+              if (has_res) v += bf2f(rv[e]);
+              if (has_aux) v *= bf2f(av[e]) > 0.f ? 1.f : p.mslope;
+              ov[e] = f2bf(v);
+            }
+          }
+          *reinterpret_cast<uint4*>(gout + idx) = o;
         }
-      };
-      if (p.act >= TG_ACT_TANH) epilogue(std::true_type{}, std::true_type{});
-      else if (interior) epilogue(std::false_type{}, std::false_type{});
-      else epilogue(std::true_type{}, std::false_type{});
+      } else {
+        // direct epilogue (fp32 outputs, channel tails): 32-bit offsets hoisted per pixel; none/ReLU/LeakyReLU are
+        // the branch-free max(v, v*slope); tanh/sigmoid and edge tiles take separate uniformly selected copies.
+        const int ybase = ty * TH + wm * TM, xbase = tx * 16 + fg * 4;
+        const int pix0 = ((n * p.H + ybase) * p.W + xbase) * p.Cout + col0;
+        const bool interior = (ty + 1) * TH <= p.H && (tx + 1) * 16 <= p.W && n0 + BN <= p.Cout;
+        auto epilogue = [&](auto check_tag, auto slow_tag) {
+          constexpr bool CHECK = decltype(check_tag)::value, SLOW = decltype(slow_tag)::value;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int off = pix0 + (i * p.W + r) * p.Cout;
+              const bool pok = !CHECK || (ybase + i < p.H && xbase + r < p.W);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                if (CHECK && !(pok && col0 + j * 16 < p.Cout)) continue;
+                const int idx = off + j * 16;
+                float v = acc[i][j][r] + bv[j];
+                if constexpr (SLOW) v = act_fwd(v, p.act, p.act_alpha);
+                else v = fmaxf(v, v * p.nslope);
+                if (has_res) v += Elem<TOut>::ld(gres + idx);
+                if (has_aux) v *= Elem<TOut>::ld(gaux + idx) > 0.f ? 1.f : p.mslope;
+                if (ABL & 1) { asm volatile("" ::"v"(v)); } else Elem<TOut>::st(gout + idx, v);
+              }
+            }
+          }
+        };
+        if (p.act >= TG_ACT_TANH) epilogue(std::true_type{}, std::true_type{});
+        else if (interior) epilogue(std::false_type{}, std::false_type{});
+        else epilogue(std::true_type{}, std::false_type{});
+      }
     }
     first = false;
     tile = ntile;
