@@ -33,6 +33,7 @@ struct Conv3P {
   float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope (ReLU 0, LeakyReLU alpha, none 1)
   int tiles_y, tiles_x, ntiles;
+  int direct_epi;     // A/B switch (TG_C3_DIRECT_EPI): per-lane stores instead of the LDS-staged rows
 };
 
 // ABL: profiling-only ablation bits (1 = skip epilogue stores, 2 = skip the MFMA block, 4 = skip reloads of later
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
       const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
       const bool has_res = gres != nullptr, has_aux = gaux != nullptr;
       constexpr bool LDS_EPI = sizeof(TOut) == 2;      // bf16 outputs: stage through LDS, 16-byte global rows
-      if (LDS_EPI && (p.Cout & 7) == 0) {
+      if (LDS_EPI && (p.Cout & 7) == 0 && !p.direct_epi) {
         // Phase 1: bias + activation in fp32 registers, bf16 tile into the (now idle) halo region of LDS.
         // Phase 2: every thread moves 16-byte rows: residual / mask operands arrive as vector loads and the
         // result leaves as one dwordx4 store per 8 channels (the per-lane 2-byte stores of the direct epilogue
@@ -389,6 +390,8 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   p.flip = d->mode == 1;
   if (aux && d->mask_act != TG_ACT_RELU && d->mask_act != TG_ACT_LRELU) return 0;   // generic engine handles others
   p.act = d->act; p.act_alpha = d->act_alpha;
+  static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
+  p.direct_epi = direct;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   if (d->in_dtype == TG_F32) launch3_typed<float, float>(p, st);
