@@ -40,6 +40,7 @@ struct ConvP {
   float mask_alpha;
   int vec;  // Cin % (16B worth) == 0 -> 16-byte loads
   float nslope, mslope;  // act(v) = max(v, v*nslope); mask = aux > 0 ? 1 : mslope
+  int direct_epi;        // A/B switch TG_C3_DIRECT_EPI
 };
 
 template <typename TIn, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN>
@@ -232,6 +233,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bv[j] = (p.bias && col0 + j * 16 < p.Cout) ? p.bias[col0 + j * 16] : 0.f;
+  const bool slow = p.act >= TG_ACT_TANH || (has_aux && p.mask_act != TG_ACT_RELU && p.mask_act != TG_ACT_LRELU);
+  if constexpr (sizeof(TOut) == 2) {
+    if ((p.Cout & 7) == 0 && !slow && !p.direct_epi) {
+      // bf16 outputs: stage the activated tile in LDS (the A panels are idle after the K loop) and move 16-byte
+      // rows; residual / mask operands arrive as vector loads (see conv3x3.hip for the measured effect).
+      u16* stage = reinterpret_cast<u16*>(As);
+      constexpr int SP = 72;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pl = ((wm * TM + i) * 16 + fg * 4 + r) * SP + wn * TN * 16 + frow;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float v = acc[i][j][r] + bv[j];
+            stage[pl + j * 16] = f2bf(fmaxf(v, v * p.nslope));
+          }
+        }
+      __syncthreads();
+      constexpr int VPP = BN / 8, NV = BM * VPP;
+      for (int it = tid; it < NV; it += 256) {
+        const int row = it / VPP, cv = it % VPP;
+        const int pix = out_pix[row], c = n0 + cv * 8;
+        if (pix < 0 || c >= p.Cout) continue;
+        uint4 o = *reinterpret_cast<const uint4*>(stage + row * SP + cv * 8);
+        const int idx = pix * p.Cout + c;
+        if (has_res || has_aux) {
+          uint4 rr = make_uint4(0, 0, 0, 0), aa = rr;
+          if (has_res) rr = *reinterpret_cast<const uint4*>(gres + idx);
+          if (has_aux) aa = *reinterpret_cast<const uint4*>(gaux + idx);
+          u16* ov = reinterpret_cast<u16*>(&o);
+          const u16* rv = reinterpret_cast<const u16*>(&rr);
+          const u16* av = reinterpret_cast<const u16*>(&aa);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = bf2f(ov[e]);
+            if (has_res) v += bf2f(rv[e]);
+            if (has_aux) v *= bf2f(av[e]) > 0.f ? 1.f : p.mslope;
+            ov[e] = f2bf(v);
+          }
+        }
+        *reinterpret_cast<uint4*>(gout + idx) = o;
+      }
+      return;
+    }
+  }
   auto epilogue = [&](auto check_tag, auto slow_tag) {
     constexpr bool CHECK = decltype(check_tag)::value, SLOW = decltype(slow_tag)::value;
 #pragma unroll
@@ -258,7 +305,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       }
     }
   };
-  const bool slow = p.act >= TG_ACT_TANH || (has_aux && p.mask_act != TG_ACT_RELU && p.mask_act != TG_ACT_LRELU);
   if (slow) epilogue(std::true_type{}, std::true_type{});
   else if (m0 + BM <= Mq && n0 + BN <= p.Cout) epilogue(std::false_type{}, std::false_type{});
   else epilogue(std::true_type{}, std::false_type{});
@@ -311,6 +357,8 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l; p.mode = d->mode;
   p.act = d->act; p.act_alpha = d->act_alpha; p.mask_act = d->mask_act; p.mask_alpha = d->mask_alpha;
+  static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
+  p.direct_epi = direct;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   const int epv = d->in_dtype == TG_F32 ? 4 : 8;
