@@ -74,7 +74,7 @@ def dominant_kernel_roofline(dtype, device):
     us = e0.elapsed_time(e1) * 1e3 / iters
     flops = 2.0 * N * H * W * Cc * 9 * Cc          # algorithmic: 2 * M * N * K = 302 MFLOP per launch
     ach = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel 3x3 64->64 @[4,32,32,64] %s" % dtype,
+    return {"bound": "mfma", "kernel": "conv3x3_tile_kernel 3x3 64->64 @[4,32,32,64] %s (generator res-block conv)" % dtype,
             "achieved": round(ach, 3), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK[dtype], 5),
             "us_per_launch": round(us, 3), "flop_per_launch": flops, "traffic": None}
 
