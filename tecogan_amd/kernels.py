@@ -239,3 +239,12 @@ def pack_d_input_backward(d_out, frames, flow_pre, flow_nxt, idx_pre, idx_nxt, d
 def affine(x, out, scale, shift):
     check(lib().tg_affine(_p(x), _p(out), x.numel(), scale, shift, _stream()), "tg_affine")
     return out
+
+
+def resblock_fused(x, w1, b1, m1, mid, w2, b2, m2, out, flip, relu1):
+    N, H, W, Cn = x.shape
+    if Cn != 64 or x.dtype != torch.bfloat16:
+        raise L.TecoHipError("resblock_fused: bf16, 64 channels only")
+    check(lib().tg_resblock_fused(_p(x), _p(w1), _p(b1), _p(m1), _p(mid), _p(w2), _p(b2), _p(m2), _p(out), N, H, W,
+                                  int(flip), int(relu1), _stream()), "tg_resblock_fused")
+    return out

@@ -10,6 +10,8 @@ Fusion plan (what the reference runs as separate TF ops, lib/frvsr.py / lib/Teco
 Activations are NHWC in `ps.act_dtype` (fp32 parity mode / bf16 throughput mode); network outputs
 that feed losses or the recurrence (HR frame, flow, D probability) are fp32.
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -120,6 +122,9 @@ class Generator:
     def __init__(self, ps, num_resblock):
         self.ps, self.nres = ps, num_resblock
         self.seq = None
+        # fused residual-block kernel: bf16 only (fp32 parity mode keeps the two-launch path); TG_NO_FUSED_RESBLOCK=1
+        # is the A/B switch
+        self.fused = ps.act_dtype == torch.bfloat16 and not os.environ.get("TG_NO_FUSED_RESBLOCK")
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None):
@@ -171,6 +176,11 @@ class Generator:
                      out=q["a"][0][t])
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
+            if self.fused:          # one launch per residual block (csrc/resblock.hip)
+                a = K.resblock_fused(a, ps.packed(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
+                                     None, q["r"][i][t], ps.packed(s + "conv_2/Conv/weights", True),
+                                     ps.view(s + "conv_2/Conv/biases"), None, q["a"][i][t], flip=False, relu1=True)
+                continue
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t])
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
                          out=q["a"][i][t])
@@ -194,6 +204,12 @@ class Generator:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
         for i in range(n, 0, -1):
             sc = p + "resblock_%d/" % i
+            if self.fused:          # dr = bwd(conv_2)(g) * relu'(r);  d a_{i-1} = bwd(conv_1)(dr) + g  [* relu'(a_0)]
+                g = K.resblock_fused(g, ps.packed(sc + "conv_2/Conv/weights", False), None, q["r"][i][t],
+                                     q["g_c1"][i][t], ps.packed(sc + "conv_1/Conv/weights", False), None,
+                                     q["a"][0][t] if i == 1 else None,
+                                     q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], flip=True, relu1=False)
+                continue
             dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
                                out=q["g_c1"][i][t])
             # d a_{i-1} = bwd(conv_1)(dr) + skip gradient; block 1's input is itself a ReLU output (masked here)

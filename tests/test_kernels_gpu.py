@@ -421,3 +421,38 @@ def test_wgrad_bf16_padded_channel_stride():
     dw = torch.zeros(3, 3, 51, 64, device=DEV)
     K.conv_wgrad(d, x56.to(DEV), gy.to(DEV), dw, None, ldx=56, ldy=64)
     close(dw, w.grad, 3e-4, "padded-stride bf16 wgrad")
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 32), (1, 9, 21), (2, 270, 40)])
+def test_resblock_fused_forward_and_backward(shape):
+    """Fused residual block (csrc/resblock.hip) vs the oracle ops composed the same way, on bf16-rounded operands."""
+    N, H, W = shape
+    bf = lambda t: t.bfloat16().float()
+    x = bf(rnd(N, H, W, 64, seed=1))
+    w1, w2 = bf(rnd(3, 3, 64, 64, seed=2, scale=0.1)), bf(rnd(3, 3, 64, 64, seed=3, scale=0.1))
+    b1, b2 = rnd(64, seed=4, scale=0.1), rnd(64, seed=5, scale=0.1)
+    # ---- forward: r = relu(conv1(x)); out = conv2(r) + x
+    r_ref = bf(torch.relu(O.conv2(x, w1, b1, 1)))
+    out_ref = O.conv2(r_ref, w2, b2, 1) + x
+    wt = lambda w: w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16)     # [tap][out][in]
+    wn = lambda w: w.reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16)                          # [tap][in][out]
+    xd = x.to(DEV, torch.bfloat16)
+    mid, out = torch.empty_like(xd), torch.empty_like(xd)
+    K.resblock_fused(xd, wt(w1), b1.to(DEV), None, mid, wt(w2), b2.to(DEV), None, out, flip=False, relu1=True)
+    close(mid, r_ref, 1e-2, "fused fwd mid")
+    close(out, out_ref, 1e-2, "fused fwd out")
+    # ---- backward: dr = bwd_conv2(g) * relu'(r); dx = bwd_conv1(dr) + g, optionally masked by relu'(a0)
+    g = bf(rnd(N, H, W, 64, seed=6))
+    a0 = rnd(N, H, W, 64, seed=7)
+    rr = r_ref.clone().requires_grad_()
+    O.conv2(rr, w2, None, 1).backward(g)
+    dr_ref = bf(rr.grad * (r_ref > 0).float())
+    xx = torch.zeros(N, H, W, 64, requires_grad=True)
+    O.conv2(xx, w1, None, 1).backward(dr_ref)
+    dx_ref = (xx.grad + g) * (a0 > 0).float()
+    gd = g.to(DEV, torch.bfloat16)
+    dmid, dout = torch.empty_like(gd), torch.empty_like(gd)
+    K.resblock_fused(gd, wn(w2), None, r_ref.to(DEV, torch.bfloat16), dmid, wn(w1), None, a0.to(DEV, torch.bfloat16),
+                     dout, flip=True, relu1=False)
+    close(dmid, dr_ref, 1e-2, "fused bwd mid")
+    close(dout, dx_ref, 1e-2, "fused bwd out")
