@@ -31,6 +31,27 @@ struct ResP {
   int N, H, W, flip, relu1, tiles_y, tiles_x;
 };
 
+// Weight panel staging.  Written as macros over two separate register arrays on purpose: as a twice-called lambda or
+// helper function the 18-vector array was demoted to scratch memory (304 B/lane; every vector took a round trip
+// through it with vmcnt waits, 3x slower kernel).  With straight-line code SROA keeps them in VGPRs.
+#define RES_LOAD_W(ARR, WSRC)                                                                  \
+  _Pragma("unroll") for (int k = 0; k < 18; ++k) {                                             \
+    const int item = tid + k * 256;                                                            \
+    const int row = item >> 3, ch = item & 7;                                                  \
+    const int tap = row >> 6, co = row & 63;                                                   \
+    const int wtap = p.flip ? 8 - tap : tap;                                                   \
+    ARR[k] = *reinterpret_cast<const uint4*>((WSRC) + (wtap * 64 + co) * 64 + ch * 8);         \
+  }
+// keep the prefetched panel in VGPRs (the compiler otherwise parks it in scratch across stage 1)
+#define RES_PIN(ARR)                                                                           \
+  _Pragma("unroll") for (int k = 0; k < 18; ++k)                                               \
+      asm volatile("" : "+v"(ARR[k].x), "+v"(ARR[k].y), "+v"(ARR[k].z), "+v"(ARR[k].w));
+#define RES_STORE_W(ARR)                                                                       \
+  _Pragma("unroll") for (int k = 0; k < 18; ++k) {                                             \
+    const int item = tid + k * 256;                                                            \
+    *reinterpret_cast<uint4*>(Bs + (item >> 3) * ROWB + (item & 7) * 16) = ARR[k];             \
+  }
+
 template <int TH>
 __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   constexpr int XW = 20, XH = TH + 4, NX = XH * XW;
@@ -56,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   const int c = w * 16 + frow;                            // this lane's output channel (both stages)
 
   // ---- global -> registers: x halo tile and W1 (unconditional clamped loads + select) ----------------------
-  uint4 rx[X_LOADS], rb[B_LOADS];
+  uint4 rx[X_LOADS], rb1[18], rb2[18];
 #pragma unroll
   for (int k = 0; k < X_LOADS; ++k) {
     const int item = min(tid + k * 256, X_ITEMS - 1);
@@ -67,32 +88,15 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
     if (!ok) v = make_uint4(0, 0, 0, 0);
     rx[k] = v;
   }
-  auto load_w = [&](const u16* wsrc) {
-#pragma unroll
-    for (int k = 0; k < B_LOADS; ++k) {
-      const int item = tid + k * 256;
-      const int row = item >> 3, ch = item & 7;
-      const int tap = row >> 6, co = row & 63;
-      const int wtap = p.flip ? 8 - tap : tap;
-      rb[k] = *reinterpret_cast<const uint4*>(wsrc + (wtap * 64 + co) * 64 + ch * 8);
-    }
-  };
-  auto store_w = [&]() {
-#pragma unroll
-    for (int k = 0; k < B_LOADS; ++k) {
-      const int item = tid + k * 256;
-      *reinterpret_cast<uint4*>(Bs + (item >> 3) * ROWB + (item & 7) * 16) = rb[k];
-    }
-  };
-  load_w(p.w1);
+  RES_LOAD_W(rb1, p.w1)
 #pragma unroll
   for (int k = 0; k < X_LOADS; ++k) {
     const int item = tid + k * 256;
     if (item < X_ITEMS) *reinterpret_cast<uint4*>(Xs + (item >> 3) * ROWB + (item & 7) * 16) = rx[k];
   }
-  store_w();
+  RES_STORE_W(rb1)
   __syncthreads();
-  load_w(p.w2);                                            // in flight during stage 1
+  RES_LOAD_W(rb2, p.w2)                                    // in flight during stage 1
 
   // ---- stage 1: mid over the (TH+2) x 18 region; wave w owns channels [16w, 16w+16) ------------------------
   f32x4 acc1[M1];
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
       }
   }
   __syncthreads();                                          // mid tile complete; every wave is done with W1
-  store_w();                                                // W2 panel (registers -> LDS)
+  RES_PIN(rb2)
+  RES_STORE_W(rb2)                                          // W2 panel (registers -> LDS)
   for (int item = tid; item < O_ITEMS; item += 256) {       // interior of mid -> global, 16-byte rows
     const int pl = item >> 3, cv = item & 7;
     const int i = pl >> 4, xx = pl & 15;
