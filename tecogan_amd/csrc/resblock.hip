@@ -13,9 +13,11 @@
 // irrelevant here), kept in LDS, and consumed by the second conv without leaving the CU.  That removes one kernel
 // boundary and one global write->read round trip per block in both directions of the BPTT chain.
 //
-// LDS: x halo tile (TH+4) x 20 px, mid tile (TH+2) x 18 px, ONE 9x64x64 weight panel (W1, then W2 -- W2's global loads
-// are issued before the first MFMA block and land in registers meanwhile), and a TH x 16 staging tile for 16-byte
-// output rows.  Rows are pixels with a 144-byte pitch (conflict-light ds_read_b128 fragments).  64 channels only.
+// LDS: x halo tile (TH+4) x 20 px, mid tile (TH+2) x 18 px and a TH x 16 staging tile for 16-byte output rows (32 KB);
+// rows are pixels with a 144-byte pitch.  Weights never touch LDS: wave w owns output channels [16w, 16w+16) in both
+// stages, so its 18 B-fragments per conv (9 taps x 2 K-halves x 16 B per lane) are loaded straight from L2 into VGPRs --
+// W2's loads are issued up front and land during stage 1.  (Staging the two full 83 KB panels through LDS, as the
+// unfused kernel does, made the fused kernel slower than two narrow-tile launches.)  64 channels only.
 #include "common.h"
 
 struct ResP {
@@ -31,26 +33,19 @@ struct ResP {
   int N, H, W, flip, relu1, tiles_y, tiles_x;
 };
 
-// Weight panel staging.  Written as macros over two separate register arrays on purpose: as a twice-called lambda or
-// helper function the 18-vector array was demoted to scratch memory (304 B/lane; every vector took a round trip
-// through it with vmcnt waits, 3x slower kernel).  With straight-line code SROA keeps them in VGPRs.
-#define RES_LOAD_W(ARR, WSRC)                                                                  \
-  _Pragma("unroll") for (int k = 0; k < 18; ++k) {                                             \
-    const int item = tid + k * 256;                                                            \
-    const int row = item >> 3, ch = item & 7;                                                  \
-    const int tap = row >> 6, co = row & 63;                                                   \
-    const int wtap = p.flip ? 8 - tap : tap;                                                   \
-    ARR[k] = *reinterpret_cast<const uint4*>((WSRC) + (wtap * 64 + co) * 64 + ch * 8);         \
+// B fragments of one conv for this wave's 16 output channels: lane (frow, fg) holds, for every (tap, K-half), the 8
+// input channels [32*kk + 8*fg, +8) of output channel 16*w + frow -- 16 contiguous bytes of the [tap][out][in] panel.
+// Macros (straight-line code) + an empty-asm pin keep the 18 vectors in VGPRs; as arrays handed to a helper/lambda the
+// compiler parked them in scratch memory across stage 1 (304 B/lane, 3x slower kernel).
+#define RES_LOAD_B(ARR, WSRC)                                                                       \
+  _Pragma("unroll") for (int t_ = 0; t_ < 18; ++t_) {                                               \
+    const int tap_ = t_ >> 1, kk_ = t_ & 1;                                                         \
+    const int wtap_ = p.flip ? 8 - tap_ : tap_;                                                     \
+    ARR[t_] = *reinterpret_cast<const uint4*>((WSRC) + (wtap_ * 64 + c) * 64 + kk_ * 32 + fg * 8);  \
   }
-// keep the prefetched panel in VGPRs (the compiler otherwise parks it in scratch across stage 1)
-#define RES_PIN(ARR)                                                                           \
-  _Pragma("unroll") for (int k = 0; k < 18; ++k)                                               \
-      asm volatile("" : "+v"(ARR[k].x), "+v"(ARR[k].y), "+v"(ARR[k].z), "+v"(ARR[k].w));
-#define RES_STORE_W(ARR)                                                                       \
-  _Pragma("unroll") for (int k = 0; k < 18; ++k) {                                             \
-    const int item = tid + k * 256;                                                            \
-    *reinterpret_cast<uint4*>(Bs + (item >> 3) * ROWB + (item & 7) * 16) = ARR[k];             \
-  }
+#define RES_PIN(ARR)                                                                                \
+  _Pragma("unroll") for (int t_ = 0; t_ < 18; ++t_)                                                 \
+      asm volatile("" : "+v"(ARR[t_].x), "+v"(ARR[t_].y), "+v"(ARR[t_].z), "+v"(ARR[t_].w));
 
 template <int TH>
 __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
@@ -59,14 +54,12 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   constexpr int M1 = (NR + 15) / 16;
   constexpr int ROWB = 144, RU = 72;                      // row pitch in bytes / in u16
   constexpr int X_ITEMS = NX * 8, X_LOADS = (X_ITEMS + 255) / 256;
-  constexpr int B_LOADS = 9 * 64 * 8 / 256;               // 18
   constexpr int O_ITEMS = TH * 16 * 8;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Xs = smem;
   unsigned char* Rs = Xs + NX * ROWB;
-  unsigned char* Bs = Rs + NR * ROWB;
-  unsigned char* Os = Bs + 576 * ROWB;
+  unsigned char* Os = Rs + NR * ROWB;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int frow = lane & 15, fg = lane >> 4;
@@ -77,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   const int c = w * 16 + frow;                            // this lane's output channel (both stages)
 
   // ---- global -> registers: x halo tile and W1 (unconditional clamped loads + select) ----------------------
-  uint4 rx[X_LOADS], rb1[18], rb2[18];
+  uint4 rx[X_LOADS], bw1[18], bw2[18];
 #pragma unroll
   for (int k = 0; k < X_LOADS; ++k) {
     const int item = min(tid + k * 256, X_ITEMS - 1);
@@ -88,15 +81,14 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
     if (!ok) v = make_uint4(0, 0, 0, 0);
     rx[k] = v;
   }
-  RES_LOAD_W(rb1, p.w1)
+  RES_LOAD_B(bw1, p.w1)
+  RES_LOAD_B(bw2, p.w2)                                    // lands during stage 1
 #pragma unroll
   for (int k = 0; k < X_LOADS; ++k) {
     const int item = tid + k * 256;
     if (item < X_ITEMS) *reinterpret_cast<uint4*>(Xs + (item >> 3) * ROWB + (item & 7) * 16) = rx[k];
   }
-  RES_STORE_W(rb1)
   __syncthreads();
-  RES_LOAD_W(rb2, p.w2)                                    // in flight during stage 1
 
   // ---- stage 1: mid over the (TH+2) x 18 region; wave w owns channels [16w, 16w+16) ------------------------
   f32x4 acc1[M1];
@@ -107,13 +99,12 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
     const int q = min(mt * 16 + frow, NR - 1);
     base1[mt] = ((q / RW) * XW + q % RW) * ROWB + fg * 16;
   }
-  const unsigned char* Bfrag = Bs + (w * 16 + frow) * ROWB + fg * 16;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      uint4 bfr = *reinterpret_cast<const uint4*>(Bfrag + tap * 64 * ROWB + kk * 64);
+      uint4 bfr = bw1[tap * 2 + kk];
 #pragma unroll
       for (int mt = 0; mt < M1; ++mt) {
         uint4 af = *reinterpret_cast<const uint4*>(Xs + base1[mt] + (kh * XW + kw) * ROWB + kk * 64);
@@ -142,9 +133,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
         R16[q * RU + c] = inside ? f2bf(v) : (u16)0;       // SAME padding of the second conv: zero outside the image
       }
   }
-  __syncthreads();                                          // mid tile complete; every wave is done with W1
-  RES_PIN(rb2)
-  RES_STORE_W(rb2)                                          // W2 panel (registers -> LDS)
+  __syncthreads();                                          // mid tile complete
   for (int item = tid; item < O_ITEMS; item += 256) {       // interior of mid -> global, 16-byte rows
     const int pl = item >> 3, cv = item & 7;
     const int i = pl >> 4, xx = pl & 15;
@@ -153,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
       *reinterpret_cast<uint4*>(p.mid + ((n * p.H + gy) * p.W + gx) * 64 + cv * 8) =
           *reinterpret_cast<const uint4*>(Rs + ((i + 1) * RW + xx + 1) * ROWB + cv * 16);
   }
-  __syncthreads();
+  RES_PIN(bw2)
 
   // ---- stage 2: out over the TH x 16 tile ------------------------------------------------------------------
   f32x4 acc2[TH];
@@ -165,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
     const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      uint4 bfr = *reinterpret_cast<const uint4*>(Bfrag + tap * 64 * ROWB + kk * 64);
+      uint4 bfr = bw2[tap * 2 + kk];
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
         uint4 af = *reinterpret_cast<const uint4*>(Afrag2 + ((i + kh) * RW + kw) * ROWB + kk * 64);
@@ -208,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
 
 template <int TH>
 static void launch_res(ResP p, hipStream_t st) {
-  constexpr int LDS = ((TH + 4) * 20 + (TH + 2) * 18 + 576 + TH * 16) * 144;
+  constexpr int LDS = ((TH + 4) * 20 + (TH + 2) * 18 + TH * 16) * 144;
   static bool attr_set = false;
   auto kern = resblock_fused_kernel<TH>;
   if (!attr_set) {
