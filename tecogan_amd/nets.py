@@ -122,9 +122,11 @@ class Generator:
     def __init__(self, ps, num_resblock):
         self.ps, self.nres = ps, num_resblock
         self.seq = None
-        # fused residual-block kernel: bf16 only (fp32 parity mode keeps the two-launch path); TG_NO_FUSED_RESBLOCK=1
-        # is the A/B switch
-        self.fused = ps.act_dtype == torch.bfloat16 and not os.environ.get("TG_NO_FUSED_RESBLOCK")
+        # fused residual-block kernel (csrc/resblock.hip): bf16 only, OPT-IN via TG_FUSED_RESBLOCK=1.  Measured on
+        # MI355X at the training shape [4,32,32,64] it LOSES to the two-launch path (9.7 us vs 8.2 us per block
+        # forward, 12.3 us backward; FRVSR step 6.9 ms vs 5.7 ms same box): with 128 tiles of one wave per SIMD the
+        # block is latency-bound and the halo recompute + second weight fetch cost more than one launch saves.
+        self.fused = ps.act_dtype == torch.bfloat16 and bool(os.environ.get("TG_FUSED_RESBLOCK"))
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None):
