@@ -34,7 +34,9 @@ struct Conv3P {
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope (ReLU 0, LeakyReLU alpha, none 1)
   int tiles_y, tiles_x, ntiles;
   int direct_epi;     // A/B switch (TG_C3_DIRECT_EPI): per-lane stores instead of the LDS-staged rows
+  unsigned in_bytes, w_bytes;   // extents of `in` / `w` for the bounds-checked buffer loads (< 2^31)
 };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ABL: profiling-only ablation bits (1 = skip epilogue stores, 2 = skip the MFMA block, 4 = skip reloads of later
 // stages, 8 = skip LDS staging writes of later stages); the product always launches ABL = 0.
@@ -62,8 +64,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   const int nchunk = (p.Cin + BK - 1) / BK;
   const bool b_stationary = nchunk == 1;
 
-  const TIn* __restrict__ gin = static_cast<const TIn*>(p.in);
-  const TIn* __restrict__ gw = static_cast<const TIn*>(p.w);
   TOut* __restrict__ gout = static_cast<TOut*>(p.out);
   const TOut* __restrict__ gres = static_cast<const TOut*>(p.res);
   const TOut* __restrict__ gaux = static_cast<const TOut*>(p.aux);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
     const int item = min(tid + k * 256, A_ITEMS - 1);
     const int pix = item >> 3, ch = item & 7;
     const int dy = pix / 18, dx = pix % 18;
-    relA[k] = (dy * p.W + dx) * p.Cin + ch * EPV;
+    relA[k] = ((dy * p.W + dx) * p.Cin + ch * EPV) * (int)sizeof(TIn);      // bytes
     dydx[k] = dy | (dx << 8) | ((ch * EPV) << 16);
   }
   int relB[B_LOADS];          // < 0: row beyond Cout (stays zero)
@@ -88,33 +88,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
     const int row = item >> 3, ch = item & 7;
     const int tap = row / BN, co = n0 + row % BN;
     const int wtap = p.flip ? 8 - tap : tap;
-    relB[k] = co < p.Cout ? (wtap * p.Cout + co) * p.Cin + ch * EPV : -1;
+    relB[k] = co < p.Cout ? ((wtap * p.Cout + co) * p.Cin + ch * EPV) * (int)sizeof(TIn) : -1;   // bytes
   }
+  // Zero padding comes from the buffer descriptor's bounds check: a lane outside the image (or past Cin / Cout) is
+  // given an out-of-range offset and the load returns 0.  The earlier form -- clamped address, then `if (!ok) v = 0`
+  // -- put a select behind every load IN the issuing basic block, so each prefetch waited for its own data
+  // (s_waitcnt vmcnt(17..0) right after the burst) and never overlapped the MFMA block it was issued ahead of.
+  constexpr unsigned OOB = 0x80000000u;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
   auto load_stage = [&](int tile, int chunk, bool with_b) {
     const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
     const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
     const int y0 = ty * TH - 1, x0 = tx * 16 - 1;
     const int c0 = chunk * BK;
-    const int base = ((n * p.H + y0) * p.W + x0) * p.Cin + c0;          // wave-uniform
+    const int base = (((n * p.H + y0) * p.W + x0) * p.Cin + c0) * (int)sizeof(TIn);   // wave-uniform, bytes
 #pragma unroll
     for (int k = 0; k < A_LOADS; ++k) {
-      // Loads are UNCONDITIONAL from a clamped in-range address and zeroed by a select afterwards: a
-      // branch around each load makes hipcc wait vmcnt(0) per load and serialises the whole burst.
+      // Loads are UNCONDITIONAL (a branch around each load makes hipcc wait vmcnt(0) per load).
       const int y = y0 + (dydx[k] & 255), x = x0 + ((dydx[k] >> 8) & 255), c = c0 + (dydx[k] >> 16);
       const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && c < p.Cin;
-      uint4 v = *reinterpret_cast<const uint4*>(gin + (ok ? base + relA[k] : 0));
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      ra[k] = v;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)(ok ? (unsigned)(base + relA[k]) : OOB), 0, 0);
+      ra[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
     if (with_b) {
 #pragma unroll
       for (int k = 0; k < B_LOADS; ++k) {
         const int c = c0 + (tid & 7) * EPV;
         const bool ok = relB[k] >= 0 && c < p.Cin;
-        uint4 v = *reinterpret_cast<const uint4*>(gw + (ok ? relB[k] + c0 : 0));
-        if (!ok) v = make_uint4(0, 0, 0, 0);
-        rb[k] = v;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcB, (int)(ok ? (unsigned)(relB[k] + c0 * (int)sizeof(TIn)) : OOB), 0, 0);
+        rb[k] = make_uint4(v.x, v.y, v.z, v.w);
       }
     }
   };
@@ -384,7 +389,11 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   const int epv = d->in_dtype == TG_F32 ? 4 : 8;
   if (d->Cin % epv != 0 || (((uintptr_t)in | (uintptr_t)weight) & 15)) return 0;
   if (d->in_dtype == TG_F32 && d->out_dtype == TG_BF16) return 0;
+  const int64_t esz = d->in_dtype == TG_F32 ? 4 : 2;
+  const int64_t in_bytes = (int64_t)d->N * d->Hin * d->Win * d->Cin * esz, w_bytes = (int64_t)9 * d->Cout * d->Cin * esz;
+  if (in_bytes >= ((int64_t)1 << 31) || w_bytes >= ((int64_t)1 << 31)) return 0;   // 32-bit buffer offsets
   Conv3P p;
+  p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
   p.flip = d->mode == 1;

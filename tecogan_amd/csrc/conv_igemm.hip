@@ -41,9 +41,14 @@ struct ConvP {
   int vec;  // Cin % (16B worth) == 0 -> 16-byte loads
   float nslope, mslope;  // act(v) = max(v, v*nslope); mask = aux > 0 ? 1 : mslope
   int direct_epi;        // A/B switch TG_C3_DIRECT_EPI
+  unsigned in_bytes, w_bytes;   // != 0: both operands < 2^31 bytes -> bounds-checked buffer loads (see load_vec)
+  int sinv;                     // ceil(2^16 / stride)
 };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <typename TIn, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN>
+// BUF: operand fetch through bounds-checked buffer loads (16-byte aligned channel runs, operands < 2^31 bytes);
+// !BUF: the general path (any channel count / alignment / size) with clamped addresses and selects.
+template <typename TIn, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool BUF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
   constexpr int EPV = 16 / (int)sizeof(TIn);  // elements per 16 bytes
@@ -112,8 +117,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   uint4 ra[APASS], rb[BPASS];
   int ikh = 0, ikw = 0, ic = 0;  // counters of the step being LOADED
 
-  auto load_vec = [&](const TIn* base, int64_t off, int c, bool ok) -> uint4 {
-    ok = ok && c < p.Cin;
+  // Fast path: buffer loads through a descriptor; a lane that must read zero (padding, tails, "no next step") gets an
+  // out-of-range offset and the hardware returns 0 -- no select behind the load, so the prefetch issued ahead of the
+  // MFMA block really stays in flight across it (a select in the issuing block made hipcc wait for the data at once).
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  auto load_vec = [&](const TIn* base, bool is_a, int64_t off, int c, bool ok) -> uint4 {
+    ok = ok & (c < p.Cin);
+    if constexpr (BUF) {
+      const unsigned boff = ok ? (unsigned)off * (unsigned)sizeof(TIn) : 0x80000000u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(is_a ? rsrcA : rsrcB, (int)boff, 0, 0);
+      return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
     if (p.vec) {
       // unconditional load from a clamped address + select: a branch per load would make hipcc wait
       // vmcnt(0) after every load and serialise the panel fetch
@@ -129,34 +144,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       tmp[e] = oke ? t : (TIn)0;
     }
     return *reinterpret_cast<uint4*>(tmp);
+    }
   };
 
-  auto load_global = [&]() {
+  auto load_global = [&](bool live) {
     const int kh = kh0 + ikh * kstep, kw = kw0 + ikw * kstep;
     const int c = ic * BK + lchunk * EPV;
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      int iy, ix;
-      bool ok = a_n[ps] >= 0;
-      if (p.mode == 0) {
-        iy = a_oy[ps] * p.s - p.pt + kh;
-        ix = a_ox[ps] * p.s - p.pl + kw;
-      } else {
-        const int ny = a_oy[ps] + p.pt - kh, nx = a_ox[ps] + p.pl - kw;
-        ok = ok && ny >= 0 && nx >= 0;
-        iy = ny / p.s;
-        ix = nx / p.s;
-      }
-      ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+      // branch-free (selects, bitwise ands): control flow between the loads would split the burst into basic blocks
+      const bool fwd = p.mode == 0;
+      const int ny = a_oy[ps] + p.pt - kh, nx = a_ox[ps] + p.pl - kw;
+      // x / s as (x * ceil(2^16 / s)) >> 16: exact for x < 16384 (image extents), and cheap enough to compute on both
+      // paths; blended with a bit mask (hipcc turns a uniform ?: into a branch, which would end the basic block)
+      const int fm = fwd ? -1 : 0;
+      const int iy = ((a_oy[ps] * p.s - p.pt + kh) & fm) | (((max(ny, 0) * p.sinv) >> 16) & ~fm);
+      const int ix = ((a_ox[ps] * p.s - p.pl + kw) & fm) | (((max(nx, 0) * p.sinv) >> 16) & ~fm);
+      const bool ok = live & (a_n[ps] >= 0) & (fwd | ((ny >= 0) & (nx >= 0))) & ((unsigned)iy < (unsigned)p.Hin) &
+                      ((unsigned)ix < (unsigned)p.Win);
       const int64_t off = ((int64_t)(a_n[ps] * p.Hin + iy) * p.Win + ix) * p.Cin + c;
-      ra[ps] = load_vec(gin, off, c, ok);
+      ra[ps] = load_vec(gin, true, off, c, ok);
     }
 #pragma unroll
     for (int ps = 0; ps < BPASS; ++ps) {
       const int row = ps * 32 + lrow;
-      const bool ok = row < BN && (n0 + row) < p.Cout;
+      const bool ok = live & (row < BN) & ((n0 + row) < p.Cout);
       const int64_t off = ((int64_t)(kh * p.KW + kw) * p.Cout + n0 + row) * p.Cin + c;
-      rb[ps] = load_vec(gw, off, c, ok);
+      rb[ps] = load_vec(gw, false, off, c, ok);
     }
     if (++ic == nchunk) {
       ic = 0;
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_global();
+  load_global(true);
   store_lds(0);
   __syncthreads();
 
@@ -191,7 +205,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int step = 0; step < T; ++step) {
     const int buf = step & 1;
     const bool more = step + 1 < T;
-    if (more) load_global();
+    if constexpr (BUF) load_global(more);    // unconditional: one straight-line block, exact vmcnt bookkeeping
+    else if (more) load_global(true);
     const unsigned char* Ab = As + (buf * BM + wm * TM * 16 + frow) * ROWB + fg * 16;
     const unsigned char* Bb = Bs + (buf * BN + wn * TN * 16 + frow) * ROWB + fg * 16;
 #pragma unroll
@@ -314,7 +329,10 @@ template <typename TIn, typename TOut, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvP& p, int nphase, int mq_max, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   dim3 grid((mq_max + BM - 1) / BM, (p.Cout + BN - 1) / BN, nphase);
-  hipLaunchKernelGGL((conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN>), grid, dim3(256), 0, st, p);
+  if (p.vec && p.in_bytes != 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN, false>), grid, dim3(256), 0, st, p);
 }
 
 template <typename TIn, typename TOut>
@@ -342,6 +360,7 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   TG_CHECK_ARG(d->KH >= 1 && d->KH <= 11 && d->KW >= 1 && d->KW <= 11, "kernel size out of range");
   TG_CHECK_ARG(d->stride >= 1 && d->stride <= 4, "stride must be 1..4");
   TG_CHECK_ARG(d->mode == 0 || d->mode == 1, "mode must be 0 (gather) or 1 (transposed)");
+  TG_CHECK_ARG(d->mode == 0 || (d->Hout < 16000 && d->Wout < 16000), "transposed mode: output extent must be < 16000");
   TG_CHECK_ARG((d->in_dtype == TG_F32 || d->in_dtype == TG_BF16) && (d->out_dtype == TG_F32 || d->out_dtype == TG_BF16),
                "bad dtype");
   TG_CHECK_ARG(!(d->in_dtype == TG_F32 && d->out_dtype == TG_BF16), "f32 in / bf16 out is not built");
@@ -363,6 +382,15 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   const int epv = d->in_dtype == TG_F32 ? 4 : 8;
   p.vec = (d->Cin % epv == 0) && (((uintptr_t)in | (uintptr_t)weight) % 16 == 0);
+  {
+    const int64_t esz = d->in_dtype == TG_F32 ? 4 : 2;
+    const int64_t ib = (int64_t)d->N * d->Hin * d->Win * d->Cin * esz, wb = (int64_t)d->KH * d->KW * d->Cout * d->Cin * esz;
+    static const bool no_buf = getenv("TG_NO_BUFFER_LOADS") != nullptr;                // A/B switch
+    const bool fits = ib < ((int64_t)1 << 31) && wb < ((int64_t)1 << 31) && !no_buf;
+    p.sinv = (65536 + d->stride - 1) / d->stride;
+    p.in_bytes = fits ? (unsigned)ib : 0u;
+    p.w_bytes = fits ? (unsigned)wb : 0u;
+  }
   int nphase = 1, mq_max = d->N * d->Hout * d->Wout;
   if (d->mode == 1 && d->stride > 1) {
     nphase = d->stride * d->stride;

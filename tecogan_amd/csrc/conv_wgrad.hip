@@ -224,8 +224,54 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   }
 }
 
+// bf16, C a multiple of 8 with C/8 a power of two <= 256: every thread streams 16-byte channel octets (8 fp32
+// partial sums), four row-strides in flight; one LDS reduction and C atomics per workgroup.
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const u16* __restrict__ x, int64_t rows, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float red[256 * 8];
+  const int OC = C >> 3, RP = 256 / OC;
+  const int oc = threadIdx.x % OC, rsub = threadIdx.x / OC;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * RP;
+  int64_t r = (int64_t)blockIdx.x * RP + rsub;
+  auto accum = [&](const uint4& v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[2 * e] += __uint_as_float(w[e] << 16);
+      s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+    }
+  };
+  for (; r + 3 * stride < rows; r += 4 * stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(x + (r + k * stride) * C + oc * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) accum(v[k]);
+  }
+  for (; r < rows; r += stride) accum(*reinterpret_cast<const uint4*>(x + r * C + oc * 8));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int k = 0; k < RP; ++k) t += red[(k * OC + (c >> 3)) * 8 + (c & 7)];
+    unsafeAtomicAdd(out + c, t);
+  }
+}
+
 extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream) {
   TG_CHECK_ARG(x && out && rows > 0 && C > 0, "bad argument");
+  if (dtype == TG_BF16 && C % 8 == 0 && C / 8 <= 256 && ((C / 8) & (C / 8 - 1)) == 0 && ((uintptr_t)x & 15) == 0) {
+    const int RP = 256 / (C / 8);
+    int gx = (int)cdiv64(rows, (int64_t)RP * 8);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3(gx), dim3(256), 0, static_cast<hipStream_t>(stream), (const u16*)x, rows,
+                       C, out);
+    TG_CHECK_LAUNCH();
+  }
   const int Cb = C < 256 ? C : 256;
   const int lpc = 256 / Cb;
   int gx = (int)cdiv64(rows, (int64_t)lpc * 64);
@@ -247,6 +293,7 @@ extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* o
 // transposing writes conflict-free (8 rows * 34 dwords = 16 mod 32).  Waves 0-1 stage X, waves 2-3 stage Y.
 // K-step = 64 pixels; each wave owns a 32x32 quadrant of the 64x64 (cx, cy) tile; fp32 accumulate; split-K over
 // pixel chunks with fp32 atomics into the flat gradient buffer.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct WgradBP {
   const u16* x;
   const u16* y;
@@ -254,13 +301,19 @@ struct WgradBP {
   float* dbias;
   int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
   int M, chunk, ytiles, ldx, ldy;
+  unsigned xbytes, ybytes;             // buffer extents for the bounds-checked loads
+  unsigned long long magicW, magicH;   // ceil(2^32 / Wy), ceil(2^32 / Hy): exact division for m * d < 2^32
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
+// PF = depth of the register prefetch ring: with ~4 resident workgroups per CU and a 64-pixel K-step whose MFMA
+// block lasts only ~200 cycles, a one-step-ahead prefetch exposes the whole L2/HBM latency every step (measured
+// 1.65 us per step at one workgroup per CU); PF steps in flight divide that exposure by PF.
+template <int PF>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
   constexpr int ROWB = 136;                       // bytes per channel row: 64 pixels * 2 B + 8 pad
   __shared__ __attribute__((aligned(16))) unsigned char Xt[64 * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char Yt[64 * ROWB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tap = blockIdx.x, kh = tap / p.KW, kw = tap % p.KW;
   const int xt = blockIdx.y / p.ytiles, yt = blockIdx.y % p.ytiles;
@@ -270,8 +323,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
   const int frow = lane & 15, fg = lane >> 4;
   // staging role: threads 0..127 -> X, 128..255 -> Y; item = (pixel pair 0..31, channel octet 0..7)... 256 items each,
   // two items per thread (pairs pp and pp+16)
-  const bool stage_x = tid < 128;
+  const bool stage_x = wave < 2;                   // wave-uniform: every role parameter below is scalar
   const int st = tid & 127, oct = st >> 4, pp0 = st & 15;
+  // One address formula for both roles: Y is the "1x1, stride 1, no padding" case of the X gather.  (A per-lane
+  // `stage_x ? p.x : p.y` made hipcc fetch the pointer from the kernarg segment with a vector load and wait
+  // vmcnt(0) in front of EVERY data load -- the whole burst was serialised.)
+  // Loads are buffer loads through a wave-uniform descriptor: a lane that must read zero (padding, tail) gets an
+  // out-of-range offset and the hardware returns 0.  A select AFTER the load (`if (!ok) v = 0`) sits in the
+  // issuing basic block and made every prefetch wait for its own data before the MFMAs started.
+  const unsigned long long sbase = (unsigned long long)(stage_x ? p.x : p.y);
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sbase);
+  const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(sbase >> 32));
+  const unsigned sbytes = __builtin_amdgcn_readfirstlane(stage_x ? p.xbytes : p.ybytes);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)bhi << 32) | blo), 0, (int)sbytes,
+                                                      0x00020000);
+  const int Hs = stage_x ? p.Hx : p.Hy, Ws = stage_x ? p.Wx : p.Wy, lds = stage_x ? p.ldx : p.ldy;
+  const int strd = stage_x ? p.s : 1, offy = stage_x ? kh - p.pt : 0, offx = stage_x ? kw - p.pl : 0;
+  const int cbase = (stage_x ? cx0 : cy0) + oct * 8;
+  const bool cok = cbase < lds;
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -280,41 +349,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  uint4 v[2][2];
-  auto load_block = [&](int mb) {      // unconditional loads (clamped address) + select; issued one block ahead
+  uint4 v[PF][2][2];
+  auto load_block = [&](uint4 (&dst)[2][2], int mb) {   // unconditional loads (clamped address) + select
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int m_raw = mb + (pp0 + h * 16) * 2 + q;
         const int m = min(m_raw, mend - 1);
-        bool ok = m_raw < mend;
-        int64_t off;
-        if (stage_x) {
-          const int ox = m % p.Wy, t = m / p.Wy;
-          const int oy = t % p.Hy, n = t / p.Hy;
-          const int iy = oy * p.s - p.pt + kh, ix = ox * p.s - p.pl + kw;
-          const int c = cx0 + oct * 8;
-          ok = ok && iy >= 0 && iy < p.Hx && ix >= 0 && ix < p.Wx && c < p.ldx;
-          off = ok ? ((int64_t)(n * p.Hx + iy) * p.Wx + ix) * p.ldx + c : 0;
-        } else {
-          const int c = cy0 + oct * 8;
-          ok = ok && c < p.ldy;
-          off = ok ? (int64_t)m * p.ldy + c : 0;
-        }
-        uint4 t4 = *reinterpret_cast<const uint4*>((stage_x ? p.x : p.y) + off);
-        if (!ok) t4 = make_uint4(0, 0, 0, 0);
-        v[h][q] = t4;
+        const int t = (int)(((unsigned long long)(unsigned)m * p.magicW) >> 32), ox = m - t * p.Wy;
+        const int n = (int)(((unsigned long long)(unsigned)t * p.magicH) >> 32), oy = t - n * p.Hy;
+        const int iy = oy * strd + offy, ix = ox * strd + offx;
+        const bool ok = m_raw < mend && cok && (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
+        const unsigned boff = ok ? (unsigned)(((n * Hs + iy) * Ws + ix) * lds + cbase) * 2u : 0x80000000u;
+        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)boff, 0, 0);
+        dst[h][q] = make_uint4(t4.x, t4.y, t4.z, t4.w);
       }
     }
   };
-  load_block(mbeg);
-  for (int mb = mbeg; mb < mend; mb += 64) {
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_block(v[d], mbeg + 64 * d);
+  for (int mb0 = mbeg; mb0 < mend; mb0 += 64 * PF) {
+#pragma unroll
+   for (int d = 0; d < PF; ++d) {
+    const int mb = mb0 + 64 * d;    // no early exit: the host makes `chunk` a multiple of 64*PF and steps past the
+                                    // end run on zeros, so the ring's load/wait pattern is one straight line
     unsigned char* panel = stage_x ? Xt : Yt;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[h][0]);   // pixel 2pp   : channels 8*oct .. +7
-      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[h][1]);   // pixel 2pp+1
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[d][h][0]);   // pixel 2pp   : channels 8*oct .. +7
+      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[d][h][1]);   // pixel 2pp+1
       const int pp = pp0 + h * 16;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -326,7 +390,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
       }
     }
     __syncthreads();
-    if (mb + 64 < mend) load_block(mb + 64);          // in flight during the MFMAs below
+    load_block(v[d], mb + 64 * PF);    // refill this ring slot, unconditionally (lanes past the end fetch nothing):
+                                       // a fixed number of loads in flight lets hipcc count vmcnt exactly
     if (do_bias && tid < 64) {
       const uint32_t* row = reinterpret_cast<const uint32_t*>(Yt + tid * ROWB);
 #pragma unroll 8
@@ -356,6 +421,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradBP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfm[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+   }
   }
   float* __restrict__ dw = p.dw + (int64_t)tap * p.Cx * p.Cy;
 #pragma unroll
@@ -382,6 +448,15 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.N = d->N; p.Hx = d->Hin; p.Wx = d->Win; p.Cx = d->Cin; p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.M = d->N * d->Hout * d->Wout; p.ldx = ldx; p.ldy = ldy;
+  const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
+  const int dmax = d->Hout > d->Wout ? d->Hout : d->Wout;
+  if (M64 * dmax >= ((int64_t)1 << 32) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
+      M64 * ldy >= ((int64_t)1 << 30))
+    return 0;                                        // 32-bit offsets / magic division out of range: generic kernel
+  p.xbytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * ldx * 2);
+  p.ybytes = (unsigned)(M64 * ldy * 2);
+  p.magicW = (((unsigned long long)1 << 32) + d->Wout - 1) / d->Wout;
+  p.magicH = (((unsigned long long)1 << 32) + d->Hout - 1) / d->Hout;
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
@@ -390,8 +465,14 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   const int max_split = (p.M + 127) / 128;
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
-  p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
+  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 4;               // A/B switch
+  const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);
+  const int quantum = 64 * pf;
+  p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
-  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(d->KH * d->KW, xtiles * p.ytiles, ksplit), dim3(256), 0, st, p);
+  const dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
+  if (pf <= 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, p);
+  else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), 0, st, p);
   return 1;
 }
