@@ -381,6 +381,150 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 8-channel inputs (bf16): the 3-channel tensors of the path after channel padding -- the input gradient of the
+// generator's output conv (8 -> 64 at HR, once per frame), VGG conv1_1 and FNet's first conv.  The general kernel
+// spends a full 64-wide K chunk per tap on them (7/8 zeros).  Here K packs the TAPS: one v_mfma_f32_16x16x32_bf16
+// consumes 4 taps x 8 channels (lane group fg <-> tap 4*kk + fg), so 3 MFMAs cover the 9 taps (3 zero-weighted
+// slots) instead of 18.  The weights are 3*NT register fragments per lane fetched once (no weight LDS at all); the
+// halo tile is 16 B per pixel, so every A fragment is one conflict-free ds_read_b128.  The kernel is then what
+// it should be: a streaming epilogue (HBM-bound on the output and mask tensors).
+struct C8P {
+  const void* in;
+  const void* w;      // [9][Cout][8]
+  const float* bias;
+  const u16* res;
+  const u16* aux;
+  u16* out;
+  int N, H, W, Cout, flip;
+  float nslope, mslope;
+  int tiles_y, tiles_x;
+  unsigned in_bytes, w_bytes;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_c8_kernel(C8P p) {
+  constexpr int TH = 4, TW = 32, HW = TW + 2, HALO = (TH + 2) * HW;
+  constexpr int SP = NT * 16 + 8;                     // u16 per staged pixel row (+16 B pad)
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[HALO * 16];
+  __shared__ __attribute__((aligned(16))) u16 stage[TH * TW * SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int frow = lane & 15, fg = lane >> 4;
+  const int tx = blockIdx.x % p.tiles_x, t1 = blockIdx.x / p.tiles_x;
+  const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * NT * 16;
+  constexpr unsigned OOB = 0x80000000u;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  {  // halo tile: one 16-byte pixel per thread, zero outside the image (buffer bounds check)
+    const int item = min(tid, HALO - 1);
+    const int dy = item / HW, dx = item - dy * HW;
+    const int y = y0 - 1 + dy, x = x0 - 1 + dx;
+    const bool ok = tid < HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)(ok ? (unsigned)(((n * p.H + y) * p.W + x) * 16) : OOB),
+                                                          0, 0);
+    if (tid < HALO) *reinterpret_cast<u32x4*>(Xs + item * 16) = v;
+  }
+  // weight fragments: lane (frow = output channel, fg = tap slot) of K-step kk holds w[tap 4*kk+fg][cout][0..7]
+  uint4 bfr[3][NT];
+  float bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + j * 16 + frow;
+    bv[j] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      const int t = 4 * kk + fg;
+      const int wt = p.flip ? 8 - t : t;
+      const bool ok = t < 9 && co < p.Cout;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(ok ? (unsigned)((wt * p.Cout + co) * 16) : OOB), 0, 0);
+      bfr[kk][j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  }
+  // per-lane tap offsets inside the halo tile (slots >= 9 re-read tap 8: finite data times zero weights)
+  int aoff[3];
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const int t = min(4 * kk + fg, 8);
+    const int kh = t / 3, kw = t - kh * 3;
+    aoff[kk] = ((wave + kh) * HW + frow + kw) * 16;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sgm = 0; sgm < TW / 16; ++sgm) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      uint4 a = *reinterpret_cast<const uint4*>(Xs + aoff[kk] + sgm * 256);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a),
+                                                         *reinterpret_cast<bf16x8*>(&bfr[kk][j]), acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pl = (wave * TW + sgm * 16 + fg * 4 + r) * SP + frow;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float v = acc[j][r] + bv[j];
+        stage[pl + j * 16] = f2bf(fmaxf(v, v * p.nslope));
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int VPP = NT * 2, NV = TH * TW * VPP;
+  const bool has_res = p.res != nullptr, has_aux = p.aux != nullptr;
+#pragma unroll
+  for (int it0 = 0; it0 < NV; it0 += 256) {
+    const int it = it0 + tid;
+    const int pl = it / VPP, cv = it % VPP;
+    const int y = y0 + pl / TW, x = x0 + pl % TW, c = n0 + cv * 8;
+    if (y >= p.H || x >= p.W || c >= p.Cout) continue;
+    uint4 o = *reinterpret_cast<const uint4*>(stage + pl * SP + cv * 8);
+    const int idx = ((n * p.H + y) * p.W + x) * p.Cout + c;
+    if (has_res || has_aux) {
+      uint4 rr = make_uint4(0, 0, 0, 0), aa = rr;
+      if (has_res) rr = *reinterpret_cast<const uint4*>(p.res + idx);
+      if (has_aux) aa = *reinterpret_cast<const uint4*>(p.aux + idx);
+      u16* ov = reinterpret_cast<u16*>(&o);
+      const u16* rv = reinterpret_cast<const u16*>(&rr);
+      const u16* av = reinterpret_cast<const u16*>(&aa);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bf2f(ov[e]);
+        if (has_res) v += bf2f(rv[e]);
+        if (has_aux) v *= bf2f(av[e]) > 0.f ? 1.f : p.mslope;
+        ov[e] = f2bf(v);
+      }
+    }
+    *reinterpret_cast<uint4*>(p.out + idx) = o;
+  }
+}
+
+static int conv3x3_c8_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                          const void* aux, void* out, hipStream_t st) {
+  static const bool enabled = getenv("TG_NO_C8") == nullptr;           // A/B switch
+  if (!enabled || d->Cin != 8 || d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
+  if (d->act >= TG_ACT_TANH || (d->Cout != 32 && d->Cout % 64 != 0)) return 0;
+  if ((((uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15)) return 0;
+  C8P p;
+  p.in = in; p.w = weight; p.bias = bias; p.res = (const u16*)res; p.aux = (const u16*)aux; p.out = (u16*)out;
+  p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cout = d->Cout; p.flip = d->mode == 1;
+  p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
+  p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
+  p.tiles_y = (p.H + 3) / 4; p.tiles_x = (p.W + 31) / 32;
+  p.in_bytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * 16);
+  p.w_bytes = (unsigned)((int64_t)9 * d->Cout * 16);
+  const int64_t blocks = (int64_t)p.N * p.tiles_y * p.tiles_x;
+  if (blocks >= ((int64_t)1 << 31)) return 0;
+  if (d->Cout == 32) hipLaunchKernelGGL(conv3x3_c8_kernel<2>, dim3((unsigned)blocks, 1), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(conv3x3_c8_kernel<4>, dim3((unsigned)blocks, d->Cout / 64), dim3(256), 0, st, p);
+  return 1;
+}
+
 // Returns 1 if the descriptor was handled by this kernel, 0 if the generic engine must take it.
 int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                    const void* aux, void* out, hipStream_t st) {
@@ -392,12 +536,13 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   const int64_t esz = d->in_dtype == TG_F32 ? 4 : 2;
   const int64_t in_bytes = (int64_t)d->N * d->Hin * d->Win * d->Cin * esz, w_bytes = (int64_t)9 * d->Cout * d->Cin * esz;
   if (in_bytes >= ((int64_t)1 << 31) || w_bytes >= ((int64_t)1 << 31)) return 0;   // 32-bit buffer offsets
+  if (aux && d->mask_act != TG_ACT_RELU && d->mask_act != TG_ACT_LRELU) return 0;   // generic engine handles others
+  if (conv3x3_c8_try(d, in, weight, bias, res, aux, out, st)) return 1;
   Conv3P p;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
   p.flip = d->mode == 1;
-  if (aux && d->mask_act != TG_ACT_RELU && d->mask_act != TG_ACT_LRELU) return 0;   // generic engine handles others
   p.act = d->act; p.act_alpha = d->act_alpha;
   static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
   p.direct_epi = direct;

@@ -305,9 +305,9 @@ struct WgradBP {
   unsigned long long magicW, magicH;   // ceil(2^32 / Wy), ceil(2^32 / Hy): exact division for m * d < 2^32
 };
 
-// PF = depth of the register prefetch ring: with ~4 resident workgroups per CU and a 64-pixel K-step whose MFMA
-// block lasts only ~200 cycles, a one-step-ahead prefetch exposes the whole L2/HBM latency every step (measured
-// 1.65 us per step at one workgroup per CU); PF steps in flight divide that exposure by PF.
+// PF = depth of the register prefetch ring (TG_WGRAD_PF).  Once the loads became buffer loads (no select behind
+// them, see below) the one-step prefetch really overlaps the MFMA block and PF = 1 measured equal or better than
+// PF = 4 at 3 of 5 shapes (tools/mb_wgrad.py); the deeper ring stays available as an A/B switch.
 template <int PF>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
   constexpr int ROWB = 136;                       // bytes per channel row: 64 pixels * 2 B + 8 pad
@@ -460,12 +460,15 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
-  static const int target = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 1024;   // measured sweet spot (128..4096 swept, profiles/r01c)
+  // workgroup target, measured (tools/mb_wgrad.py, 256/512/1024 swept): 512 for the full 64x64-channel tiles of the
+  // LR generator layers, 1024 elsewhere (narrow tiles and the large HR / D layers)
+  static const int target_env = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 0;
+  const int target = target_env ? target_env : ((p.Cx >= 64 && p.Cy >= 64 && p.M <= 65536) ? 512 : 1024);
   int ksplit = (target + base_blocks - 1) / base_blocks;           // workgroup target: trades parallelism vs atomics
   const int max_split = (p.M + 127) / 128;
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
-  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 4;               // A/B switch
+  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 1;               // A/B switch
   const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);
   const int quantum = 64 * pf;
   p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;

@@ -136,6 +136,29 @@ def test_conv_bwd_mask_and_residual_epilogue():
         close(dx, (x.grad + res) * fac, 1e-4, "mask epilogue act=%d" % act)
 
 
+@pytest.mark.parametrize("case", [(2, 30, 45, 64), (1, 128, 128, 64), (3, 9, 70, 128), (2, 17, 33, 32)])
+def test_conv3x3_8channel_tap_packed_kernel(case):
+    """bf16 8-channel inputs take the tap-packed kernel (csrc/conv3x3.hip conv3x3_c8_kernel): forward with bias +
+    LeakyReLU, and the input-gradient form (mirrored taps, + residual, * relu' mask) of the generator's output conv."""
+    N, H, W, Cout = case
+    x, w, b = rnd(N, H, W, 8, seed=1), rnd(3, 3, 8, Cout, seed=2, scale=0.3), rnd(Cout, seed=3)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    ref = O.lrelu(O.conv2(xb, wb, b, 1), 0.2)
+    got = run_conv_fwd(x, w, b, 1, ACT_LRELU, 0.2, dtype=torch.bfloat16)
+    close(got, ref, 1e-2, "c8 fwd %s" % (case,))
+    # input-gradient form: y = conv(z, w2) with z [N,H,W,Cout] and 8 output channels; dz = bwd(gy) [+ res] * relu'(aux)
+    w2 = rnd(3, 3, Cout, 8, seed=4, scale=0.3).bfloat16().float()
+    gy = rnd(N, H, W, 8, seed=5).bfloat16().float()
+    res, aux = rnd(N, H, W, Cout, seed=6).bfloat16().float(), rnd(N, H, W, Cout, seed=7).bfloat16().float()
+    z = torch.zeros(N, H, W, Cout, requires_grad=True)
+    O.conv2(z, w2, None, 1).backward(gy)
+    d = K.conv_desc(N, H, W, 8, H, W, Cout, 3, 3, 1, 1, 1, 1, TG_BF16, TG_BF16, 0, 0.0, ACT_RELU, 0.0)
+    dz = torch.empty(N, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+    K.conv_forward(d, gy.to(DEV, torch.bfloat16), w2.reshape(9, Cout, 8).contiguous().to(DEV, torch.bfloat16), None,
+                   res.to(DEV, torch.bfloat16), aux.to(DEV, torch.bfloat16), dz)
+    close(dz, (z.grad + res) * (aux > 0).float(), 2e-2, "c8 bwd-form %s" % (case,))
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 64, 64), (1, 5, 7, 64, 64), (1, 16, 16, 32, 64)])
 def test_deconv_fwd_bwd_fp32(shape):
     N, H, W, Cin, Cout = shape
