@@ -38,6 +38,22 @@ __device__ __forceinline__ u16 f2bf(float f) {
   return (u16)(u >> 16);
 }
 
+// 8 bf16 <-> 8 f32 (one 16-byte vector): the unit of the vectorised pointwise kernels
+__device__ __forceinline__ void bf8_unpack(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __uint_as_float(w[e] << 16);
+    f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 bf8_pack(const float (&f)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(f[2 * e]) | ((uint32_t)f2bf(f[2 * e + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }

@@ -118,9 +118,66 @@ __global__ __launch_bounds__(256) void cosine_loss_kernel(const T* __restrict__ 
   block_atomic_add(acc * cos_scale, cos_sum);
 }
 
+// bf16, C in {64,128,256,512}: LP = C/8 lanes share a pixel (64/LP pixels per wave), every lane owns
+// one 16-byte channel octet of g and t, kept in registers for the gradient pass; sub-wave xor reductions.
+template <int LP>
+__global__ __launch_bounds__(256) void cosine_loss_x8_kernel(const u16* __restrict__ g, const u16* __restrict__ t,
+                                                             int64_t npix, float cos_scale, float grad_scale,
+                                                             float* __restrict__ cos_sum, u16* __restrict__ d_g) {
+  constexpr int PPW = 64 / LP, C = LP * 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LP, oc = lane % LP;
+  float acc = 0.f;
+  for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * PPW; p0 < npix; p0 += (int64_t)gridDim.x * 4 * PPW) {
+    const int64_t pix = p0 + sub;
+    const bool ok = pix < npix;
+    const int64_t off = (ok ? pix : p0) * C + oc * 8;
+    float a[8], b[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(g + off), a);
+    bf8_unpack(*reinterpret_cast<const uint4*>(t + off), b);
+    float gg = 0.f, tt = 0.f, gt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gg += a[k] * a[k];
+      tt += b[k] * b[k];
+      gt += a[k] * b[k];
+    }
+#pragma unroll
+    for (int o = LP / 2; o > 0; o >>= 1) {
+      gg += __shfl_xor(gg, o, 64);
+      tt += __shfl_xor(tt, o, 64);
+      gt += __shfl_xor(gt, o, 64);
+    }
+    const float ng = sqrtf(gg + 1e-12f), nt = sqrtf(tt + 1e-12f);
+    const float cosv = gt / (ng * nt);
+    if (ok && oc == 0) acc += cosv;
+    if (d_g && ok) {
+      const float k1 = grad_scale / (ng * nt), k2 = grad_scale * cosv / (ng * ng);
+      float d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = k1 * b[k] - k2 * a[k];
+      *reinterpret_cast<uint4*>(d_g + off) = bf8_pack(d);
+    }
+  }
+  block_atomic_add(acc * cos_scale, cos_sum);
+}
+
 extern "C" int tg_cosine_loss(const void* g, const void* t, int dtype, int64_t npix, int C, float cos_scale,
                               float grad_scale, float* cos_sum, void* d_g, void* stream) {
   TG_CHECK_ARG(g && t && cos_sum && npix > 0 && C > 0, "bad argument");
+  if (dtype == TG_BF16 && (C == 64 || C == 128 || C == 256 || C == 512) &&
+      ((((uintptr_t)g | (uintptr_t)t | (uintptr_t)d_g)) & 15) == 0) {
+    hipStream_t sx = static_cast<hipStream_t>(stream);
+    const int lp = C / 8;
+    dim3 gx(grid_1d(npix, 4 * (64 / lp), 8192));
+#define TG_COS(LP_) hipLaunchKernelGGL((cosine_loss_x8_kernel<LP_>), gx, dim3(256), 0, sx, (const u16*)g, (const u16*)t, npix, cos_scale, grad_scale, cos_sum, (u16*)d_g)
+    if (lp == 8) TG_COS(8);
+    else if (lp == 16) TG_COS(16);
+    else if (lp == 32) TG_COS(32);
+    else TG_COS(64);
+#undef TG_COS
+    TG_CHECK_LAUNCH();
+  }
   dim3 grid(grid_1d(npix, 4, 4096));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == TG_F32) hipLaunchKernelGGL((cosine_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)g, (const float*)t, npix, C, cos_scale, grad_scale, cos_sum, (float*)d_g);

@@ -56,6 +56,80 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
   }
 }
 
+// bf16, C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads and stores, 32-bit index math.
+__global__ __launch_bounds__(256) void maxpool2_fwd_x8_kernel(const u16* __restrict__ in, u16* __restrict__ out, int N,
+                                                              int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C8 = C >> 3;
+  const int n = N * Ho * Wo * C8;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int c8 = e % C8;
+    int t = e / C8;
+    const int x = t % Wo;
+    t /= Wo;
+    const int y = t % Ho, b = t / Ho;
+    const u16* __restrict__ p = in + ((int64_t)(b * H + 2 * y) * W + 2 * x) * C + c8 * 8;
+    const uint4 q0 = *reinterpret_cast<const uint4*>(p), q1 = *reinterpret_cast<const uint4*>(p + C);
+    const uint4 q2 = *reinterpret_cast<const uint4*>(p + (int64_t)W * C), q3 = *reinterpret_cast<const uint4*>(p + (int64_t)W * C + C);
+    float v0[8], v1[8], v2[8], v3[8], m[8];
+    bf8_unpack(q0, v0); bf8_unpack(q1, v1); bf8_unpack(q2, v2); bf8_unpack(q3, v3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+    *reinterpret_cast<uint4*>(out + (int64_t)e * 8) = bf8_pack(m);
+  }
+}
+
+// One thread per (2x2 window, channel octet): reads the window and the pooled gradient once, writes all four input
+// gradients (first-max-wins tie rule of the scalar kernel; odd trailing rows/columns are zeroed by the last windows).
+__global__ __launch_bounds__(256) void maxpool2_bwd_x8_kernel(const u16* __restrict__ in, const u16* __restrict__ d_out,
+                                                              u16* __restrict__ d_in, int N, int H, int W, int C, int act,
+                                                              float alpha) {
+  const int Ho = H / 2, Wo = W / 2, C8 = C >> 3;
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;                // windows incl. the ragged edge
+  const int n = N * Hc * Wc * C8;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int c8 = e % C8;
+    int t = e / C8;
+    const int ox = t % Wc;
+    t /= Wc;
+    const int oy = t % Hc, b = t / Hc;
+    const int64_t base = ((int64_t)(b * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (oy >= Ho || ox >= Wo) {                                 // ragged edge: no pooling window covers these pixels
+      *reinterpret_cast<uint4*>(d_in + base) = zero;
+      if (2 * ox + 1 < W) *reinterpret_cast<uint4*>(d_in + base + C) = zero;
+      if (2 * oy + 1 < H) {
+        *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C) = zero;
+        if (2 * ox + 1 < W) *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C + C) = zero;
+      }
+      continue;
+    }
+    float v[4][8], g[8], o[4][8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(in + base), v[0]);
+    bf8_unpack(*reinterpret_cast<const uint4*>(in + base + C), v[1]);
+    bf8_unpack(*reinterpret_cast<const uint4*>(in + base + (int64_t)W * C), v[2]);
+    bf8_unpack(*reinterpret_cast<const uint4*>(in + base + (int64_t)W * C + C), v[3]);
+    bf8_unpack(*reinterpret_cast<const uint4*>(d_out + ((int64_t)(b * Ho + oy) * Wo + ox) * C + c8 * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int am = 0;
+      float m = v[0][k];
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (v[j][k] > m) {
+          m = v[j][k];
+          am = j;
+        }
+      const float gv = g[k] * act_grad_from_out(m, act, alpha);   // `in` is the activation OUTPUT
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j][k] = am == j ? gv : 0.f;
+    }
+    *reinterpret_cast<uint4*>(d_in + base) = bf8_pack(o[0]);
+    *reinterpret_cast<uint4*>(d_in + base + C) = bf8_pack(o[1]);
+    *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C) = bf8_pack(o[2]);
+    *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C + C) = bf8_pack(o[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // tf.image.resize_images x2, legacy bilinear -- reference lib/frvsr.py:21-22  [TF1] A.4
 template <typename T>
@@ -170,6 +244,19 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const TI* __restrict__ d_o
     float g = Elem<TI>::ld(d_out + e) * scale;
     if (y) g *= act_grad_from_out(Elem<TI>::ld(y + e), act, alpha);
     Elem<TO>::st(d_in + e, g);
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_x8_kernel(const u16* __restrict__ d_out, const u16* __restrict__ y,
+                                                         u16* __restrict__ d_in, int64_t n8, int act, float alpha,
+                                                         float scale) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+    float g[8], yv[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(d_out + e * 8), g);
+    if (y) bf8_unpack(*reinterpret_cast<const uint4*>(y + e * 8), yv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = g[k] * scale * (y ? act_grad_from_out(yv[k], act, alpha) : 1.f);
+    *reinterpret_cast<uint4*>(d_in + e * 8) = bf8_pack(g);
   }
 }
 
@@ -376,6 +463,13 @@ __global__ __launch_bounds__(256) void sum_diff_kernel(const T* __restrict__ a, 
 
 extern "C" int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream) {
   TG_CHECK_ARG(in && out && N > 0 && H > 1 && W > 1 && C > 0, "bad argument");
+  const bool x8 = dtype == TG_BF16 && C % 8 == 0 && ((((uintptr_t)in | (uintptr_t)out)) & 15) == 0 &&
+                  (int64_t)N * H * W * C < ((int64_t)1 << 31);
+  if (x8) {
+    hipLaunchKernelGGL(maxpool2_fwd_x8_kernel, dim3(grid_1d((int64_t)N * (H / 2) * (W / 2) * (C / 8), 256, 1 << 20)), dim3(256),
+                       0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
+    TG_CHECK_LAUNCH();
+  }
   dim3 grid(grid_1d((int64_t)N * (H / 2) * (W / 2) * C, 256));
   if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_fwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (float*)out, N, H, W, C);
   else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_fwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
@@ -386,6 +480,14 @@ extern "C" int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, 
 extern "C" int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W,
                                     int C, int act, float alpha, void* stream) {
   TG_CHECK_ARG(in && d_out && d_in && N > 0 && H > 1 && W > 1 && C > 0, "bad argument");
+  const bool x8 = dtype == TG_BF16 && C % 8 == 0 && ((((uintptr_t)in | (uintptr_t)d_out | (uintptr_t)d_in)) & 15) == 0 &&
+                  (int64_t)N * H * W * C < ((int64_t)1 << 31);
+  if (x8) {
+    hipLaunchKernelGGL(maxpool2_bwd_x8_kernel,
+                       dim3(grid_1d((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8), 256, 1 << 20)), dim3(256), 0,
+                       ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha);
+    TG_CHECK_LAUNCH();
+  }
   dim3 grid(grid_1d((int64_t)N * H * W * C, 256));
   if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (const float*)d_out, (float*)d_in, N, H, W, C, act, alpha);
   else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha);
@@ -425,6 +527,12 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
 extern "C" int tg_act_backward(const void* d_out, const void* y, void* d_in, int in_dtype, int out_dtype, int64_t n,
                                int act, float alpha, float scale, void* stream) {
   TG_CHECK_ARG(d_out && d_in && n > 0, "bad argument");
+  if (in_dtype == TG_BF16 && out_dtype == TG_BF16 && n % 8 == 0 &&
+      ((((uintptr_t)d_out | (uintptr_t)y | (uintptr_t)d_in)) & 15) == 0) {
+    hipLaunchKernelGGL(act_bwd_x8_kernel, dim3(grid_1d(n / 8, 256, 1 << 20)), dim3(256), 0, ST(stream), (const u16*)d_out,
+                       (const u16*)y, (u16*)d_in, n / 8, act, alpha, scale);
+    TG_CHECK_LAUNCH();
+  }
   dim3 grid(grid_1d(n, 256));
   if (in_dtype == TG_F32 && out_dtype == TG_F32) hipLaunchKernelGGL((act_bwd_kernel<float, float>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (const float*)y, (float*)d_in, n, act, alpha, scale);
   else if (in_dtype == TG_F32 && out_dtype == TG_BF16) hipLaunchKernelGGL((act_bwd_kernel<float, u16>), grid, dim3(256), 0, ST(stream), (const float*)d_out, (const float*)y, (u16*)d_in, n, act, alpha, scale);

@@ -396,6 +396,32 @@ def test_act_backward_and_reductions():
     close(out[1], (a - b).abs().sum() * 2.0, 1e-5, "sum abs")
 
 
+@pytest.mark.parametrize("C", [64, 128, 256, 512, 48])
+def test_cosine_loss_bf16_vectorised_and_scalar(C):
+    """VGG cosine loss (reference lib/Teco.py:15-23): C in {64..512} takes the 16-byte kernel, 48 the scalar one."""
+    npix = 37
+    g = (rnd(npix, C, seed=1) + 0.3).bfloat16().float().requires_grad_()
+    t = (rnd(npix, C, seed=2) + 0.3).bfloat16().float()
+    gh = g / torch.sqrt((g * g).sum(-1, keepdim=True) + 1e-12)
+    th = t / torch.sqrt((t * t).sum(-1, keepdim=True) + 1e-12)
+    cos = (gh * th).sum(-1).sum()
+    (cos * 0.7).backward()
+    out = torch.zeros(1, device=DEV)
+    dg = torch.empty(npix, C, device=DEV, dtype=torch.bfloat16)
+    K.cosine_loss(g.detach().to(DEV, torch.bfloat16), t.to(DEV, torch.bfloat16), 0.25, 0.7, out, dg)
+    close(out[0], cos.detach() * 0.25, 1e-4, "cosine sum C=%d" % C)
+    close(dg, g.grad, 1e-2, "cosine grad C=%d" % C)
+
+
+def test_act_backward_bf16_vectorised():
+    y, g = rnd(2, 9, 5, 64, seed=1).bfloat16().float(), rnd(2, 9, 5, 64, seed=2).bfloat16().float()
+    d = torch.empty(2, 9, 5, 64, device=DEV, dtype=torch.bfloat16)
+    K.act_backward(g.to(DEV, torch.bfloat16), y.to(DEV, torch.bfloat16), d, ACT_LRELU, 0.2, 0.5)
+    close(d, 0.5 * g * torch.where(y > 0, 1.0, 0.2), 1e-2, "lrelu bwd bf16 x8")
+    K.act_backward(g.to(DEV, torch.bfloat16), None, d, ACT_NONE, 0.0, 2.0)
+    close(d, 2.0 * g, 1e-2, "scale-only bf16 x8")
+
+
 def test_pack_weights():
     flat = rnd(9 * 8 * 16 + 16 * 4, seed=1).to(DEV)
     tab = torch.tensor([[0, 0, 9, 8, 16, 8, 16], [9 * 8 * 16, 9 * 8 * 16, 1, 16, 4, 16, 4]], dtype=torch.int64,
