@@ -302,13 +302,8 @@ struct WgradBP {
   int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
   int M, chunk, ytiles, ldx, ldy;
   unsigned xbytes, ybytes;             // buffer extents for the bounds-checked loads
-  unsigned long long magicW, magicH;   // ceil(2^32 / Wy), ceil(2^32 / Hy): exact division for m * d < 2^32
 };
 
-// PF = depth of the register prefetch ring (TG_WGRAD_PF).  Once the loads became buffer loads (no select behind
-// them, see below) the one-step prefetch really overlaps the MFMA block and PF = 1 measured equal or better than
-// PF = 4 at 3 of 5 shapes (tools/mb_wgrad.py); the deeper ring stays available as an A/B switch.
-template <int PF>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
   constexpr int ROWB = 136;                       // bytes per channel row: 64 pixels * 2 B + 8 pad
   __shared__ __attribute__((aligned(16))) unsigned char Xt[64 * ROWB];
@@ -341,6 +336,30 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
   const int strd = stage_x ? p.s : 1, offy = stage_x ? kh - p.pt : 0, offx = stage_x ? kw - p.pl : 0;
   const int cbase = (stage_x ? cx0 : cy0) + oct * 8;
   const bool cok = cbase < lds;
+  // Incremental addressing: the K loop advances every thread's pixel by 64; (ix, iy, byte offset) follow with adds and
+  // two conditional corrections (column carry, image wrap).  The first version recomputed n/oy/ox per load with
+  // magic-number divisions: 44 quarter-rate integer multiplies per step made the loop VALU-bound (~1000 cycles of
+  // address math against 128 cycles of MFMA).
+  const int WyS = p.Wy * strd, HyS = p.Hy * strd;
+  const int ixLim = WyS + offx, iyLim = HyS + offy;
+  const int q64 = 64 / p.Wy, r64 = 64 - q64 * p.Wy, qH = q64 / p.Hy, rH = q64 - qH * p.Hy;
+  const int dxs = r64 * strd, dys = rH * strd;
+  const unsigned K0 = (unsigned)((dxs + dys * Ws + qH * Hs * Ws) * lds * 2);
+  const unsigned K1 = (unsigned)((strd * Ws - WyS) * lds * 2);           // column carry: ox -= Wy, oy += 1
+  const unsigned K2 = (unsigned)((Hs * Ws - HyS * Ws) * lds * 2);        // image wrap:   oy -= Hy, n += 1
+  const unsigned qstep = (unsigned)(strd * lds * 2);                      // pixel m+1 (same row: m and Wy are even)
+  int sm[2], six[2], siy[2];
+  unsigned soff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int m = mbeg + (pp0 + h * 16) * 2;
+    const int t = m / p.Wy, ox = m - t * p.Wy;
+    const int n = t / p.Hy, oy = t - n * p.Hy;
+    sm[h] = m;
+    six[h] = ox * strd + offx;
+    siy[h] = oy * strd + offy;
+    soff[h] = (unsigned)(((n * Hs + siy[h]) * Ws + six[h]) * lds + cbase) * 2u;
+  }
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -349,36 +368,37 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  uint4 v[PF][2][2];
-  auto load_block = [&](uint4 (&dst)[2][2], int mb) {   // unconditional loads (clamped address) + select
+  uint4 v[2][2];
+  auto load_block = [&]() {            // issues the 4 loads of the current state, then advances the state by 64 pixels
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int m_raw = mb + (pp0 + h * 16) * 2 + q;
-        const int m = min(m_raw, mend - 1);
-        const int t = (int)(((unsigned long long)(unsigned)m * p.magicW) >> 32), ox = m - t * p.Wy;
-        const int n = (int)(((unsigned long long)(unsigned)t * p.magicH) >> 32), oy = t - n * p.Hy;
-        const int iy = oy * strd + offy, ix = ox * strd + offx;
-        const bool ok = m_raw < mend && cok && (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
-        const unsigned boff = ok ? (unsigned)(((n * Hs + iy) * Ws + ix) * lds + cbase) * 2u : 0x80000000u;
-        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)boff, 0, 0);
-        dst[h][q] = make_uint4(t4.x, t4.y, t4.z, t4.w);
-      }
+      const bool rowok = cok & ((unsigned)siy[h] < (unsigned)Hs);
+      const bool ok0 = rowok & (sm[h] < mend) & ((unsigned)six[h] < (unsigned)Ws);
+      const bool ok1 = rowok & (sm[h] + 1 < mend) & ((unsigned)(six[h] + strd) < (unsigned)Ws);
+      const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok0 ? soff[h] : 0x80000000u), 0, 0);
+      const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok1 ? soff[h] + qstep : 0x80000000u), 0, 0);
+      v[h][0] = make_uint4(t0.x, t0.y, t0.z, t0.w);
+      v[h][1] = make_uint4(t1.x, t1.y, t1.z, t1.w);
+      sm[h] += 64;
+      six[h] += dxs;
+      siy[h] += dys;
+      soff[h] += K0;
+      const bool c = six[h] >= ixLim;
+      six[h] -= c ? WyS : 0;
+      siy[h] += c ? strd : 0;
+      soff[h] += c ? K1 : 0u;
+      const bool w = siy[h] >= iyLim;
+      siy[h] -= w ? HyS : 0;
+      soff[h] += w ? K2 : 0u;
     }
   };
-#pragma unroll
-  for (int d = 0; d < PF; ++d) load_block(v[d], mbeg + 64 * d);
-  for (int mb0 = mbeg; mb0 < mend; mb0 += 64 * PF) {
-#pragma unroll
-   for (int d = 0; d < PF; ++d) {
-    const int mb = mb0 + 64 * d;    // no early exit: the host makes `chunk` a multiple of 64*PF and steps past the
-                                    // end run on zeros, so the ring's load/wait pattern is one straight line
+  load_block();
+  for (int mb = mbeg; mb < mend; mb += 64) {
     unsigned char* panel = stage_x ? Xt : Yt;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[d][h][0]);   // pixel 2pp   : channels 8*oct .. +7
-      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[d][h][1]);   // pixel 2pp+1
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[h][0]);   // pixel 2pp   : channels 8*oct .. +7
+      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[h][1]);   // pixel 2pp+1
       const int pp = pp0 + h * 16;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -390,8 +410,8 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       }
     }
     __syncthreads();
-    load_block(v[d], mb + 64 * PF);    // refill this ring slot, unconditionally (lanes past the end fetch nothing):
-                                       // a fixed number of loads in flight lets hipcc count vmcnt exactly
+    load_block();                      // next step, unconditionally (lanes past the end fetch nothing): in flight
+                                       // during the MFMAs below, and one straight-line block for hipcc's vmcnt counts
     if (do_bias && tid < 64) {
       const uint32_t* row = reinterpret_cast<const uint32_t*>(Yt + tid * ROWB);
 #pragma unroll 8
@@ -421,7 +441,6 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfm[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
-   }
   }
   float* __restrict__ dw = p.dw + (int64_t)tap * p.Cx * p.Cy;
 #pragma unroll
@@ -449,14 +468,11 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
   p.M = d->N * d->Hout * d->Wout; p.ldx = ldx; p.ldy = ldy;
   const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
-  const int dmax = d->Hout > d->Wout ? d->Hout : d->Wout;
-  if (M64 * dmax >= ((int64_t)1 << 32) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
-      M64 * ldy >= ((int64_t)1 << 30))
-    return 0;                                        // 32-bit offsets / magic division out of range: generic kernel
+  if (M64 >= ((int64_t)1 << 30) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
+      M64 * ldy >= ((int64_t)1 << 30) || (d->Wout & 1))
+    return 0;                           // 32-bit byte offsets out of range, or odd width (pixel pairs): generic kernel
   p.xbytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * ldx * 2);
   p.ybytes = (unsigned)(M64 * ldy * 2);
-  p.magicW = (((unsigned long long)1 << 32) + d->Wout - 1) / d->Wout;
-  p.magicH = (((unsigned long long)1 << 32) + d->Hout - 1) / d->Hout;
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
@@ -468,14 +484,8 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   const int max_split = (p.M + 127) / 128;
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
-  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 1;               // A/B switch
-  const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);
-  const int quantum = 64 * pf;
-  p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
+  p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
-  const dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
-  if (pf <= 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, p);
-  else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(d->KH * d->KW, xtiles * p.ytiles, ksplit), dim3(256), 0, st, p);
   return 1;
 }

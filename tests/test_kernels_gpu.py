@@ -437,7 +437,11 @@ def test_pack_weights():
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 3, 1), (1, 9, 11, 32, 128, 4, 2), (3, 7, 5, 128, 64, 3, 1),
-                                  (40, 32, 32, 64, 64, 3, 1), (2, 16, 16, 256, 8, 1, 1)])
+                                  (40, 32, 32, 64, 64, 3, 1), (2, 16, 16, 256, 8, 1, 1),
+                                  # incremental addressing: several images per 64-pixel step, ragged carries, rows wider
+                                  # than a step, strided output with ragged extents
+                                  (21, 4, 4, 64, 64, 3, 1), (3, 6, 20, 64, 32, 3, 1), (2, 3, 70, 32, 64, 3, 1),
+                                  (3, 5, 12, 64, 64, 4, 2), (5, 2, 2, 64, 64, 3, 1), (2, 10, 6, 8, 64, 3, 1)])
 def test_wgrad_bf16_mfma_path(case):
     """bf16-MFMA weight gradient (transposed LDS staging) vs autograd on the same bf16-rounded operands."""
     N, H, W, Cin, Cout, k, s = case
