@@ -302,6 +302,7 @@ struct WgradBP {
   int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
   int M, chunk, ytiles, ldx, ldy;
   unsigned xbytes, ybytes;             // buffer extents for the bounds-checked loads
+  int abl;                             // TG_WGRAD_ABL ablation bits (profiling only; 0 in the product)
 };
 
 __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
@@ -366,7 +367,13 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  // bias gradient (column sums of Y): the Y-staging threads of the tap-0 workgroups add up the 8 channels x 4 pixels
+  // they hold in registers anyway.  (Summing the staged LDS rows instead -- 32 dependent reads per step in one wave --
+  // put ~1000 cycles per step on the critical path of those workgroups: 5 of 22 us at the generator shape.)
+  const bool bias_thread = do_bias && !stage_x;
+  float bsum[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
 
   uint4 v[2][2];
   auto load_block = [&]() {            // issues the 4 loads of the current state, then advances the state by 64 pixels
@@ -395,6 +402,20 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
   load_block();
   for (int mb = mbeg; mb < mend; mb += 64) {
     unsigned char* panel = stage_x ? Xt : Yt;
+    if (bias_thread) {                 // wave-uniform branch
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t w4[4] = {v[h][q].x, v[h][q].y, v[h][q].z, v[h][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bsum[2 * e] += __uint_as_float(w4[e] << 16);
+            bsum[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+          }
+        }
+    }
+    if (!(p.abl & 8))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[h][0]);   // pixel 2pp   : channels 8*oct .. +7
@@ -410,13 +431,9 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       }
     }
     __syncthreads();
-    load_block();                      // next step, unconditionally (lanes past the end fetch nothing): in flight
+    if (!(p.abl & 16)) load_block();   // next step, unconditionally (lanes past the end fetch nothing): in flight
                                        // during the MFMAs below, and one straight-line block for hipcc's vmcnt counts
-    if (do_bias && tid < 64) {
-      const uint32_t* row = reinterpret_cast<const uint32_t*>(Yt + tid * ROWB);
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) bsum += __uint_as_float(row[k] << 16) + __uint_as_float(row[k] & 0xffff0000u);
-    }
+    if (!(p.abl & 4))
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {                 // 2 x 32 pixels
       bf16x8 af[2], bfm[2];
@@ -451,9 +468,21 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       for (int r = 0; r < 4; ++r) {
         const int cx = cx0 + wm * 32 + i * 16 + fg * 4 + r;
         const int cy = cy0 + wn * 32 + j * 16 + frow;
-        if (cx < p.Cx && cy < p.Cy) unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[i][j][r]);
+        if (cx < p.Cx && cy < p.Cy) {
+          if (p.abl == 1) asm volatile("" ::"v"(acc[i][j][r]));                    // profiling only: no output
+          else if (p.abl == 2) dw[(int64_t)cx * p.Cy + cy] = acc[i][j][r];           // profiling only: plain stores
+          else unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[i][j][r]);
+        }
       }
-  if (do_bias && tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, bsum);
+  if (bias_thread) {                   // 16 lanes (pixel pairs) share a channel octet: xor-reduce, lane pp0 == 0 adds
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) bsum[k] += __shfl_xor(bsum[k], o, 64);
+      const int cy = cy0 + oct * 8 + k;
+      if (pp0 == 0 && cy < p.Cy) unsafeAtomicAdd(p.dbias + cy, bsum[k]);
+    }
+  }
 }
 
 // returns 1 if launched
@@ -471,6 +500,8 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   if (M64 >= ((int64_t)1 << 30) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
       M64 * ldy >= ((int64_t)1 << 30) || (d->Wout & 1))
     return 0;                           // 32-bit byte offsets out of range, or odd width (pixel pairs): generic kernel
+  static const int abl = getenv("TG_WGRAD_ABL") ? atoi(getenv("TG_WGRAD_ABL")) : 0;
+  p.abl = abl;
   p.xbytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * ldx * 2);
   p.ybytes = (unsigned)(M64 * ldy * 2);
   const int xtiles = (p.Cx + 63) / 64;
