@@ -302,10 +302,13 @@ struct WgradBP {
   int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
   int M, chunk, ytiles, ldx, ldy;
   unsigned xbytes, ybytes;             // buffer extents for the bounds-checked loads
-  int abl;                             // TG_WGRAD_ABL ablation bits (profiling only; 0 in the product)
 };
 
-__global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
+// PF = depth of the register prefetch ring: PF K-steps of loads stay in flight (the MFMA block of one step is only
+// ~200 cycles, an L2 round trip 3-4x that).  The loop body is one straight line -- the host makes `chunk` a multiple of
+// 64*PF and steps past the end run on zeros (out-of-range lanes fetch nothing) -- so hipcc's vmcnt counts are exact.
+template <int PF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
   constexpr int ROWB = 136;                       // bytes per channel row: 64 pixels * 2 B + 8 pad
   __shared__ __attribute__((aligned(16))) unsigned char Xt[64 * ROWB];
   __shared__ __attribute__((aligned(16))) unsigned char Yt[64 * ROWB];
@@ -375,8 +378,8 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
 
-  uint4 v[2][2];
-  auto load_block = [&]() {            // issues the 4 loads of the current state, then advances the state by 64 pixels
+  uint4 v[PF][2][2];
+  auto load_block = [&](uint4 (&dst)[2][2]) {   // issues the 4 loads of the current state, then advances it by 64 pixels
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool rowok = cok & ((unsigned)siy[h] < (unsigned)Hs);
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       const bool ok1 = rowok & (sm[h] + 1 < mend) & ((unsigned)(six[h] + strd) < (unsigned)Ws);
       const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok0 ? soff[h] : 0x80000000u), 0, 0);
       const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok1 ? soff[h] + qstep : 0x80000000u), 0, 0);
-      v[h][0] = make_uint4(t0.x, t0.y, t0.z, t0.w);
-      v[h][1] = make_uint4(t1.x, t1.y, t1.z, t1.w);
+      dst[h][0] = make_uint4(t0.x, t0.y, t0.z, t0.w);
+      dst[h][1] = make_uint4(t1.x, t1.y, t1.z, t1.w);
       sm[h] += 64;
       six[h] += dxs;
       siy[h] += dys;
@@ -399,15 +402,18 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       soff[h] += w ? K2 : 0u;
     }
   };
-  load_block();
-  for (int mb = mbeg; mb < mend; mb += 64) {
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_block(v[d]);
+  for (int mb = mbeg; mb < mend; mb += 64 * PF) {
+#pragma unroll
+   for (int d = 0; d < PF; ++d) {
     unsigned char* panel = stage_x ? Xt : Yt;
     if (bias_thread) {                 // wave-uniform branch
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const uint32_t w4[4] = {v[h][q].x, v[h][q].y, v[h][q].z, v[h][q].w};
+          const uint32_t w4[4] = {v[d][h][q].x, v[d][h][q].y, v[d][h][q].z, v[d][h][q].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             bsum[2 * e] += __uint_as_float(w4[e] << 16);
@@ -415,11 +421,10 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
           }
         }
     }
-    if (!(p.abl & 8))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[h][0]);   // pixel 2pp   : channels 8*oct .. +7
-      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[h][1]);   // pixel 2pp+1
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[d][h][0]);   // pixel 2pp   : channels 8*oct .. +7
+      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[d][h][1]);   // pixel 2pp+1
       const int pp = pp0 + h * 16;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -431,9 +436,8 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       }
     }
     __syncthreads();
-    if (!(p.abl & 16)) load_block();   // next step, unconditionally (lanes past the end fetch nothing): in flight
+    load_block(v[d]);                  // refill this ring slot, unconditionally (lanes past the end fetch nothing): in flight
                                        // during the MFMAs below, and one straight-line block for hipcc's vmcnt counts
-    if (!(p.abl & 4))
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {                 // 2 x 32 pixels
       bf16x8 af[2], bfm[2];
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfm[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+   }
   }
   float* __restrict__ dw = p.dw + (int64_t)tap * p.Cx * p.Cy;
 #pragma unroll
@@ -468,20 +473,23 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_bf16_kernel(WgradBP p) {
       for (int r = 0; r < 4; ++r) {
         const int cx = cx0 + wm * 32 + i * 16 + fg * 4 + r;
         const int cy = cy0 + wn * 32 + j * 16 + frow;
-        if (cx < p.Cx && cy < p.Cy) {
-          if (p.abl == 1) asm volatile("" ::"v"(acc[i][j][r]));                    // profiling only: no output
-          else if (p.abl == 2) dw[(int64_t)cx * p.Cy + cy] = acc[i][j][r];           // profiling only: plain stores
-          else unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[i][j][r]);
-        }
+        if (cx < p.Cx && cy < p.Cy) unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[i][j][r]);
       }
-  if (bias_thread) {                   // 16 lanes (pixel pairs) share a channel octet: xor-reduce, lane pp0 == 0 adds
+  if (do_bias) {                       // workgroup-uniform
+    // 16 lanes (pixel pairs) share a channel octet: xor-reduce, gather the 64 sums in LDS and let ONE instruction add
+    // them (64 consecutive addresses).  Per-octet atomics from 16 separate instructions per workgroup serialised on the
+    // four cache lines every bias workgroup hits: +7 us at the generator shape.
+    float* red = reinterpret_cast<float*>(Xt);       // the panels are idle after the loop's final barrier
+    if (bias_thread) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 8; ++k) {
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) bsum[k] += __shfl_xor(bsum[k], o, 64);
-      const int cy = cy0 + oct * 8 + k;
-      if (pp0 == 0 && cy < p.Cy) unsafeAtomicAdd(p.dbias + cy, bsum[k]);
+        for (int o = 8; o > 0; o >>= 1) bsum[k] += __shfl_xor(bsum[k], o, 64);
+        if (pp0 == 0) red[oct * 8 + k] = bsum[k];
+      }
     }
+    __syncthreads();
+    if (tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, red[tid]);
   }
 }
 
@@ -500,8 +508,6 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   if (M64 >= ((int64_t)1 << 30) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
       M64 * ldy >= ((int64_t)1 << 30) || (d->Wout & 1))
     return 0;                           // 32-bit byte offsets out of range, or odd width (pixel pairs): generic kernel
-  static const int abl = getenv("TG_WGRAD_ABL") ? atoi(getenv("TG_WGRAD_ABL")) : 0;
-  p.abl = abl;
   p.xbytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * ldx * 2);
   p.ybytes = (unsigned)(M64 * ldy * 2);
   const int xtiles = (p.Cx + 63) / 64;
@@ -515,8 +521,14 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   const int max_split = (p.M + 127) / 128;
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
-  p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
+  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 4;               // A/B switch
+  const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);
+  const int quantum = 64 * pf;
+  p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
-  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(d->KH * d->KW, xtiles * p.ytiles, ksplit), dim3(256), 0, st, p);
+  const dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
+  if (pf == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, p);
+  else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), 0, st, p);
   return 1;
 }
