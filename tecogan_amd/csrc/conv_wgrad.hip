@@ -300,7 +300,7 @@ struct WgradBP {
   float* dw;
   float* dbias;
   int N, Hx, Wx, Cx, Hy, Wy, Cy, KH, KW, s, pt, pl;
-  int M, chunk, ytiles, ldx, ldy;
+  int M, chunk, xtiles, ytiles, ldx, ldy;
   unsigned xbytes, ybytes;             // buffer extents for the bounds-checked loads
 };
 
@@ -314,10 +314,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
   __shared__ __attribute__((aligned(16))) unsigned char Yt[64 * ROWB];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tap = blockIdx.x, kh = tap / p.KW, kw = tap % p.KW;
-  const int xt = blockIdx.y / p.ytiles, yt = blockIdx.y % p.ytiles;
+  // XCD-aware work mapping.  Workgroup b runs on XCD b % 8, each XCD has its own L2, and the KH*KW taps (and channel
+  // tiles) of one pixel chunk all read the same X / Y rows.  With the natural (tap, tile, chunk) grid the taps of a
+  // chunk were sprayed over all 8 XCDs, so every L2 pulled the whole of X and Y through the fabric (8x the traffic:
+  // ~84 MB per launch at the generator shape, which is what bounded the kernel at ~20 us).  Bijective remap: XCD x owns a
+  // contiguous range of work items, a work item = (chunk, tile, tap) with tap fastest.
+  const int nwg = gridDim.x, L = blockIdx.x;
+  const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int per_chunk = p.KH * p.KW * p.xtiles * p.ytiles;
+  const int zc = work / per_chunk, rem = work - zc * per_chunk;
+  const int ntap = p.KH * p.KW, tile = rem / ntap, tap = rem - tile * ntap;
+  const int kh = tap / p.KW, kw = tap % p.KW;
+  const int xt = tile / p.ytiles, yt = tile % p.ytiles;
   const int cx0 = xt * 64, cy0 = yt * 64;
-  const int mbeg = blockIdx.z * p.chunk, mend = min(mbeg + p.chunk, p.M);
+  const int mbeg = zc * p.chunk, mend = min(mbeg + p.chunk, p.M);
   const bool do_bias = p.dbias != nullptr && tap == 0 && xt == 0;
   const int frow = lane & 15, fg = lane >> 4;
   // staging role: threads 0..127 -> X, 128..255 -> Y; item = (pixel pair 0..31, channel octet 0..7)... 256 items each,
@@ -512,6 +523,7 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.ybytes = (unsigned)(M64 * ldy * 2);
   const int xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
+  p.xtiles = xtiles;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
   // workgroup target, measured (tools/mb_wgrad.py, 256/512/1024 swept): 512 for the full 64x64-channel tiles of the
   // LR generator layers, 1024 elsewhere (narrow tiles and the large HR / D layers)
@@ -526,7 +538,7 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   const int quantum = 64 * pf;
   p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
-  const dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
+  const dim3 grid((unsigned)(d->KH * d->KW * xtiles * p.ytiles * ksplit));   // 1-D: the kernel maps work XCD-aware
   if (pf == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, p);
   else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), 0, st, p);
