@@ -304,6 +304,21 @@ struct WgradBP {
   unsigned xbytes, ybytes;             // buffer extents for the bounds-checked loads
 };
 
+// Cycle-stamp instrumentation (tools/trace_wgrad.py builds a private copy of the library with -DTG_WGRAD_TRACE; the
+// product build contains none of it): wave 0 of one mid-grid workgroup records s_memtime at the phase boundaries.
+#ifdef TG_WGRAD_TRACE
+__device__ unsigned long long tg_wgrad_trace_buf[64];
+#define TG_STAMP(i)                                                                  \
+  do {                                                                               \
+    if (trace_on && (i) < 64) tg_wgrad_trace_buf[(i)] = (unsigned long long)clock64(); \
+  } while (0)
+extern "C" int tg_debug_wgrad_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_wgrad_trace_buf), sizeof(unsigned long long) * 64);
+}
+#else
+#define TG_STAMP(i) do { } while (0)
+#endif
+
 // PF = depth of the register prefetch ring: PF K-steps of loads stay in flight (the MFMA block of one step is only
 // ~200 cycles, an L2 round trip 3-4x that).  The loop body is one straight line -- the host makes `chunk` a multiple of
 // 64*PF and steps past the end run on zeros (out-of-range lanes fetch nothing) -- so hipcc's vmcnt counts are exact.
@@ -322,6 +337,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
   const int nwg = gridDim.x, L = blockIdx.x;
   const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
   const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+#ifdef TG_WGRAD_TRACE
+  const bool trace_on = work == (nwg / 2) && threadIdx.x == 0;
+  int stamp = 3;
+#endif
+  TG_STAMP(0);
   const int per_chunk = p.KH * p.KW * p.xtiles * p.ytiles;
   const int zc = work / per_chunk, rem = work - zc * per_chunk;
   const int ntap = p.KH * p.KW, tile = rem / ntap, tap = rem - tile * ntap;
@@ -413,12 +433,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
       soff[h] += w ? K2 : 0u;
     }
   };
+  TG_STAMP(1);
 #pragma unroll
   for (int d = 0; d < PF; ++d) load_block(v[d]);
+  TG_STAMP(2);
   for (int mb = mbeg; mb < mend; mb += 64 * PF) {
 #pragma unroll
    for (int d = 0; d < PF; ++d) {
     unsigned char* panel = stage_x ? Xt : Yt;
+#ifdef TG_WGRAD_TRACE
+    TG_STAMP(stamp); ++stamp;          // step top
+#endif
     if (bias_thread) {                 // wave-uniform branch
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -446,7 +471,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
         *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e + 1) * ROWB + pp * 4) = c1;
       }
     }
+#ifdef TG_WGRAD_TRACE
+    TG_STAMP(stamp); ++stamp;          // data arrived + staged
+#endif
     __syncthreads();
+#ifdef TG_WGRAD_TRACE
+    TG_STAMP(stamp); ++stamp;          // barrier passed
+#endif
     load_block(v[d]);                  // refill this ring slot, unconditionally (lanes past the end fetch nothing): in flight
                                        // during the MFMAs below, and one straight-line block for hipcc's vmcnt counts
 #pragma unroll
@@ -472,9 +503,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfm[j], acc[i][j], 0, 0, 0);
     }
+#ifdef TG_WGRAD_TRACE
+    TG_STAMP(stamp); ++stamp;          // MFMAs issued
+#endif
     __syncthreads();
    }
   }
+#ifdef TG_WGRAD_TRACE
+  TG_STAMP(60);
+#endif
   float* __restrict__ dw = p.dw + (int64_t)tap * p.Cx * p.Cy;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -502,6 +539,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
     __syncthreads();
     if (tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, red[tid]);
   }
+#ifdef TG_WGRAD_TRACE
+  __builtin_amdgcn_s_waitcnt(0);       // atomics retired (vmcnt/lgkmcnt/expcnt = 0)
+  TG_STAMP(61);
+#endif
 }
 
 // returns 1 if launched
