@@ -319,14 +319,17 @@ extern "C" int tg_debug_wgrad_trace(unsigned long long* out) {
 #define TG_STAMP(i) do { } while (0)
 #endif
 
-// PF = depth of the register prefetch ring: PF K-steps of loads stay in flight (the MFMA block of one step is only
-// ~200 cycles, an L2 round trip 3-4x that).  The loop body is one straight line -- the host makes `chunk` a multiple of
-// 64*PF and steps past the end run on zeros (out-of-range lanes fetch nothing) -- so hipcc's vmcnt counts are exact.
+// PF = 64-pixel slots per macro-step: one barrier pair covers 64*PF pixels.  A cycle-stamp trace (tools/trace_wgrad.py)
+// of the 64-pixel version showed ~1700 cycles per step around 128 cycles of MFMA at the 1-2 waves per SIMD these
+// launches run at: the stage -> barrier -> fragment reads -> MFMA -> barrier chain is pure exposed latency, so the fix is
+// more pixels per trip through it (and 4*PF loads in flight across the MFMA block).  The host makes `chunk` a multiple of
+// 64*PF; slots past the end run on zeros (out-of-range lanes fetch nothing).
 template <int PF>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
-  constexpr int ROWB = 136;                       // bytes per channel row: 64 pixels * 2 B + 8 pad
-  __shared__ __attribute__((aligned(16))) unsigned char Xt[64 * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char Yt[64 * ROWB];
+  constexpr int ROWB = 128 * PF + 8;             // bytes per channel row: 64*PF pixels * 2 B + 8 pad
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+  unsigned char* Xt = wg_smem;                    // [64 channels][ROWB]
+  unsigned char* Yt = wg_smem + 64 * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware work mapping.  Workgroup b runs on XCD b % 8, each XCD has its own L2, and the KH*KW taps (and channel
@@ -437,40 +440,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
 #pragma unroll
   for (int d = 0; d < PF; ++d) load_block(v[d]);
   TG_STAMP(2);
+  unsigned char* panel = stage_x ? Xt : Yt;
   for (int mb = mbeg; mb < mend; mb += 64 * PF) {
-#pragma unroll
-   for (int d = 0; d < PF; ++d) {
-    unsigned char* panel = stage_x ? Xt : Yt;
 #ifdef TG_WGRAD_TRACE
-    TG_STAMP(stamp); ++stamp;          // step top
+    TG_STAMP(stamp); ++stamp;          // macro-step top
 #endif
     if (bias_thread) {                 // wave-uniform branch
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int d = 0; d < PF; ++d)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const uint32_t w4[4] = {v[d][h][q].x, v[d][h][q].y, v[d][h][q].z, v[d][h][q].w};
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            bsum[2 * e] += __uint_as_float(w4[e] << 16);
-            bsum[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t w4[4] = {v[d][h][q].x, v[d][h][q].y, v[d][h][q].z, v[d][h][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              bsum[2 * e] += __uint_as_float(w4[e] << 16);
+              bsum[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+            }
           }
+    }
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[d][h][0]);   // pixel 2pp   : channels 8*oct .. +7
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[d][h][1]);   // pixel 2pp+1
+        const int pp = pp0 + h * 16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // channels 2e, 2e+1 of the octet: {lo = pixel 2pp, hi = pixel 2pp+1}
+          const uint32_t c0 = (a[e] & 0xffffu) | (b[e] << 16);
+          const uint32_t c1 = (a[e] >> 16) | (b[e] & 0xffff0000u);
+          *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e) * ROWB + d * 128 + pp * 4) = c0;
+          *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e + 1) * ROWB + d * 128 + pp * 4) = c1;
         }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t* a = reinterpret_cast<const uint32_t*>(&v[d][h][0]);   // pixel 2pp   : channels 8*oct .. +7
-      const uint32_t* b = reinterpret_cast<const uint32_t*>(&v[d][h][1]);   // pixel 2pp+1
-      const int pp = pp0 + h * 16;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // channels 2e, 2e+1 of the octet: {lo = pixel 2pp, hi = pixel 2pp+1}
-        const uint32_t c0 = (a[e] & 0xffffu) | (b[e] << 16);
-        const uint32_t c1 = (a[e] >> 16) | (b[e] & 0xffff0000u);
-        *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e) * ROWB + pp * 4) = c0;
-        *reinterpret_cast<uint32_t*>(panel + (oct * 8 + 2 * e + 1) * ROWB + pp * 4) = c1;
       }
-    }
 #ifdef TG_WGRAD_TRACE
     TG_STAMP(stamp); ++stamp;          // data arrived + staged
 #endif
@@ -478,10 +483,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
 #ifdef TG_WGRAD_TRACE
     TG_STAMP(stamp); ++stamp;          // barrier passed
 #endif
-    load_block(v[d]);                  // refill this ring slot, unconditionally (lanes past the end fetch nothing): in flight
-                                       // during the MFMAs below, and one straight-line block for hipcc's vmcnt counts
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {                 // 2 x 32 pixels
+    for (int d = 0; d < PF; ++d) load_block(v[d]);   // next macro-step, unconditionally (lanes past the end fetch
+                                                     // nothing): 4*PF loads in flight across the MFMA block below
+#pragma unroll
+    for (int kk = 0; kk < 2 * PF; ++kk) {            // 2*PF x 32 pixels
       bf16x8 af[2], bfm[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -507,7 +513,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
     TG_STAMP(stamp); ++stamp;          // MFMAs issued
 #endif
     __syncthreads();
-   }
   }
 #ifdef TG_WGRAD_TRACE
   TG_STAMP(60);
@@ -580,8 +585,15 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   const dim3 grid((unsigned)(d->KH * d->KW * xtiles * p.ytiles * ksplit));   // 1-D: the kernel maps work XCD-aware
-  if (pf == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, p);
-  else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), 0, st, p);
+  const unsigned lds = 2u * 64u * (128u * pf + 8u);
+  static bool attr_set = false;
+  if (!attr_set) {                                                    // PF = 4 needs 66.5 KB of dynamic LDS
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 4 + 8));
+    attr_set = true;
+  }
+  if (pf == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), lds, st, p);
+  else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), lds, st, p);
   return 1;
 }
