@@ -550,12 +550,211 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row kernel: stride-1 convolutions with 3 horizontal taps and SAME width (every 3x3 layer of generator_F, FNet and the
+// D input conv).  One workgroup accumulates the THREE kw taps of one kernel row kh for a 64x64 channel tile:
+//   * the Y^T panel is staged once and its fragments feed 3x the MFMAs;
+//   * the three shifted X pixel pairs {(x-1,x), (x,x+1), (x+1,x+2)} come from FOUR 16-byte loads of one input row;
+//   * with stride 1 and equal extents the input offset is linear in the output pixel index, so the per-step address
+//     update is one add (plus the (ox, iy) bookkeeping for the zero padding).
+// The cycle-stamp trace of the per-tap kernel (tools/trace_wgrad.py) showed ~1300 issue cycles of staging / address /
+// fragment-read instructions around 128 cycles of MFMA per 64-pixel step at the 1-2 waves per SIMD these launches get:
+// the loop is instruction-issue bound, so the lever is MFMAs per staged byte.  Here: 24 MFMAs per step for about the same
+// instruction count.  Panels are [64 channels][64 pixels] with a 144-byte pitch: conflict-free transposing writes for
+// the (32 pixel pairs x 2 octets) a wave writes per instruction, and 16-byte aligned rows -> one ds_read_b128 per fragment.
+struct WgradRP {
+  const u16* x;
+  const u16* y;
+  float* dw;
+  float* dbias;
+  int N, H, W, Cx, Cy, KH, pt;
+  int M, chunk, xtiles, ytiles, ldx, ldy;
+  unsigned xbytes, ybytes;
+};
+
+__device__ __forceinline__ void tg_interleave_store(const u32x4& a, const u32x4& b, unsigned char* dst) {
+  // a = 8 channels of pixel 2pp, b = of pixel 2pp+1; row c gets {lo = a[c], hi = b[c]} (one v_perm_b32 per dword)
+  const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    *reinterpret_cast<unsigned*>(dst + (2 * e) * 144) = __builtin_amdgcn_perm(bv[e], av[e], 0x05040100u);
+    *reinterpret_cast<unsigned*>(dst + (2 * e + 1) * 144) = __builtin_amdgcn_perm(bv[e], av[e], 0x07060302u);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p) {
+  constexpr int ROWB = 144, PANEL = 64 * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * PANEL];   // X(kw=0), X(kw=1), X(kw=2), Y
+  unsigned char* Yt = smem + 3 * PANEL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+  // XCD-aware work mapping (see conv_wgrad_bf16_kernel): work item = (chunk, channel tile, kh), kh fastest
+  const int nwg = gridDim.x, L = blockIdx.x;
+  const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int per_chunk = p.KH * p.xtiles * p.ytiles;
+  const int zc = work / per_chunk, rem = work - zc * per_chunk;
+  const int tile = rem / p.KH, kh = rem - tile * p.KH;
+  const int xt = tile / p.ytiles, yt = tile - xt * p.ytiles;
+  const int cx0 = xt * 64, cy0 = yt * 64;
+  const int mbeg = zc * p.chunk, mend = min(mbeg + p.chunk, p.M);
+  const bool do_bias = p.dbias != nullptr && kh == 0 && xt == 0;
+
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x), 0, (int)p.xbytes, 0x00020000);
+  const auto rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.y), 0, (int)p.ybytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // staging item of this thread: pixel pair pp (pixels 2pp, 2pp+1 of the 64-pixel step) x channel octet oct, for X and Y
+  const int pp = tid & 31, oct = tid >> 5;
+  const bool cxok = cx0 + oct * 8 < p.ldx, cyok = cy0 + oct * 8 < p.ldy;
+  int m = mbeg + 2 * pp;                                    // output pixel of the pair (even; W is even)
+  int ox, iy;                                               // output column, input row of this kernel row
+  {
+    const int t = m / p.W;
+    ox = m - t * p.W;
+    iy = t % p.H + kh - p.pt;
+  }
+  // stride 1, equal extents: the input pixel of (output pixel m, tap kh, kw) is m + (kh-pt)*W + (kw-1), linear in m
+  unsigned offx = (unsigned)(((m + (kh - p.pt) * p.W) * p.ldx + cx0 + oct * 8) * 2);
+  unsigned offy = (unsigned)((m * p.ldy + cy0 + oct * 8) * 2);
+  const unsigned pixb = (unsigned)(p.ldx * 2), stepx = 64u * pixb, stepy = (unsigned)(64 * p.ldy * 2);
+  const int q64 = 64 / p.W, r64 = 64 - q64 * p.W, rH = q64 % p.H;
+  const int iyLim = p.H + kh - p.pt;
+
+  u32x4 rx[4], ry[2];
+  auto load_step = [&]() {             // 6 loads for the current state, then advance the state by 64 pixels
+    const bool rowok = cxok & ((unsigned)iy < (unsigned)p.H);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = rowok & ((unsigned)(ox - 1 + j) < (unsigned)p.W);
+      rx[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(ok ? offx + (unsigned)(j - 1) * pixb : OOB), 0, 0);
+    }
+    // pixels past the chunk contribute nothing because their Y is zero (X stays finite: in-image data or zeros)
+    ry[0] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (int)((cyok & (m < mend)) ? offy : OOB), 0, 0);
+    ry[1] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (int)((cyok & (m + 1 < mend)) ? offy + (unsigned)(p.ldy * 2) : OOB), 0, 0);
+    m += 64;
+    offx += stepx;
+    offy += stepy;
+    ox += r64;
+    const bool c = ox >= p.W;
+    ox -= c ? p.W : 0;
+    iy += rH + (c ? 1 : 0);
+    iy -= iy >= iyLim ? p.H : 0;
+  };
+
+  f32x4 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
+
+  unsigned char* wbase = smem + (oct * 8) * ROWB + pp * 4;
+  const unsigned char* Abase = smem + (wm * 32 + frow) * ROWB + fg * 16;
+  const unsigned char* Bbase = Yt + (wn * 32 + frow) * ROWB + fg * 16;
+
+  load_step();
+  for (int mb = mbeg; mb < mend; mb += 64) {
+    if (do_bias) {                     // workgroup-uniform
+      const unsigned w0[4] = {ry[0].x, ry[0].y, ry[0].z, ry[0].w}, w1[4] = {ry[1].x, ry[1].y, ry[1].z, ry[1].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bsum[2 * e] += __uint_as_float(w0[e] << 16) + __uint_as_float(w1[e] << 16);
+        bsum[2 * e + 1] += __uint_as_float(w0[e] & 0xffff0000u) + __uint_as_float(w1[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) tg_interleave_store(rx[t], rx[t + 1], wbase + t * PANEL);
+    tg_interleave_store(ry[0], ry[1], wbase + 3 * PANEL);
+    __syncthreads();
+    load_step();                       // next step (lanes past the end fetch nothing): in flight across the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 bf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bbase + j * 16 * ROWB + kk * 64);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        uint4 af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const uint4*>(Abase + t * PANEL + i * 16 * ROWB + kk * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[i]),
+                                                                   *reinterpret_cast<bf16x8*>(&bf[j]), acc[t][i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* __restrict__ dw = p.dw + (int64_t)(kh * 3 + t) * p.Cx * p.Cy;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cx = cx0 + wm * 32 + i * 16 + fg * 4 + r;
+          const int cy = cy0 + wn * 32 + j * 16 + frow;
+          if (cx < p.Cx && cy < p.Cy) unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[t][i][j][r]);
+        }
+  }
+  if (do_bias) {                       // 32 lanes (pixel pairs) share an octet: xor-reduce, one 64-wide atomic instruction
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) bsum[k] += __shfl_xor(bsum[k], o, 64);
+      if (pp == 0) red[oct * 8 + k] = bsum[k];
+    }
+    __syncthreads();
+    if (tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, red[tid]);
+  }
+}
+
+static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
+                             hipStream_t st) {
+  static const bool enabled = getenv("TG_NO_WGRAD_ROW3") == nullptr;                               // A/B switch
+  if (!enabled || d->KW != 3 || d->stride != 1 || d->pad_l != 1 || d->Win != d->Wout || d->Hin != d->Hout) return 0;
+  if ((d->Wout & 1) || d->KH > 11 || d->pad_t < 0 || d->pad_t >= d->KH) return 0;
+  const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
+  if (M64 * ldx >= ((int64_t)1 << 29) || M64 * ldy >= ((int64_t)1 << 29)) return 0;            // 32-bit byte offsets
+  WgradRP p;
+  p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;
+  p.N = d->N; p.H = d->Hout; p.W = d->Wout; p.Cx = d->Cin; p.Cy = d->Cout; p.KH = d->KH; p.pt = d->pad_t;
+  p.M = (int)M64; p.ldx = ldx; p.ldy = ldy;
+  p.xbytes = (unsigned)(M64 * ldx * 2);
+  p.ybytes = (unsigned)(M64 * ldy * 2);
+  p.xtiles = (p.Cx + 63) / 64;
+  p.ytiles = (p.Cy + 63) / 64;
+  const int base_blocks = d->KH * p.xtiles * p.ytiles;
+  static const int target_env = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 0;
+  const int target = target_env ? target_env : 512;
+  int ksplit = (target + base_blocks - 1) / base_blocks;
+  const int max_split = (p.M + 127) / 128;
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
+  ksplit = (p.M + p.chunk - 1) / p.chunk;
+  hipLaunchKernelGGL(conv_wgrad_row3_bf16_kernel, dim3((unsigned)(base_blocks * ksplit)), dim3(256), 0, st, p);
+  return 1;
+}
+
 // returns 1 if launched
 int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx, const void* y, int y_dtype, int ldy,
                       float* dw, float* dbias, hipStream_t st) {
   static const bool enabled = getenv("TG_NO_WGRAD_BF16") == nullptr;
   if (!enabled || x_dtype != TG_BF16 || y_dtype != TG_BF16) return 0;
   if (ldx % 8 || ldy % 8 || (((uintptr_t)x | (uintptr_t)y) & 15)) return 0;
+  if (tg_wgrad_row3_try(d, x, ldx, y, ldy, dw, dbias, st)) return 1;
   WgradBP p;
   p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;
   p.N = d->N; p.Hx = d->Hin; p.Wx = d->Win; p.Cx = d->Cin; p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
