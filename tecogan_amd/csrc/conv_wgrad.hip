@@ -12,6 +12,7 @@
 // (weight gradients are accumulated in full fp32 products; the flat fp32 gradient buffer is also
 // the RCCL all-reduce buffer).  grid = (taps, Cx/64 * Cy/64 tiles, pixel chunks).
 #include "common.h"
+#include <math.h>
 #include <stdlib.h>
 
 int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx, const void* y, int y_dtype, int ldy,
@@ -294,6 +295,29 @@ extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* o
 // K-step = 64 pixels; each wave owns a 32x32 quadrant of the 64x64 (cx, cy) tile; fp32 accumulate; split-K over
 // pixel chunks with fp32 atomics into the flat gradient buffer.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Split-K degree.  Measured model of these kernels on MI355X (tools/mb_wgrad.py sweeps + tools/trace_wgrad.py):
+//   T ~ fixed + a * (64-pixel steps per workgroup) + b * (fp32 atomics issued, in millions)
+// with a ~ 0.85 us (a step is issue-latency bound at the 1-2 waves per SIMD these launches run at) and b ~ 2 us
+// (the L2 atomic units retire ~0.5 T adds/s chip-wide).  steps = M/64/ksplit, atomics = outputs * ksplit:
+// the optimum is ksplit = sqrt(a * (M/64) / (b * outputs)), capped so that the grid stays within ~1024 workgroups.
+static int tg_wgrad_ksplit(int M, int64_t outputs, int base_blocks, int quantum) {
+  static const int target_env = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 0;
+  int ksplit;
+  if (target_env) {
+    ksplit = (target_env + base_blocks - 1) / base_blocks;
+  } else {
+    const double steps = (double)M / 64.0, b = 2.0e-6 * (double)outputs;
+    ksplit = (int)(sqrt(0.85 * steps / b) + 0.5);
+    const int cap = (1024 + base_blocks - 1) / base_blocks;
+    if (ksplit > cap) ksplit = cap;
+  }
+  const int max_split = (M + 2 * quantum - 1) / (2 * quantum);
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  return ksplit;
+}
+
 struct WgradBP {
   const u16* x;
   const u16* y;
@@ -736,12 +760,7 @@ static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, cons
   p.xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * p.xtiles * p.ytiles;
-  static const int target_env = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 0;
-  const int target = target_env ? target_env : 512;
-  int ksplit = (target + base_blocks - 1) / base_blocks;
-  const int max_split = (p.M + 127) / 128;
-  if (ksplit > max_split) ksplit = max_split;
-  if (ksplit < 1) ksplit = 1;
+  int ksplit = tg_wgrad_ksplit(p.M, (int64_t)d->KH * 3 * p.xtiles * p.ytiles * 4096, base_blocks, 64);
   p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   hipLaunchKernelGGL(conv_wgrad_row3_bf16_kernel, dim3((unsigned)(base_blocks * ksplit)), dim3(256), 0, st, p);
@@ -770,17 +789,10 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.ytiles = (p.Cy + 63) / 64;
   p.xtiles = xtiles;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
-  // workgroup target, measured (tools/mb_wgrad.py, 256/512/1024 swept): 512 for the full 64x64-channel tiles of the
-  // LR generator layers, 1024 elsewhere (narrow tiles and the large HR / D layers)
-  static const int target_env = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 0;
-  const int target = target_env ? target_env : ((p.Cx >= 64 && p.Cy >= 64 && p.M <= 65536) ? 512 : 1024);
-  int ksplit = (target + base_blocks - 1) / base_blocks;           // workgroup target: trades parallelism vs atomics
-  const int max_split = (p.M + 127) / 128;
-  if (ksplit > max_split) ksplit = max_split;
-  if (ksplit < 1) ksplit = 1;
-  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 4;               // A/B switch
-  const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);
+  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 2;               // A/B switch
+  const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);        // 2: best or within noise at every swept shape
   const int quantum = 64 * pf;
+  int ksplit = tg_wgrad_ksplit(p.M, (int64_t)base_blocks * 4096, base_blocks, quantum);
   p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   const dim3 grid((unsigned)(d->KH * d->KW * xtiles * p.ytiles * ksplit));   // 1-D: the kernel maps work XCD-aware
