@@ -50,8 +50,11 @@ def synthetic_batch(F, seed, device):
 
 
 def dominant_kernel_roofline(dtype, device):
-    """Time the generator's 3x3 64->64 convolution (the res-block workhorse, 20 of the 24 convs of every
-    generator_F call) at the training shape [4,32,32,64] with HIP events on the launch stream."""
+    """Time the generator's 3x3 64->64 convolution (the res-block workhorse: 20 of the 24 convs of every generator_F call,
+    and with mirrored taps their input gradients) at the training shape [4,32,32,64].  The launches are captured in a
+    hipGraph (as the product step is) and the graph is replayed between two HIP events recorded on the launch stream, so the
+    figure is GPU time per launch, not Python/ctypes dispatch time.  `traffic` = HBM-side bytes per launch from the
+    committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by tools/pmc_summary.py), null if absent."""
     from tecogan_amd import kernels as K
     from tecogan_amd._lib import ACT_RELU
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
@@ -61,22 +64,42 @@ def dominant_kernel_roofline(dtype, device):
     b = torch.zeros(Cc, device=device)
     out = torch.empty_like(x)
     d = K.conv_desc(N, H, W, Cc, H, W, Cc, 3, 3, 1, 1, 1, 0, K.dt(x), K.dt(out), ACT_RELU)
-    for _ in range(20):
-        K.conv_forward(d, x, w, b, None, None, out)
-    iters = 400
+    per_graph, replays = 200, 10
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            K.conv_forward(d, x, w, b, None, None, out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per_graph):
+            K.conv_forward(d, x, w, b, None, None, out)
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        K.conv_forward(d, x, w, b, None, None, out)
+    for _ in range(replays):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
+    us = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
     flops = 2.0 * N * H * W * Cc * 9 * Cc          # algorithmic: 2 * M * N * K = 302 MFLOP per launch
     ach = flops / (us * 1e-6) / 1e12
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            t = json.load(fh).get("conv3x3_tile_kernel@[4,32,32,64->64]_%s" % dtype)
+        if t:
+            traffic = t["fetch_bytes"] + t["write_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "mfma", "kernel": "conv3x3_tile_kernel 3x3 64->64 @[4,32,32,64] %s (generator res-block conv)" % dtype,
             "achieved": round(ach, 3), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK[dtype], 5),
-            "us_per_launch": round(us, 3), "flop_per_launch": flops, "traffic": None}
+            "us_per_launch": round(us, 3), "flop_per_launch": flops,
+            "algorithmic_bytes": N * H * W * Cc * 2 * (2 if dtype == "bf16" else 4) + 9 * Cc * Cc * (2 if dtype == "bf16" else 4),
+            "traffic": traffic}
 
 
 def cpu_baseline(config, seconds):
