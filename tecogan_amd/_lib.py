@@ -79,6 +79,11 @@ def lib():
             raise TecoHipError(
                 "libtecogan_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `python tecogan_amd/build.py`; tecogan_amd has no fallback path." % LIB_PATH)
+        # One HIP runtime per process: PyTorch (device memory, streams, hipGraph capture) bundles its own libamdhip64 and
+        # must be loaded BEFORE this library resolves the runtime.  Loaded the other way round (observed with
+        # `build()` then `smoke()` in one interpreter) the process ends up with two runtimes and every launch from
+        # this library fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)
