@@ -80,11 +80,6 @@ int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*
  * forward : x = block input, relu1 = 1, flip = 0, w1/w2 = [9][out][in] panels of conv_1 / conv_2, mid = r, out = block output
  * backward: x = d(block output), flip = 1, w1/w2 = natural ([9][in][out]) panels of conv_2 / conv_1, m1 = r,
  *           mid = gradient w.r.t. conv_1's pre-activation, out = d(block input), m2 = ReLU output feeding the block or NULL. */
-/* Workgroup budget of the persistent 3x3 tile kernel for subsequently enqueued launches (1..256, anything else
- * restores the default of one workgroup per CU).  Host-side state; used by the training engine to leave CUs to a
- * concurrent stream (experimental overlap of the VGG target pass with the recurrent generator, lib/Teco.py:174-178). */
-int tg_conv3x3_set_max_workgroups(int n);
-
 int tg_resblock_fused(const void* x, const void* w1, const float* b1 /*nullable*/, const void* m1 /*nullable*/,
                       void* mid, const void* w2, const float* b2 /*nullable*/, const void* m2 /*nullable*/, void* out,
                       int N, int H, int W, int flip, int relu1, void* stream);

@@ -57,7 +57,6 @@ SIGNATURES = {
     "tg_pingpong": [_P, _P, _I, _I, _L, _F, _F, _P, _P],
     "tg_vgg_preprocess_forward": [_P, _P, _I, _L, _I, _P],
     "tg_vgg_preprocess_backward": [_P, _I, _P, _L, _I, _P],
-    "tg_conv3x3_set_max_workgroups": [_I],
     "tg_cosine_loss": [_P, _P, _I, _L, _I, _F, _F, _P, _P, _P],
     "tg_l1_loss": [_P, _P, _I, _L, _F, _F, _P, _P, _P],
     "tg_gan_losses": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P],

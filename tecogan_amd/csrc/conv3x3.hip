@@ -297,14 +297,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   }
 }
 
-// Workgroup budget of the persistent tile loop (default: one per CU).  tg_conv3x3_set_max_workgroups() lowers it for
-// launches that are meant to share the chip with a concurrent stream (host-side state, read when a launch is enqueued).
-static int g_c3_max_wg = 256;
-extern "C" int tg_conv3x3_set_max_workgroups(int n) {
-  g_c3_max_wg = (n >= 1 && n <= 256) ? n : 256;
-  return TG_OK;
-}
-
 template <typename TIn, typename TOut, int TH, int BN, int ABL = 0>
 static void launch3(Conv3P p, hipStream_t st) {
   constexpr int LDS = ((TH + 2) * 18 + 9 * BN) * 144;
@@ -319,7 +311,7 @@ static void launch3(Conv3P p, hipStream_t st) {
   p.ntiles = p.N * p.tiles_y * p.tiles_x;
   const int nt = (p.Cout + BN - 1) / BN;
   int gx = p.ntiles;
-  const int per = g_c3_max_wg / nt > 0 ? g_c3_max_wg / nt : 1;   // one workgroup per CU (LDS-bound residency)
+  const int per = 256 / nt > 0 ? 256 / nt : 1;        // one workgroup per CU (LDS-bound residency)
   if (gx > per) gx = per;
   hipLaunchKernelGGL(kern, dim3(gx, nt), dim3(256), LDS, st, p);
 }

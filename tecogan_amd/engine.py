@@ -136,20 +136,6 @@ class TrainEngine:
         lr_seq = self.in_lr.transpose(0, 1).index_select(0, self.seq_idx).contiguous()      # [T,B,h,h,3]
         hr_seq = self.in_hr.transpose(0, 1).index_select(0, self.seq_idx).contiguous()      # [T,B,H,H,3]
         npair = (T - 1) * B
-        # ---- optional: VGG features of the TARGET frames on the side stream (they depend on the batch only), with a
-        #      workgroup cap so the latency-bound recurrent chain below keeps CUs of its own (TG_OVERLAP_VGG=<cap>)
-        self._taps_t = None
-        cap = int(os.environ.get("TG_OVERLAP_VGG", "0"))
-        if self.use_vgg and cap > 0:
-            main, side = torch.cuda.current_stream(), self.side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                K.conv3x3_set_max_workgroups(cap)
-                n, H = T * B, 4 * h
-                xt = K.vgg_preprocess_forward(hr_seq.view(n, H, H, 3),
-                                              torch.empty(n, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
-                self._taps_t, _ = self.V.forward(xt, keep=False)
-                K.conv3x3_set_max_workgroups(0)
         # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
         pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
         cur_lr = lr_seq[1:].reshape(npair, h, h, 3)
@@ -240,12 +226,8 @@ class TrainEngine:
         F, T, B, H = self.F, self.T, self.B, 4 * self.cs
         n = T * B
         xg = K.vgg_preprocess_forward(gen.view(n, H, H, 3), torch.empty(n, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
-        if self._taps_t is not None:                                   # computed on the side stream (TG_OVERLAP_VGG)
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-            taps_t, self._taps_t = self._taps_t, None
-        else:
-            xt = K.vgg_preprocess_forward(hr_seq.view(n, H, H, 3), torch.empty_like(xg))
-            taps_t, _ = self.V.forward(xt, keep=False)
+        xt = K.vgg_preprocess_forward(hr_seq.view(n, H, H, 3), torch.empty_like(xg))
+        taps_t, _ = self.V.forward(xt, keep=False)
         taps_g, acts = self.V.forward(xg)
         d_taps = {}
         for i, key in enumerate(VGG_TAPS):

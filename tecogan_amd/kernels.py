@@ -201,10 +201,6 @@ def vgg_preprocess_backward(d_out, d_x):
           "tg_vgg_preprocess_backward")
 
 
-def conv3x3_set_max_workgroups(n):
-    check(lib().tg_conv3x3_set_max_workgroups(int(n)), "tg_conv3x3_set_max_workgroups")
-
-
 def cosine_loss(g, t, cos_scale, grad_scale, cos_sum, d_g):
     Cn = g.shape[-1]
     check(lib().tg_cosine_loss(_p(g), _p(t), dt(g), g.numel() // Cn, Cn, cos_scale, grad_scale, _p(cos_sum), _p(d_g),
