@@ -268,7 +268,7 @@ extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* o
   if (dtype == TG_BF16 && C % 8 == 0 && C / 8 <= 256 && ((C / 8) & (C / 8 - 1)) == 0 && ((uintptr_t)x & 15) == 0) {
     const int RP = 256 / (C / 8);
     int gx = (int)cdiv64(rows, (int64_t)RP * 8);
-    if (gx > 1024) gx = 1024;
+    if (gx > 256) gx = 256;              // every workgroup ends with C atomics on the same C addresses
     hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3(gx), dim3(256), 0, static_cast<hipStream_t>(stream), (const u16*)x, rows,
                        C, out);
     TG_CHECK_LAUNCH();

@@ -390,6 +390,150 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- bf16, C % 8 == 0 with C/8 a power of two <= 32 (the D widths 64/128/256): 16-byte accesses, every thread owns one
+//      channel octet for the whole launch (its per-channel constants live in registers), <= 256 workgroups per
+//      reduction so that the per-channel atomics of a launch stay few (same-address atomics serialise).
+template <int PASS>   // 0: mean, 1: biased variance around stats[c]
+__global__ __launch_bounds__(256) void bn_stats_x8_kernel(const u16* __restrict__ x, int64_t rows, int C,
+                                                          float* __restrict__ stats) {
+  __shared__ float red[256 * 8];
+  const int OC = C >> 3, RP = 256 / OC, oc = threadIdx.x % OC, rsub = threadIdx.x / OC;
+  float mu[8], s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = PASS ? stats[oc * 8 + k] : 0.f;
+    s[k] = 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RP + rsub; r < rows; r += (int64_t)gridDim.x * RP) {
+    float v[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(x + r * C + oc * 8), v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d = v[k] - mu[k];
+      s[k] += PASS ? d * d : d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = s[k];
+  __syncthreads();
+  const float inv = 1.f / (float)rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int k = 0; k < RP; ++k) t += red[(k * OC + (c >> 3)) * 8 + (c & 7)];
+    unsafeAtomicAdd(stats + PASS * C + c, t * inv);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_lrelu_apply_x8_kernel(const u16* __restrict__ x, u16* __restrict__ y,
+                                                                int64_t rows, int C, const float* __restrict__ beta,
+                                                                const float* __restrict__ stats, float eps, float alpha,
+                                                                float* __restrict__ moving) {
+  if (moving && blockIdx.x == 0) {   // [TF1] moving stats: decay .9, unbiased variance fed to the average
+    const float corr = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      moving[c] = moving[c] * 0.9f + stats[c] * 0.1f;
+      moving[C + c] = moving[C + c] * 0.9f + stats[C + c] * corr * 0.1f;
+    }
+  }
+  const int OC = C >> 3;
+  const int64_t n8 = rows * OC;
+  const int oc = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % OC);     // constant per thread: 256 % OC == 0
+  float mu[8], rs[8], bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = stats[oc * 8 + k];
+    rs[k] = rsqrtf(stats[C + oc * 8 + k] + eps);
+    bt[k] = beta[oc * 8 + k];
+  }
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+    float v[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(x + e * 8), v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t = (v[k] - mu[k]) * rs[k] + bt[k];
+      v[k] = t > 0.f ? t : t * alpha;
+    }
+    *reinterpret_cast<uint4*>(y + e * 8) = bf8_pack(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_sums_x8_kernel(const u16* __restrict__ x, const u16* __restrict__ y,
+                                                             const u16* __restrict__ dy, int64_t rows, int C,
+                                                             const float* __restrict__ stats, float eps, float alpha,
+                                                             float* __restrict__ sums) {
+  __shared__ float red0[256 * 8], red1[256 * 8];
+  const int OC = C >> 3, RP = 256 / OC, oc = threadIdx.x % OC, rsub = threadIdx.x / OC;
+  float mu[8], rs[8], s0[8], s1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = stats[oc * 8 + k];
+    rs[k] = rsqrtf(stats[C + oc * 8 + k] + eps);
+    s0[k] = s1[k] = 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RP + rsub; r < rows; r += (int64_t)gridDim.x * RP) {
+    float xv[8], yv[8], gv[8];
+    const int64_t off = r * C + oc * 8;
+    bf8_unpack(*reinterpret_cast<const uint4*>(x + off), xv);
+    bf8_unpack(*reinterpret_cast<const uint4*>(y + off), yv);
+    bf8_unpack(*reinterpret_cast<const uint4*>(dy + off), gv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float dz = gv[k] * (yv[k] > 0.f ? 1.f : alpha);
+      s0[k] += dz;
+      s1[k] += dz * (xv[k] - mu[k]) * rs[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red0[threadIdx.x * 8 + k] = s0[k];
+    red1[threadIdx.x * 8 + k] = s1[k];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < RP; ++k) {
+      t0 += red0[(k * OC + (c >> 3)) * 8 + (c & 7)];
+      t1 += red1[(k * OC + (c >> 3)) * 8 + (c & 7)];
+    }
+    unsafeAtomicAdd(sums + c, t0);
+    unsafeAtomicAdd(sums + C + c, t1);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_x8_kernel(const u16* __restrict__ x, const u16* __restrict__ y,
+                                                              const u16* __restrict__ dy, u16* __restrict__ dx,
+                                                              int64_t rows, int C, const float* __restrict__ stats,
+                                                              float eps, float alpha, const float* __restrict__ sums,
+                                                              float* __restrict__ d_beta) {
+  const float inv = 1.f / (float)rows;
+  if (d_beta && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) d_beta[c] += sums[c];
+  const int OC = C >> 3;
+  const int64_t n8 = rows * OC;
+  const int oc = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % OC);
+  float mu[8], rs[8], m0[8], m1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = stats[oc * 8 + k];
+    rs[k] = rsqrtf(stats[C + oc * 8 + k] + eps);
+    m0[k] = sums[oc * 8 + k] * inv;
+    m1[k] = sums[C + oc * 8 + k] * inv;
+  }
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n8; e += (int64_t)gridDim.x * 256) {
+    float xv[8], yv[8], gv[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(x + e * 8), xv);
+    bf8_unpack(*reinterpret_cast<const uint4*>(y + e * 8), yv);
+    bf8_unpack(*reinterpret_cast<const uint4*>(dy + e * 8), gv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xhat = (xv[k] - mu[k]) * rs[k];
+      const float dz = gv[k] * (yv[k] > 0.f ? 1.f : alpha);
+      gv[k] = rs[k] * (dz - m0[k] - xhat * m1[k]);
+    }
+    *reinterpret_cast<uint4*>(dx + e * 8) = bf8_pack(gv);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // tf.train.AdamOptimizer (reference lib/Teco.py:425,439-440)  [TF1] A.11
 // hyper = {lr_t, beta1, beta2, eps, gate}; gate == 0 leaves p, m, v untouched (tf.cond D-gate).
@@ -572,6 +716,12 @@ extern "C" int tg_lincomb(const float* a, const float* b, float* out, int64_t n,
   TG_CHECK_LAUNCH();
 }
 
+static bool bn_x8_ok(int dtype, int C, const void* a, const void* b, const void* c, const void* d) {
+  const int oc = C / 8;
+  return dtype == TG_BF16 && C % 8 == 0 && oc >= 1 && oc <= 32 && (oc & (oc - 1)) == 0 &&
+         ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d)) & 15) == 0;
+}
+
 static dim3 reduce_grid(int64_t rows, int C) {
   const int Cb = C < 256 ? C : 256, lpc = 256 / Cb;
   int gx = (int)cdiv64(rows, (int64_t)lpc * 32);
@@ -587,6 +737,15 @@ extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t ro
   if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
     tg_set_error("tg_bn_lrelu_forward: memset failed");
     return TG_ELAUNCH;
+  }
+  if (bn_x8_ok(dtype, C, x, y, nullptr, nullptr)) {
+    const int OC = C / 8, RP = 256 / OC;
+    const dim3 rg8(grid_1d(rows, RP * 16, 256)), eg8(grid_1d(rows * OC, 256, 2048));
+    hipLaunchKernelGGL((bn_stats_x8_kernel<0>), rg8, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
+    hipLaunchKernelGGL((bn_stats_x8_kernel<1>), rg8, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
+    hipLaunchKernelGGL(bn_lrelu_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (u16*)y, rows, C, beta, stats,
+                       eps, alpha, moving);
+    TG_CHECK_LAUNCH();
   }
   const dim3 rg = reduce_grid(rows, C);
   const dim3 eg(grid_1d(rows * C, 256));
@@ -610,6 +769,15 @@ extern "C" int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_
   if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
     tg_set_error("tg_bn_lrelu_backward: memset failed");
     return TG_ELAUNCH;
+  }
+  if (bn_x8_ok(dtype, C, x, y, d_y, d_x)) {
+    const int OC = C / 8, RP = 256 / OC;
+    const dim3 rg8(grid_1d(rows, RP * 16, 256)), eg8(grid_1d(rows * OC, 256, 2048));
+    hipLaunchKernelGGL(bn_bwd_sums_x8_kernel, rg8, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows,
+                       C, stats, eps, alpha, ws);
+    hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y,
+                       (u16*)d_x, rows, C, stats, eps, alpha, ws, d_beta);
+    TG_CHECK_LAUNCH();
   }
   const dim3 rg = reduce_grid(rows, C);
   const dim3 eg(grid_1d(rows * C, 256));

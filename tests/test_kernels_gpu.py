@@ -365,6 +365,36 @@ def test_bn_lrelu_forward_backward():
     close(dbeta, beta.grad, 1e-4, "bn dbeta")
 
 
+@pytest.mark.parametrize("C", [64, 128, 256, 40])
+def test_bn_lrelu_bf16(C):
+    """bf16 activations: C in {64,128,256} takes the 16-byte kernels, 40 the scalar ones; reference = fp32 math on the
+    same bf16-rounded operands (slim.batch_norm training mode + lrelu, reference lib/ops.py:84-90)."""
+    x = (rnd(3, 7, 9, C, seed=1) * 2 + 0.7).bfloat16().float().requires_grad_()
+    beta = rnd(C, seed=2).requires_grad_()
+    y, mean, var = O.batchnorm(x, beta)
+    y = O.lrelu(y, 0.2)
+    xd = x.detach().to(DEV, torch.bfloat16)
+    out = torch.empty_like(xd)
+    stats = torch.empty(2, C, device=DEV)
+    K.bn_lrelu_forward(xd, out, beta.detach().to(DEV), 1e-3, 0.2, stats, None)
+    close(stats[0], mean, 1e-4, "bn mean bf16")
+    close(stats[1], var, 1e-4, "bn var bf16")
+    close(out, y, 1e-2, "bn fwd bf16")
+    g = rnd(*y.shape, seed=3).bfloat16().float()
+    # backward reference on the bf16-rounded forward output (its sign selects the lrelu branch in the kernel)
+    yb = out.float().cpu()
+    xr = x.detach().clone().requires_grad_()
+    br = beta.detach().clone().requires_grad_()
+    yr, _, _ = O.batchnorm(xr, br)
+    (yr * torch.where(yb > 0, 1.0, 0.2) * g).sum().backward()
+    dx = torch.empty_like(xd)
+    dbeta = torch.zeros(C, device=DEV)
+    ws = torch.empty(2, C, device=DEV)
+    K.bn_lrelu_backward(xd, out, g.to(DEV, torch.bfloat16), dx, stats, 1e-3, 0.2, dbeta, ws)
+    close(dx, xr.grad, 2e-2, "bn dx bf16")
+    close(dbeta, br.grad, 1e-3, "bn dbeta bf16")
+
+
 def test_adam_and_gate():
     p, g = rnd(1000, seed=1), rnd(1000, seed=2)
     m, v = torch.zeros(1000), torch.zeros(1000)
