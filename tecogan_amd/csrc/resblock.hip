@@ -47,6 +47,17 @@ struct ResP {
   _Pragma("unroll") for (int t_ = 0; t_ < 18; ++t_)                                                 \
       asm volatile("" : "+v"(ARR[t_].x), "+v"(ARR[t_].y), "+v"(ARR[t_].z), "+v"(ARR[t_].w));
 
+// Cycle stamps (tools/trace_resblock.py builds a private -DTG_RES_TRACE copy; the product build has none of it).
+#ifdef TG_RES_TRACE
+__device__ unsigned long long tg_res_trace_buf[16];
+#define RES_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) tg_res_trace_buf[(i)] = (unsigned long long)clock64(); } while (0)
+extern "C" int tg_debug_res_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_res_trace_buf), sizeof(unsigned long long) * 16);
+}
+#else
+#define RES_STAMP(i) do { } while (0)
+#endif
+
 template <int TH>
 __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   constexpr int XW = 20, XH = TH + 4, NX = XH * XW;
@@ -61,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   unsigned char* Rs = Xs + NX * ROWB;
   unsigned char* Os = Rs + NR * ROWB;
 
+  RES_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int frow = lane & 15, fg = lane >> 4;
   const int tile = blockIdx.x;
@@ -83,12 +95,14 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
   }
   RES_LOAD_B(bw1, p.w1)
   RES_LOAD_B(bw2, p.w2)                                    // lands during stage 1
+  RES_STAMP(1);
 #pragma unroll
   for (int k = 0; k < X_LOADS; ++k) {
     const int item = tid + k * 256;
     if (item < X_ITEMS) *reinterpret_cast<uint4*>(Xs + (item >> 3) * ROWB + (item & 7) * 16) = rx[k];
   }
   __syncthreads();
+  RES_STAMP(2);
 
   // ---- stage 1: mid over the (TH+2) x 18 region; wave w owns channels [16w, 16w+16) ------------------------
   f32x4 acc1[M1];
@@ -113,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
       }
     }
   }
+  RES_STAMP(3);
   {
     const float bias1 = p.b1 ? p.b1[c] : 0.f;
     u16* R16 = reinterpret_cast<u16*>(Rs);
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
       }
   }
   __syncthreads();                                          // mid tile complete
+  RES_STAMP(4);
   for (int item = tid; item < O_ITEMS; item += 256) {       // interior of mid -> global, 16-byte rows
     const int pl = item >> 3, cv = item & 7;
     const int i = pl >> 4, xx = pl & 15;
@@ -143,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
           *reinterpret_cast<const uint4*>(Rs + ((i + 1) * RW + xx + 1) * ROWB + cv * 16);
   }
   RES_PIN(bw2)
+  RES_STAMP(5);
 
   // ---- stage 2: out over the TH x 16 tile ------------------------------------------------------------------
   f32x4 acc2[TH];
@@ -163,6 +180,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
       }
     }
   }
+  RES_STAMP(6);
   {
     const float bias2 = p.b2 ? p.b2[c] : 0.f;
     const u16* X16 = reinterpret_cast<const u16*>(Xs);
@@ -177,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
       }
   }
   __syncthreads();
+  RES_STAMP(7);
   for (int item = tid; item < O_ITEMS; item += 256) {
     const int pl = item >> 3, cv = item & 7;
     const int i = pl >> 4, xx = pl & 15;
@@ -193,6 +212,11 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
     }
     *reinterpret_cast<uint4*>(p.out + idx) = o;
   }
+  RES_STAMP(8);
+#ifdef TG_RES_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  RES_STAMP(9);
+#endif
 }
 
 template <int TH>
