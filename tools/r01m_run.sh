@@ -18,5 +18,5 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_frvsr12 -o frvsr -- python $R/bench.py --no-cpu-baseline > $O/prof_frvsr12.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_teco9 -o teco -- python $R/bench.py --config tecogan --steps 10 --no-cpu-baseline > $O/prof_teco9.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_inf6 -o inf -- python $R/tools/bench_infer.py > $O/prof_inf6.log 2>&1
-for n in frvsr11:frvsr teco8:tecogan inf5:infer1080p; do d=${n%%:*}; f=${n##*:}; db=$(find $O/prof_$d -name "*.db" | head -1); python $R/tools/prof_summary.py $db $O/r01m_${f}_bf16_kernel_stats.txt; done
+for n in frvsr12:frvsr teco9:tecogan inf6:infer1080p; do d=${n%%:*}; f=${n##*:}; db=$(find $O/prof_$d -name "*.db" | head -1); python $R/tools/prof_summary.py $db $O/r01m_${f}_bf16_kernel_stats.txt; done
 head -8 $O/r01m_frvsr_bf16_kernel_stats.txt
