@@ -217,19 +217,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
         __syncthreads();                   // all waves are done reading the halo tile
         u16* stage = reinterpret_cast<u16*>(As);
         constexpr int SP = 72;             // u16 per staged pixel row: 64 channels + 8 pad (144 B)
-        const bool slow = p.act >= TG_ACT_TANH;
+        // two uniformly selected copies: a per-element `slow ? tanh/sigmoid : max` left 191 scalar branches (and unpaired
+        // bf16 conversions) in the 64-element fast path
+        auto stage_tile = [&](auto slow_tag) {
+          constexpr bool SLOW = decltype(slow_tag)::value;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int pl = ((wm * TM + i) * 16 + fg * 4 + r) * SP + wn * TN * 16 + frow;
+            for (int r = 0; r < 4; ++r) {
+              const int pl = ((wm * TM + i) * 16 + fg * 4 + r) * SP + wn * TN * 16 + frow;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              float v = acc[i][j][r] + bv[j];
-              v = slow ? act_fwd(v, p.act, p.act_alpha) : fmaxf(v, v * p.nslope);
-              stage[pl + j * 16] = f2bf(v);
+              for (int j = 0; j < TN; ++j) {
+                float v = acc[i][j][r] + bv[j];
+                if constexpr (SLOW) v = act_fwd(v, p.act, p.act_alpha);
+                else v = fmaxf(v, v * p.nslope);
+                stage[pl + j * 16] = f2bf(v);
+              }
             }
-          }
+        };
+        if (p.act >= TG_ACT_TANH) stage_tile(std::true_type{});
+        else stage_tile(std::false_type{});
         __syncthreads();
         constexpr int VPP = BN / 8;        // 16-byte vectors per pixel
         constexpr int NV = TH * 16 * VPP;
