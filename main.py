@@ -38,22 +38,34 @@ class Logger(object):
 
 
 def save_checkpoint(eng, output_dir, step):
+    """`<output_dir>/model-<step>` (torch file: exact resume) and, beside it, the same state as a TensorFlow tensor
+    bundle `model-<step>.index/.data-00000-of-00001` -- the files `saver.save` writes (reference main.py:365,420)."""
+    from tecogan_amd.checkpoint import save_bundle
     path = os.path.join(output_dir, "model-%d" % step)
     torch.save({"variables": eng.ps.state_dict(), "adam_m": eng.ps.m.cpu(), "adam_v": eng.ps.v.cpu(),
                 "sched": eng.sched.cpu(), "global_step": step}, path)
+    save_bundle(path, eng.ps, step, beta1=eng.F.beta)
     return path
 
 
 def restore_training(eng, FLAGS):
     """reference main.py:312-320,345-352: full resume vs weights-only ("pre-trained") restore."""
-    ck = torch.load(FLAGS.checkpoint, map_location="cpu")
-    saved = ck["variables"]
+    from tecogan_amd.checkpoint import load_variables
+    saved, ck = load_variables(FLAGS.checkpoint)                      # torch file or TensorFlow bundle prefix
     if not FLAGS.pre_trained_model:
         print('Loading everything from the checkpoint to continue the training...')
-        eng.ps.load(saved)
-        eng.ps.m.copy_(ck["adam_m"])
-        eng.ps.v.copy_(ck["adam_v"])
-        eng.sched.copy_(ck["sched"])
+        eng.ps.load({k: v for k, v in saved.items() if k in eng.ps.entries})
+        if isinstance(ck.get("adam_m"), dict):                        # bundle: per-variable Adam slots
+            for name in eng.ps.entries:
+                if name in ck["adam_m"] and name in ck["adam_v"]:
+                    eng.ps.view(name, eng.ps.m).copy_(ck["adam_m"][name])
+                    eng.ps.view(name, eng.ps.v).copy_(ck["adam_v"][name])
+            if "global_step" in ck:
+                eng.sched[0] = float(ck["global_step"])
+        else:
+            eng.ps.m.copy_(ck["adam_m"])
+            eng.ps.v.copy_(ck["adam_v"])
+            eng.sched.copy_(ck["sched"])
         return
     print('Loading weights from the pre-trained model to start a new training...')
     vals, zero = {}, 0
@@ -83,10 +95,9 @@ def run_inference(FLAGS):
     eng = InferenceEngine(FLAGS.num_resblock, h, w, "cuda", tdt, seed=FLAGS.rand_seed + 41)
     print('Finish building the network')
     if FLAGS.checkpoint != "random":
-        if not os.path.exists(FLAGS.checkpoint):
-            raise ValueError('checkpoint %s not found (torch file keyed by TF variable names)' % FLAGS.checkpoint)
+        from tecogan_amd.checkpoint import load_variables
         print('Loading weights from ckpt model')
-        saved = torch.load(FLAGS.checkpoint, map_location="cpu")["variables"]
+        saved, _ = load_variables(FLAGS.checkpoint)                   # torch file or TensorFlow bundle prefix (ValueError if absent)
         eng.load({k: v for k, v in saved.items() if k in eng.ps.entries})
     image_dir = FLAGS.output_dir if FLAGS.output_pre == "" else os.path.join(FLAGS.output_dir, FLAGS.output_pre)
     os.makedirs(image_dir, exist_ok=True)
@@ -128,7 +139,9 @@ def run_training(FLAGS):
     if FLAGS.checkpoint is not None:
         restore_training(eng, FLAGS)
     if FLAGS.vgg_scaling > 0.0 and FLAGS.vgg_ckpt and os.path.exists(FLAGS.vgg_ckpt):
-        eng.vps.load(torch.load(FLAGS.vgg_ckpt, map_location="cpu")["variables"])
+        from tecogan_amd.checkpoint import load_variables
+        vgg_vars, _ = load_variables(FLAGS.vgg_ckpt)
+        eng.vps.load({k: v for k, v in vgg_vars.items() if k in eng.vps.entries})
         print('VGG19 restored successfully!!')
     if rank == 0:
         print('Save initial checkpoint, before any training')

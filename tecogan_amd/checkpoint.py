@@ -1,0 +1,86 @@
+"""Checkpoint I/O for the reference's variable names.
+
+Two on-disk forms, both keyed by the TF variable names:
+  * a torch file `model-<step>` = {"variables", "adam_m", "adam_v", "sched", "global_step"} (exact resume of this backend);
+  * a TensorFlow tensor bundle `model-<step>.index` / `.data-00000-of-00001` (tecogan_amd/tf_bundle.py), the format the
+    reference's `tf.train.Saver` reads and writes (reference main.py:224,245,307-352,365,420).  Variables are stored under
+    their TF names, Adam slots under TF's slot names (`<optimizer scope>/<variable>/Adam`, `/Adam_1`; optimizer scopes
+    `generator_train`, `tdicriminator_train` [sic], reference lib/Teco.py:420,439), plus `global_step`.
+`load_variables(path)` accepts either: the path of a torch file, or a bundle prefix (also `model/TecoGAN`-style prefixes
+of pre-trained models and `vgg_19.ckpt`).
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import tf_bundle
+
+OPT_SCOPE = {"generator": "generator_train", "fnet": "generator_train", "tdiscriminator": "tdicriminator_train"}
+
+
+def _is_torch_file(path):
+    """A regular file that is not a TensorFlow V1 (tensor-slice) checkpoint such as slim's `vgg_19.ckpt`: those are sorted
+    string tables too (same trailing magic) but hold SavedTensorSlices protos -- not supported, convert them once with
+    TensorFlow (`tf.train.Saver(..., write_version=V2)`) or to the torch form."""
+    if not os.path.isfile(path):
+        return False
+    with open(path, "rb") as fh:
+        fh.seek(0, os.SEEK_END)
+        n = fh.tell()
+        if n >= 8:
+            fh.seek(n - 8)
+            if int.from_bytes(fh.read(8), "little") == tf_bundle.MAGIC:
+                raise NotImplementedError("%s is a TensorFlow V1 (tensor-slice) checkpoint; only tensor bundles "
+                                          "(<prefix>.index + .data-*) and torch files are read" % path)
+    return True
+
+
+def load_variables(path):
+    """-> (variables: OrderedDict name -> torch tensor, extra: dict).  `extra` holds what a full resume needs when the
+    file has it: "adam_m"/"adam_v" (flat torch buffers of the torch form, or name -> tensor dicts of a bundle),
+    "sched", "global_step"."""
+    if _is_torch_file(path):
+        ck = torch.load(path, map_location="cpu")
+        return OrderedDict(ck["variables"]), {k: v for k, v in ck.items() if k != "variables"}
+    if not tf_bundle.is_bundle(path):
+        raise ValueError("checkpoint %s not found (neither a torch file nor a TensorFlow bundle prefix)" % path)
+    r = tf_bundle.BundleReader(path)
+    variables, m, v, extra = OrderedDict(), {}, {}, {}
+    for key in r.keys():
+        if key.endswith("/Adam") or key.endswith("/Adam_1"):
+            base = key.rsplit("/", 1)[0]
+            for scope in set(OPT_SCOPE.values()):                     # strip the optimizer's variable scope
+                if base.startswith(scope + "/"):
+                    base = base[len(scope) + 1:]
+            (m if key.endswith("/Adam") else v)[base] = torch.from_numpy(r.get(key))
+            continue
+        if key == "global_step":
+            extra["global_step"] = int(r.get(key))
+            continue
+        if "beta1_power" in key or "beta2_power" in key or "ExponentialMovingAverage" in key:
+            continue
+        a = r.get(key)
+        if a.dtype in (np.float32, np.float64, np.float16):
+            variables[key] = torch.from_numpy(a.astype(np.float32))
+    if m and v:
+        extra["adam_m"], extra["adam_v"] = m, v
+    return variables, extra
+
+
+def save_bundle(prefix, ps, global_step, beta1=0.9, beta2=0.999):
+    """Write the parameter store (variables + Adam slots + global_step) as a TensorFlow tensor bundle."""
+    out = OrderedDict()
+    for name, e in ps.entries.items():
+        out[name] = ps.view(name).detach().cpu().numpy()
+        scope = OPT_SCOPE.get(e["scope"])
+        if scope is not None and ps.trainable:
+            out["%s/%s/Adam" % (scope, name)] = ps.view(name, ps.m).detach().cpu().numpy()
+            out["%s/%s/Adam_1" % (scope, name)] = ps.view(name, ps.v).detach().cpu().numpy()
+    out["global_step"] = np.asarray(int(global_step), dtype=np.int64)
+    t = max(int(global_step), 0)
+    for scope in sorted(set(OPT_SCOPE[e["scope"]] for e in ps.entries.values() if e["scope"] in OPT_SCOPE)):
+        out[scope + "/beta1_power"] = np.asarray(beta1 ** (t + 1), dtype=np.float32)   # TF stores beta^(t+1) after t updates
+        out[scope + "/beta2_power"] = np.asarray(beta2 ** (t + 1), dtype=np.float32)
+    return tf_bundle.write_bundle(prefix, out)

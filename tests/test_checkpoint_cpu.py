@@ -1,0 +1,155 @@
+"""TensorFlow tensor-bundle reader/writer (tecogan_amd/tf_bundle.py) and the checkpoint front end -- CPU only.
+The format is restated from the TensorFlow sources (no TF-written file is available offline): these tests pin the
+primitive encodings with hand-built bytes and check round trips."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tecogan_amd import tf_bundle as TB                      # noqa: E402
+
+
+def test_crc32c_check_values_and_masking():
+    assert TB.crc32c(b"123456789") == 0xE3069283                     # the standard CRC-32C check value
+    assert TB.crc32c(b"") == 0
+    assert TB.crc32c(b"\x00" * 32) == 0x8A9136AA                      # RFC 3720 B.4 test vector
+    assert TB.crc32c(b"\xff" * 32) == 0x62A8AB43                      # RFC 3720 B.4 test vector
+    assert TB.crc32c(b"6789", TB.crc32c(b"12345")) == 0xE3069283      # incremental
+    for c in (0, 1, 0xE3069283, 0xFFFFFFFF):
+        assert TB.unmask_crc(TB.mask_crc(c)) == c
+    assert TB.mask_crc(0) == 0xA282EAD8
+
+
+def test_varint_and_shape_proto_encoding():
+    assert TB._put_varint(0) == b"\x00" and TB._put_varint(300) == b"\xac\x02"
+    assert TB._get_varint(b"\xac\x02", 0) == (300, 2)
+    assert TB._put_varint(-1) == b"\xff" * 9 + b"\x01"                 # int64 -1: ten-byte two's complement
+    # TensorShapeProto{dim{size:3} dim{size:64}} = 12 02 08 03 12 02 08 40
+    assert TB._encode_shape((3, 64)) == bytes([0x12, 2, 8, 3, 0x12, 2, 8, 64])
+    assert TB._decode_shape(bytes([0x12, 2, 8, 3, 0x12, 2, 8, 64])) == (3, 64)
+    assert TB._decode_shape(b"") == ()
+
+
+def test_block_prefix_compression_hand_built():
+    # two entries "apple"->"1", "apply"->"22" (shares "appl"), one restart at 0
+    block = bytes([0, 5, 1]) + b"apple" + b"1" + bytes([4, 1, 2]) + b"y" + b"22" + struct.pack("<II", 0, 1)
+    assert list(TB._block_entries(block)) == [(b"apple", b"1"), (b"apply", b"22")]
+    assert TB._build_block([(b"apple", b"1"), (b"apply", b"22")], 16) == block
+
+
+def test_snappy_raw_decompress_hand_built():
+    # 20 x 'a': varint length 20, literal 'a', copy(2-byte offset form) of 19 bytes from offset 1
+    assert TB._snappy_decompress(bytes([20, 0x00, ord("a"), (18 << 2) | 2, 1, 0])) == b"a" * 20
+    # literal with a one-byte length field (tag 60<<2): 61 bytes
+    payload = bytes(range(61))
+    assert TB._snappy_decompress(bytes([61, 60 << 2, 60]) + payload) == payload
+
+
+def test_bundle_round_trip_many_blocks(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {"generator/generator_unit/resblock_%d/conv_1/Conv/weights" % i: rng.standard_normal((3, 3, 4, 5)).astype(np.float32)
+               for i in range(40)}
+    tensors["global_step"] = np.asarray(1234, dtype=np.int64)
+    tensors["fnet/autoencode_unit/encoder_1/conv_1/Conv/biases"] = np.zeros(32, np.float32)
+    tensors["flags/some_int32"] = np.arange(6, dtype=np.int32).reshape(2, 3)
+    prefix = str(tmp_path / "model-7")
+    TB.write_bundle(prefix, tensors, block_size=256)                   # small blocks: many data blocks + a real index block
+    assert TB.is_bundle(prefix)
+    r = TB.BundleReader(prefix)
+    assert r.header["num_shards"] == 1 and r.keys() == sorted(tensors, key=lambda s: s.encode())
+    assert r.shape("global_step") == () and r.shape("flags/some_int32") == (2, 3)
+    back = TB.read_bundle(prefix, verify=True)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    # footer: 48 bytes ending in the table magic
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xdb4775248b80fb57
+
+
+def test_bundle_detects_corruption(tmp_path):
+    prefix = str(tmp_path / "m")
+    TB.write_bundle(prefix, {"a": np.ones(4, np.float32), "b": np.zeros((2, 2), np.float32)})
+    raw = bytearray(open(prefix + ".index", "rb").read())
+    raw[3] ^= 0x40
+    open(prefix + ".index", "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        TB.BundleReader(prefix)
+    TB.write_bundle(prefix, {"a": np.ones(4, np.float32)})
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    data[0] ^= 1
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(ValueError):
+        TB.read_bundle(prefix, verify=True)
+
+
+def test_bfloat16_entries_are_widened(tmp_path):
+    prefix = str(tmp_path / "bf")
+    x = np.array([1.0, -2.5, 3.140625], np.float32)
+    TB.write_bundle(prefix, {"w": (x.view(np.uint32) >> 16).astype(np.uint16)})
+    r = TB.BundleReader(prefix)
+    r.entries["w"]["dtype"] = TB.DT_BFLOAT16                           # as a TF bfloat16 variable would be tagged
+    assert np.array_equal(r.get("w"), x)
+
+
+def test_checkpoint_front_end_reads_both_forms(tmp_path):
+    from tecogan_amd.checkpoint import load_variables
+    vals = {"generator/generator_unit/input_stage/conv/Conv/weights": torch.randn(3, 3, 51, 64),
+            "generator/generator_unit/input_stage/conv/Conv/biases": torch.zeros(64)}
+    tpath = str(tmp_path / "model-5")
+    torch.save({"variables": vals, "global_step": 5}, tpath)
+    got, extra = load_variables(tpath)
+    assert extra["global_step"] == 5 and all(torch.equal(got[k], v) for k, v in vals.items())
+    prefix = str(tmp_path / "TecoGAN")
+    b = {k: v.numpy() for k, v in vals.items()}
+    k0 = "generator/generator_unit/input_stage/conv/Conv/weights"
+    b["generator_train/%s/Adam" % k0] = np.full((3, 3, 51, 64), 0.5, np.float32)
+    b["generator_train/%s/Adam_1" % k0] = np.full((3, 3, 51, 64), 0.25, np.float32)
+    b["generator_train/beta1_power"] = np.asarray(0.9, np.float32)
+    b["global_step"] = np.asarray(77, np.int64)
+    TB.write_bundle(prefix, b)
+    got, extra = load_variables(prefix)
+    assert set(got) == set(vals) and all(torch.equal(got[k], v) for k, v in vals.items())
+    assert extra["global_step"] == 77 and float(extra["adam_m"][k0].mean()) == 0.5 and float(extra["adam_v"][k0].mean()) == 0.25
+    with pytest.raises(ValueError):
+        load_variables(str(tmp_path / "missing"))
+    with pytest.raises(NotImplementedError):                           # a V1 (tensor-slice) checkpoint: table magic in a plain file
+        load_variables(prefix + ".index")
+
+
+def test_crc32c_large_input_path_matches_bytewise():
+    rng = np.random.default_rng(1)
+    for n in (65536, 65537, 200003):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        ref = TB._crc_raw_small(d, 0xFFFFFFFF) ^ 0xFFFFFFFF
+        assert TB.crc32c(d) == ref
+        assert TB.crc32c(d[n // 3:], TB.crc32c(d[:n // 3])) == ref
+
+
+def test_parameter_store_round_trips_through_a_bundle(tmp_path):
+    """save_bundle() writes variables + TF-named Adam slots + global_step; load_variables() returns them."""
+    from collections import OrderedDict
+    from tecogan_amd import params as P
+    from tecogan_amd.checkpoint import load_variables, save_bundle
+    specs = OrderedDict(generator=P.generator_spec(1), fnet=P.fnet_spec())
+    ps = P.ParamStore(specs, "cpu")
+    g = torch.Generator().manual_seed(3)
+    ps.flat.copy_(torch.randn(ps.numel, generator=g))
+    ps.m.copy_(torch.randn(ps.numel, generator=g))
+    ps.v.copy_(torch.rand(ps.numel, generator=g))
+    prefix = str(tmp_path / "model-12")
+    save_bundle(prefix, ps, 12)
+    r = TB.BundleReader(prefix)
+    name = "fnet/autoencode_unit/decoder_2/conv_1/Conv/weights"
+    assert r.shape(name) == (3, 3, 256, 128) and r.shape("global_step") == ()
+    assert "generator_train/%s/Adam_1" % name in r.keys() and "generator_train/beta1_power" in r.keys()
+    got, extra = load_variables(prefix)
+    assert set(got) == set(ps.entries) and extra["global_step"] == 12
+    for n in ps.entries:
+        assert torch.equal(got[n], ps.view(n)), n
+        assert torch.equal(extra["adam_m"][n], ps.view(n, ps.m)) and torch.equal(extra["adam_v"][n], ps.view(n, ps.v)), n
+    assert abs(float(r.get("generator_train/beta2_power")) - 0.999 ** 13) < 1e-7
