@@ -375,7 +375,7 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
   } else {
     // single chunk, weights stationary: the largest tile that still gives every CU a workgroup.  Narrow
     // channel tiles (BN 32/16) shrink the weight panel each workgroup stages and were measured faster in situ
-    // for the small recurrent-chain shapes (FRVSR step 6.10 -> 5.61 ms with <4,16>; profiles/r01c).
+    // for the small recurrent-chain shapes (FRVSR step 6.10 -> 5.61 ms with <4,16>, same-session A/B via TG_C3_FORCE).
     auto blocks = [&](int th, int bn) {
       return (int64_t)p.N * ((p.H + th - 1) / th) * ((p.W + 15) / 16) * ((p.Cout + bn - 1) / bn);
     };

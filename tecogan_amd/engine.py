@@ -173,7 +173,7 @@ class TrainEngine:
         # weight gradients (shared weights: one launch per layer over many frames) and the FNet backward are
         # independent of it, so they run on a side stream (parallel branches of the captured hipGraph).
         main = torch.cuda.current_stream()
-        # measured on MI355X (profiles/r01c): the parallel branches slow the latency-critical chain more than they hide
+        # measured on MI355X (same-session A/B): the parallel branches slow the latency-critical chain more than they hide
         # (6.16 vs 6.00 ms FRVSR, 26.8 vs 25.8 ms TecoGAN), so the overlap is opt-in: TG_OVERLAP=1
         side = self.side_stream if os.environ.get("TG_OVERLAP") else main
         half = T // 2
