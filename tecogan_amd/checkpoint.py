@@ -6,8 +6,8 @@ Two on-disk forms, both keyed by the TF variable names:
     reference's `tf.train.Saver` reads and writes (reference main.py:224,245,307-352,365,420).  Variables are stored under
     their TF names, Adam slots under TF's slot names (`<optimizer scope>/<variable>/Adam`, `/Adam_1`; optimizer scopes
     `generator_train`, `tdicriminator_train` [sic], reference lib/Teco.py:420,439), plus `global_step`.
-`load_variables(path)` accepts either: the path of a torch file, or a bundle prefix (also `model/TecoGAN`-style prefixes
-of pre-trained models and `vgg_19.ckpt`).
+`load_variables(path)` accepts the path of a torch file, a bundle prefix (`model/TecoGAN`-style prefixes of the pre-trained
+models) or a TensorFlow V1 tensor-slice file (slim's original `vgg_19.ckpt`).
 """
 import os
 from collections import OrderedDict
@@ -21,20 +21,7 @@ OPT_SCOPE = {"generator": "generator_train", "fnet": "generator_train", "tdiscri
 
 
 def _is_torch_file(path):
-    """A regular file that is not a TensorFlow V1 (tensor-slice) checkpoint such as slim's `vgg_19.ckpt`: those are sorted
-    string tables too (same trailing magic) but hold SavedTensorSlices protos -- not supported, convert them once with
-    TensorFlow (`tf.train.Saver(..., write_version=V2)`) or to the torch form."""
-    if not os.path.isfile(path):
-        return False
-    with open(path, "rb") as fh:
-        fh.seek(0, os.SEEK_END)
-        n = fh.tell()
-        if n >= 8:
-            fh.seek(n - 8)
-            if int.from_bytes(fh.read(8), "little") == tf_bundle.MAGIC:
-                raise NotImplementedError("%s is a TensorFlow V1 (tensor-slice) checkpoint; only tensor bundles "
-                                          "(<prefix>.index + .data-*) and torch files are read" % path)
-    return True
+    return os.path.isfile(path) and not tf_bundle.is_v1_checkpoint(path)
 
 
 def load_variables(path):
@@ -44,6 +31,10 @@ def load_variables(path):
     if _is_torch_file(path):
         ck = torch.load(path, map_location="cpu")
         return OrderedDict(ck["variables"]), {k: v for k, v in ck.items() if k != "variables"}
+    if tf_bundle.is_v1_checkpoint(path):                                # TF V1 tensor-slice file (slim's vgg_19.ckpt)
+        vals = tf_bundle.read_v1_checkpoint(path)
+        return OrderedDict((k, torch.from_numpy(v.astype(np.float32))) for k, v in vals.items()
+                           if v.dtype in (np.float32, np.float64, np.float16)), {}
     if not tf_bundle.is_bundle(path):
         raise ValueError("checkpoint %s not found (neither a torch file nor a TensorFlow bundle prefix)" % path)
     r = tf_bundle.BundleReader(path)

@@ -148,7 +148,9 @@ def _get_varint(buf, pos):
 
 
 def _proto_fields(buf):
-    """Yield (field_number, wire_type, value) of one serialized message (value: int or bytes)."""
+    """Yield (field_number, wire_type, value) of one serialized message; length-delimited values are zero-copy
+    memoryview slices (a VGG fc6 entry is 400 MB: nothing is copied until a wanted tensor is materialised)."""
+    buf = memoryview(buf)
     pos, n = 0, len(buf)
     while pos < n:
         key, pos = _get_varint(buf, pos)
@@ -160,7 +162,7 @@ def _proto_fields(buf):
             pos += 8
         elif wt == 2:
             ln, pos = _get_varint(buf, pos)
-            v = bytes(buf[pos:pos + ln])
+            v = buf[pos:pos + ln]
             pos += ln
         elif wt == 5:
             v = struct.unpack_from("<I", buf, pos)[0]
@@ -448,3 +450,114 @@ def write_bundle(prefix, tensors, block_size=4096, with_crc=True):
     with open(prefix + ".index", "wb") as fh:
         fh.write(bytes(out))
     return prefix
+
+
+# ---- TensorFlow V1 ("tensor slice") checkpoints: slim's vgg_19.ckpt ---------------------------------------------------
+# One sorted string table (blocks usually snappy-compressed, tensorflow/core/util/tensor_slice_writer.cc):
+#   key ""  -> SavedTensorSlices{1: meta = SavedTensorSliceMeta{1: repeated SavedSliceMeta{1: name, 2: shape, 3: type,
+#              4: repeated TensorSliceProto}}}
+#   other   -> SavedTensorSlices{2: data = SavedSlice{1: name, 2: TensorSliceProto, 3: TensorProto}}
+#              TensorProto{1: dtype, 2: shape, 4: tensor_content, 5: packed float_val, 6: double_val, 7: int_val,
+#                          10: int64_val}; TensorSliceProto{1: repeated Extent{1: start, 2: length}} (empty = whole dim)
+# The reader walks the data entries and uses the name stored INSIDE each value, so it does not depend on the
+# ordered-code key encoding.  Restated from the TensorFlow sources; unpinned against a TF-written file.
+def is_v1_checkpoint(path):
+    if not os.path.isfile(path) or os.path.getsize(path) < 48:
+        return False
+    with open(path, "rb") as fh:
+        fh.seek(-8, os.SEEK_END)
+        return struct.unpack("<Q", fh.read(8))[0] == MAGIC
+
+
+def _tensor_from_proto(buf, shape, dtype_enum):
+    content, floats, doubles, ints, int64s = None, [], [], [], []
+    for f, wt, v in _proto_fields(buf):
+        if f == 4:
+            content = v
+        elif f == 5:
+            floats.append(np.frombuffer(v, "<f4") if wt == 2 else np.array([struct.unpack("<f", struct.pack("<I", v))[0]], "<f4"))
+        elif f == 6:
+            doubles.append(np.frombuffer(v, "<f8") if wt == 2 else np.array([struct.unpack("<d", struct.pack("<Q", v))[0]], "<f8"))
+        elif f == 7:
+            if wt == 2:
+                pos, vals = 0, []
+                while pos < len(v):
+                    x, pos = _get_varint(v, pos)
+                    vals.append(_signed64(x))
+                ints.append(np.array(vals, np.int32))
+            else:
+                ints.append(np.array([_signed64(v)], np.int32))
+        elif f == 10:
+            if wt == 2:
+                pos, vals = 0, []
+                while pos < len(v):
+                    x, pos = _get_varint(v, pos)
+                    vals.append(_signed64(x))
+                int64s.append(np.array(vals, np.int64))
+            else:
+                int64s.append(np.array([_signed64(v)], np.int64))
+    if content is not None and len(content):
+        a = np.frombuffer(content, np.dtype(DT_TO_NP[dtype_enum]).newbyteorder("<"))
+    else:
+        parts = floats or doubles or ints or int64s
+        a = np.concatenate(parts) if parts else np.zeros(0, DT_TO_NP.get(dtype_enum, np.float32))
+    n = 1
+    for d in shape:
+        n *= d
+    if a.size == 1 and n > 1:                              # TensorProto may store a constant tensor as one value
+        a = np.full(n, a[0], a.dtype)
+    if a.size != n:
+        raise ValueError("V1 checkpoint: tensor with %d values for shape %s" % (a.size, shape))
+    return a.reshape(shape).copy()
+
+
+def read_v1_checkpoint(path, names=None, verify=True):
+    """name -> numpy array for every (or the listed) whole-tensor entry of a V1 checkpoint file."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if len(data) < 48 or struct.unpack_from("<Q", data, len(data) - 8)[0] != MAGIC:
+        raise ValueError("%s is not a TensorFlow V1 checkpoint (bad magic)" % path)
+    foot = data[len(data) - 48:]
+    _, pos = _get_varint(foot, 0)
+    _, pos = _get_varint(foot, pos)
+    ioff, pos = _get_varint(foot, pos)
+    isize, pos = _get_varint(foot, pos)
+    want = None if names is None else set(names)
+    meta, out = {}, OrderedDict()
+    for _, hv in _block_entries(_read_block(data, ioff, isize, verify)):
+        boff, p = _get_varint(hv, 0)
+        bsize, _ = _get_varint(hv, p)
+        for key, value in _block_entries(_read_block(data, boff, bsize, verify)):
+            for f, _, v in _proto_fields(value):
+                if f == 1 and key == b"":                  # meta
+                    for f2, _, v2 in _proto_fields(v):
+                        if f2 == 1:
+                            name, shape, dt = None, (), 1
+                            for f3, _, v3 in _proto_fields(v2):
+                                if f3 == 1:
+                                    name = bytes(v3).decode("utf-8")
+                                elif f3 == 2:
+                                    shape = _decode_shape(v3)
+                                elif f3 == 3:
+                                    dt = v3
+                            meta[name] = (shape, dt)
+                elif f == 2:                               # data: SavedSlice
+                    name, tproto, partial = None, None, False
+                    for f2, _, v2 in _proto_fields(v):
+                        if f2 == 1:
+                            name = bytes(v2).decode("utf-8")
+                        elif f2 == 2:
+                            for f3, _, v3 in _proto_fields(v2):          # any Extent with a start/length = a partial slice
+                                if f3 == 1 and len(v3):
+                                    partial = True
+                        elif f2 == 3:
+                            tproto = v2
+                    if name is None or tproto is None or (want is not None and name not in want):
+                        continue
+                    if partial:
+                        raise NotImplementedError("V1 checkpoint: %s is stored in partial slices" % name)
+                    shape, dt = meta.get(name, (None, 1))
+                    if shape is None:
+                        raise ValueError("V1 checkpoint: data for %s precedes its metadata" % name)
+                    out[name] = _tensor_from_proto(tproto, shape, dt)
+    return out

@@ -117,8 +117,6 @@ def test_checkpoint_front_end_reads_both_forms(tmp_path):
     assert extra["global_step"] == 77 and float(extra["adam_m"][k0].mean()) == 0.5 and float(extra["adam_v"][k0].mean()) == 0.25
     with pytest.raises(ValueError):
         load_variables(str(tmp_path / "missing"))
-    with pytest.raises(NotImplementedError):                           # a V1 (tensor-slice) checkpoint: table magic in a plain file
-        load_variables(prefix + ".index")
 
 
 def test_crc32c_large_input_path_matches_bytewise():
@@ -153,3 +151,57 @@ def test_parameter_store_round_trips_through_a_bundle(tmp_path):
         assert torch.equal(got[n], ps.view(n)), n
         assert torch.equal(extra["adam_m"][n], ps.view(n, ps.m)) and torch.equal(extra["adam_v"][n], ps.view(n, ps.v)), n
     assert abs(float(r.get("generator_train/beta2_power")) - 0.999 ** 13) < 1e-7
+
+
+def _v1_file(path, tensors):
+    """Minimal writer of the V1 tensor-slice layout (test helper): meta entry under key "", one SavedSlice per tensor with
+    packed float_val / tensor_content, keys in the ordered-code form TF uses (0 prefix, escaped name, dims, full extents)."""
+    def lenfield(f, payload):
+        return TB._field(f, 2, TB._put_varint(len(payload)) + payload)
+    metas, items = b"", []
+    for name, a in sorted(tensors.items()):
+        shp = TB._encode_shape(a.shape)
+        sm = lenfield(1, name.encode()) + lenfield(2, shp) + TB._field(3, 0, TB._put_varint(TB.NP_TO_DT[a.dtype]))
+        sm += lenfield(4, b"".join(lenfield(1, b"") for _ in a.shape))
+        metas += lenfield(1, sm)
+        tp = TB._field(1, 0, TB._put_varint(TB.NP_TO_DT[a.dtype])) + lenfield(2, shp)
+        tp += lenfield(5, a.astype("<f4").tobytes()) if a.dtype == np.float32 else lenfield(4, a.tobytes())
+        sl = lenfield(1, name.encode()) + lenfield(2, b"".join(lenfield(1, b"") for _ in a.shape)) + lenfield(3, tp)
+        key = b"\x00" + name.encode().replace(b"\x00", b"\x00\xff") + b"\x00\x01" + bytes([1, a.ndim]) + b"\x80\x7f" * a.ndim
+        items.append((key, lenfield(2, sl)))
+    items.insert(0, (b"", lenfield(1, metas)))
+    out = bytearray()
+
+    def emit(block):
+        off = len(out)
+        out.extend(block + b"\x00" + struct.pack("<I", TB.mask_crc(TB.crc32c(block + b"\x00"))))
+        return off, len(block)
+    index = []
+    for kv in items:                                                   # one entry per block, like big tensors in real files
+        off, size = emit(TB._build_block([kv], 16))
+        index.append((kv[0], TB._handle(off, size)))
+    moff, msize = emit(TB._build_block([], 1))
+    ioff, isize = emit(TB._build_block(index, 1))
+    foot = TB._handle(moff, msize) + TB._handle(ioff, isize)
+    out.extend(foot + b"\x00" * (40 - len(foot)) + struct.pack("<Q", TB.MAGIC))
+    open(path, "wb").write(bytes(out))
+
+
+def test_v1_tensor_slice_checkpoint_reader(tmp_path):
+    from tecogan_amd.checkpoint import load_variables
+    rng = np.random.default_rng(5)
+    tensors = {"vgg_19/conv1/conv1_1/weights": rng.standard_normal((3, 3, 3, 64)).astype(np.float32),
+               "vgg_19/conv1/conv1_1/biases": rng.standard_normal(64).astype(np.float32),
+               "global_step": np.asarray([7], np.int64).reshape(())}
+    path = str(tmp_path / "vgg_19.ckpt")
+    _v1_file(path, tensors)
+    assert TB.is_v1_checkpoint(path)
+    got = TB.read_v1_checkpoint(path)
+    assert set(got) == set(tensors)
+    for k, v in tensors.items():
+        assert got[k].shape == v.shape and np.array_equal(got[k], v), k
+    only = TB.read_v1_checkpoint(path, names=["vgg_19/conv1/conv1_1/biases"])
+    assert list(only) == ["vgg_19/conv1/conv1_1/biases"]
+    variables, _ = load_variables(path)                                # the front end keeps the float variables
+    assert set(variables) == {"vgg_19/conv1/conv1_1/weights", "vgg_19/conv1/conv1_1/biases"}
+    assert torch.equal(variables["vgg_19/conv1/conv1_1/weights"], torch.from_numpy(tensors["vgg_19/conv1/conv1_1/weights"]))
