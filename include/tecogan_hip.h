@@ -96,6 +96,15 @@ int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, int ldx /*c
                   const void* y, int y_dtype, int ldy /*0 = Cout*/, float* dw, float* dbias /*nullable*/,
                   void* stream);
 
+/* The same for `groups` layers of identical geometry in one call (the 2*num_resblock 64->64 convs of generator_F,
+ * lib/frvsr.py:50-57, whose weight gradients are all due at the end of the BPTT chain): x[g], y[g], dw[g], dbias[g]
+ * (dbias nullable as a whole or per entry) are HOST arrays of device pointers.  Up to 40 bf16 stride-1 3-wide layers
+ * become ONE launch (per-launch fixed cost paid once, lower split-K degree per layer); anything else runs as
+ * `groups` ordinary tg_conv_wgrad launches -- the result is the same either way. */
+int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
+                          const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
+                          void* stream);
+
 /* out[c] += sum over rows of x[rows][C]  (bias gradient helper) */
 int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream);
 

@@ -30,6 +30,7 @@ _D = C.POINTER(ConvDesc)
 SIGNATURES = {
     "tg_conv_forward": [_D, _P, _P, _P, _P, _P, _P, _P],
     "tg_conv_wgrad": [_D, _P, _I, _I, _P, _I, _I, _P, _P, _P],
+    "tg_conv_wgrad_grouped": [_D, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "tg_colsum": [_P, _I, _L, _I, _P, _P],
     "tg_resblock_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tg_pack_weights": [_P, _P, _I, _P, _I, _I, _P],

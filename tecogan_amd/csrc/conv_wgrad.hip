@@ -586,11 +586,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
 // the loop is instruction-issue bound, so the lever is MFMAs per staged byte.  Here: 24 MFMAs per step for about the same
 // instruction count.  Panels are [64 channels][64 pixels] with a 144-byte pitch: conflict-free transposing writes for
 // the (32 pixel pairs x 2 octets) a wave writes per instruction, and 16-byte aligned rows -> one ds_read_b128 per fragment.
+// Grouped form: `groups` layers of identical geometry (the 2*num_resblock 64->64 convs of generator_F) in ONE launch,
+// each with its own X / Y / dW / dbias pointers.  A launch of this kernel costs ~8 us before the first useful step
+// (launch, prologue, first loads) and after the last (atomics drain); one launch for all layers pays that once, and
+// with groups x more workgroups per launch the split-K degree per layer (= atomics) drops.
+#define TG_WGRAD_MAX_GROUPS 40
 struct WgradRP {
-  const u16* x;
-  const u16* y;
-  float* dw;
-  float* dbias;
+  const u16* xs[TG_WGRAD_MAX_GROUPS];
+  const u16* ys[TG_WGRAD_MAX_GROUPS];
+  float* dws[TG_WGRAD_MAX_GROUPS];
+  float* dbs[TG_WGRAD_MAX_GROUPS];
+  int groups, nchunk;
   int N, H, W, Cx, Cy, KH, pt;
   int M, chunk, xtiles, ytiles, ldx, ldy;
   unsigned xbytes, ybytes;
@@ -613,20 +619,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
-  // XCD-aware work mapping (see conv_wgrad_bf16_kernel): work item = (chunk, channel tile, kh), kh fastest
+  // XCD-aware work mapping (see conv_wgrad_bf16_kernel): work item = (group, chunk, channel tile, kh), kh fastest
   const int nwg = gridDim.x, L = blockIdx.x;
   const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
   const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
   const int per_chunk = p.KH * p.xtiles * p.ytiles;
-  const int zc = work / per_chunk, rem = work - zc * per_chunk;
+  const int per_group = per_chunk * p.nchunk;
+  const int grp = work / per_group, wrem = work - grp * per_group;
+  const int zc = wrem / per_chunk, rem = wrem - zc * per_chunk;
+  const u16* __restrict__ gx = p.xs[grp];             // workgroup-uniform: scalar loads from the kernarg tables
+  const u16* __restrict__ gy = p.ys[grp];
+  float* __restrict__ gdw = p.dws[grp];
+  float* __restrict__ gdb = p.dbs[grp];
   const int tile = rem / p.KH, kh = rem - tile * p.KH;
   const int xt = tile / p.ytiles, yt = tile - xt * p.ytiles;
   const int cx0 = xt * 64, cy0 = yt * 64;
   const int mbeg = zc * p.chunk, mend = min(mbeg + p.chunk, p.M);
-  const bool do_bias = p.dbias != nullptr && kh == 0 && xt == 0;
+  const bool do_bias = gdb != nullptr && kh == 0 && xt == 0;
 
-  const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.x), 0, (int)p.xbytes, 0x00020000);
-  const auto rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.y), 0, (int)p.ybytes, 0x00020000);
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.xbytes, 0x00020000);
+  const auto rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.ybytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
 
   // staging item of this thread: pixel pair pp (pixels 2pp, 2pp+1 of the 64-pixel step) x channel octet oct, for X and Y
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
   }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    float* __restrict__ dw = p.dw + (int64_t)(kh * 3 + t) * p.Cx * p.Cy;
+    float* __restrict__ dw = gdw + (int64_t)(kh * 3 + t) * p.Cx * p.Cy;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -740,19 +752,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
       if (pp == 0) red[oct * 8 + k] = bsum[k];
     }
     __syncthreads();
-    if (tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(p.dbias + cy0 + tid, red[tid]);
+    if (tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(gdb + cy0 + tid, red[tid]);
   }
 }
 
-static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
-                             hipStream_t st) {
+static bool tg_wgrad_row3_applies(const tg_conv_desc* d, int ldx, int ldy) {
   static const bool enabled = getenv("TG_NO_WGRAD_ROW3") == nullptr;                               // A/B switch
-  if (!enabled || d->KW != 3 || d->stride != 1 || d->pad_l != 1 || d->Win != d->Wout || d->Hin != d->Hout) return 0;
-  if ((d->Wout & 1) || d->KH > 11 || d->pad_t < 0 || d->pad_t >= d->KH) return 0;
+  if (!enabled || d->KW != 3 || d->stride != 1 || d->pad_l != 1 || d->Win != d->Wout || d->Hin != d->Hout) return false;
+  if ((d->Wout & 1) || d->KH > 11 || d->pad_t < 0 || d->pad_t >= d->KH) return false;
   const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
-  if (M64 * ldx >= ((int64_t)1 << 29) || M64 * ldy >= ((int64_t)1 << 29)) return 0;            // 32-bit byte offsets
+  return M64 * ldx < ((int64_t)1 << 29) && M64 * ldy < ((int64_t)1 << 29);                       // 32-bit byte offsets
+}
+
+// groups >= 1 layers of identical geometry; pointer arrays live on the host and are copied into the kernel arguments
+static int tg_wgrad_row3_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
+                                float* const* dw, float* const* dbias, hipStream_t st) {
+  if (groups < 1 || groups > TG_WGRAD_MAX_GROUPS || !tg_wgrad_row3_applies(d, ldx, ldy)) return 0;
+  const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
   WgradRP p;
-  p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;
+  for (int g = 0; g < TG_WGRAD_MAX_GROUPS; ++g) {
+    const int k = g < groups ? g : 0;
+    p.xs[g] = (const u16*)x[k]; p.ys[g] = (const u16*)y[k]; p.dws[g] = dw[k]; p.dbs[g] = dbias ? dbias[k] : nullptr;
+  }
+  p.groups = groups;
   p.N = d->N; p.H = d->Hout; p.W = d->Wout; p.Cx = d->Cin; p.Cy = d->Cout; p.KH = d->KH; p.pt = d->pad_t;
   p.M = (int)M64; p.ldx = ldx; p.ldy = ldy;
   p.xbytes = (unsigned)(M64 * ldx * 2);
@@ -760,11 +782,37 @@ static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, cons
   p.xtiles = (p.Cx + 63) / 64;
   p.ytiles = (p.Cy + 63) / 64;
   const int base_blocks = d->KH * p.xtiles * p.ytiles;
-  int ksplit = tg_wgrad_ksplit(p.M, (int64_t)d->KH * 3 * p.xtiles * p.ytiles * 4096, base_blocks, 64);
+  // the atomics of all groups share the chip's atomic units and the workgroups of all groups share its CUs: the model of
+  // tg_wgrad_ksplit applied to the whole launch
+  int ksplit = tg_wgrad_ksplit(p.M, (int64_t)groups * d->KH * 3 * p.xtiles * p.ytiles * 4096, groups * base_blocks, 64);
   p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
-  hipLaunchKernelGGL(conv_wgrad_row3_bf16_kernel, dim3((unsigned)(base_blocks * ksplit)), dim3(256), 0, st, p);
+  p.nchunk = ksplit;
+  hipLaunchKernelGGL(conv_wgrad_row3_bf16_kernel, dim3((unsigned)(groups * base_blocks * ksplit)), dim3(256), 0, st, p);
   return 1;
+}
+
+static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
+                             hipStream_t st) {
+  return tg_wgrad_row3_launch(d, 1, &x, ldx, &y, ldy, &dw, dbias ? &dbias : nullptr, st);
+}
+
+extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
+                                     const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
+                                     void* stream) {
+  TG_CHECK_ARG(d && x && y && dw && groups >= 1, "null pointer / no groups");
+  for (int g = 0; g < groups; ++g) TG_CHECK_ARG(x[g] && y[g] && dw[g], "null group pointer");
+  const int lx = ldx > 0 ? ldx : d->Cin, ly = ldy > 0 ? ldy : d->Cout;
+  bool fast = d->mode == 0 && x_dtype == TG_BF16 && y_dtype == TG_BF16 && lx % 8 == 0 && ly % 8 == 0 && lx >= d->Cin &&
+              ly >= d->Cout && getenv("TG_NO_WGRAD_BF16") == nullptr;
+  for (int g = 0; g < groups && fast; ++g) fast = ((((uintptr_t)x[g] | (uintptr_t)y[g])) & 15) == 0;
+  if (fast && tg_wgrad_row3_launch(d, groups, x, lx, y, ly, dw, dbias, static_cast<hipStream_t>(stream)))
+    TG_CHECK_LAUNCH();
+  for (int g = 0; g < groups; ++g) {                        // any other geometry / dtype: one ordinary launch per layer
+    const int rc = tg_conv_wgrad(d, x[g], x_dtype, ldx, y[g], y_dtype, ldy, dw[g], dbias ? dbias[g] : nullptr, stream);
+    if (rc != TG_OK) return rc;
+  }
+  return TG_OK;
 }
 
 // returns 1 if launched

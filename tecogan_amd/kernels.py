@@ -53,6 +53,19 @@ def conv_wgrad(desc, x, y, dw, dbias, ldx=0, ldy=0):
           "tg_conv_wgrad")
 
 
+def conv_wgrad_grouped(desc, xs, ys, dws, dbiases, ldx=0, ldy=0):
+    """Weight gradients of len(xs) layers of identical geometry in one call (one launch for bf16 3x3 stride-1 layers)."""
+    G = len(xs)
+    assert G >= 1 and len(ys) == G and len(dws) == G and (dbiases is None or len(dbiases) == G)
+
+    def table(ts):
+        return (C.c_void_p * G)(*[_p(t) if t is not None else None for t in ts])
+    tx, ty, tw = table(xs), table(ys), table(dws)
+    tb = table(dbiases) if dbiases is not None else None
+    check(lib().tg_conv_wgrad_grouped(C.byref(desc), G, tx, dt(xs[0]), ldx, ty, dt(ys[0]), ldy, tw, tb, _stream()),
+          "tg_conv_wgrad_grouped")
+
+
 def colsum(x, rows, Cn, out):
     check(lib().tg_colsum(_p(x), dt(x), rows, Cn, _p(out), _stream()), "tg_colsum")
 

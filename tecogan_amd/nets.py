@@ -127,6 +127,8 @@ class Generator:
         # forward, 12.3 us backward; FRVSR step 6.9 ms vs 5.7 ms same box): with 128 tiles of one wave per SIMD the
         # block is latency-bound and the halo recompute + second weight fetch cost more than one launch saves.
         self.fused = ps.act_dtype == torch.bfloat16 and bool(os.environ.get("TG_FUSED_RESBLOCK"))
+        # one grouped weight-gradient launch for all res-block convs (TG_WGRAD_GROUPED=0/1 is the A/B switch)
+        self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "0") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None):
@@ -235,10 +237,29 @@ class Generator:
 
         conv_wgrad(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", flat(q["x_in"]),
                    flat(q["g_in"]))
-        for i in range(1, n + 1):
-            sc = p + "resblock_%d/" % i
-            conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", flat(q["a"][i - 1]), flat(q["g_c1"][i]))
-            conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", flat(q["r"][i]), flat(q["g_c2"][i]))
+        if self.grouped_wgrad and n >= 1:
+            # the 2n res-block convs have one geometry and their gradients are all due here: ONE grouped launch
+            # (tg_conv_wgrad_grouped) instead of 2n -- the per-launch fixed cost is paid once
+            names, xs, dys = [], [], []
+            for i in range(1, n + 1):
+                sc = p + "resblock_%d/" % i
+                names += [sc + "conv_1/Conv/", sc + "conv_2/Conv/"]
+                xs += [flat(q["a"][i - 1]), flat(q["r"][i])]
+                dys += [flat(q["g_c1"][i]), flat(q["g_c2"][i])]
+            e = ps.entries[names[0] + "weights"]
+            N, H, W, Cp = xs[0].shape
+            _, pt = K.same_pad(H, e["k"], 1)
+            _, pl = K.same_pad(W, e["k"], 1)
+            d = K.conv_desc(N, H, W, e["A"], H, W, e["B"], e["k"], e["k"], 1, pt, pl, 0, 0, 0)
+            for g0 in range(0, len(names), 40):                     # TG_WGRAD_MAX_GROUPS per call
+                sl = slice(g0, g0 + 40)
+                K.conv_wgrad_grouped(d, xs[sl], dys[sl], [ps.gview(nm + "weights") for nm in names[sl]],
+                                     [ps.gview(nm + "biases") for nm in names[sl]], ldx=Cp, ldy=dys[0].shape[-1])
+        else:
+            for i in range(1, n + 1):
+                sc = p + "resblock_%d/" % i
+                conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", flat(q["a"][i - 1]), flat(q["g_c1"][i]))
+                conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", flat(q["r"][i]), flat(q["g_c2"][i]))
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
         deconv_wgrad(ps, s % 1 + "weights", s % 1 + "biases", flat(q["a"][n]), flat(q["g_t1"]))
         deconv_wgrad(ps, s % 2 + "weights", s % 2 + "biases", flat(q["t1"]), flat(q["g_t2"]))

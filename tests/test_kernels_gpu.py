@@ -491,6 +491,29 @@ def test_wgrad_bf16_mfma_path(case):
     close(db, b.grad, 3e-4, "bf16 bgrad %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(5, 6, 8, 8, 64, 64, 3, 1), (1, 2, 16, 16, 64, 64, 3, 1), (3, 2, 16, 16, 64, 64, 4, 2)])
+def test_wgrad_grouped_matches_per_layer(case):
+    """tg_conv_wgrad_grouped == G independent tg_conv_wgrad calls (one launch for bf16 3x3 s1 layers, per-layer
+    launches for any other geometry): the res-block layers of generator_F share one geometry (lib/frvsr.py:50-57)."""
+    G, N, H, W, Cin, Cout, k, s = case
+    Ho, pt = K.same_pad(H, k, s)
+    Wo, pl = K.same_pad(W, k, s)
+    d = K.conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 0, TG_BF16, TG_BF16)
+    xs = [rnd(N, H, W, Cin, seed=10 + g).to(DEV, torch.bfloat16) for g in range(G)]
+    ys = [rnd(N, Ho, Wo, Cout, seed=50 + g).to(DEV, torch.bfloat16) for g in range(G)]
+    ref_w = [torch.zeros(k, k, Cin, Cout, device=DEV) for _ in range(G)]
+    ref_b = [torch.zeros(Cout, device=DEV) for _ in range(G)]
+    for g in range(G):
+        K.conv_wgrad(d, xs[g], ys[g], ref_w[g], ref_b[g])
+    got_w = [torch.full((k, k, Cin, Cout), 0.5, device=DEV) for _ in range(G)]      # accumulates: start from 0.5
+    got_b = [torch.zeros(Cout, device=DEV) for _ in range(G)]
+    K.conv_wgrad_grouped(d, xs, ys, got_w, got_b)
+    for g in range(G):
+        close(got_w[g] - 0.5, ref_w[g], 2e-4, "grouped dW layer %d %s" % (g, case))
+        close(got_b[g], ref_b[g], 2e-4, "grouped dbias layer %d %s" % (g, case))
+    assert not torch.equal(got_w[0], got_w[-1]) or G == 1
+
+
 def test_wgrad_bf16_padded_channel_stride():
     """First-layer case: 51 logical input channels stored with stride 56 (zero pad) -> dW is [3,3,51,64]."""
     N, H, W = 2, 8, 8
