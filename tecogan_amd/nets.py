@@ -127,8 +127,9 @@ class Generator:
         # forward, 12.3 us backward; FRVSR step 6.9 ms vs 5.7 ms same box): with 128 tiles of one wave per SIMD the
         # block is latency-bound and the halo recompute + second weight fetch cost more than one launch saves.
         self.fused = ps.act_dtype == torch.bfloat16 and bool(os.environ.get("TG_FUSED_RESBLOCK"))
-        # one grouped weight-gradient launch for all res-block convs (TG_WGRAD_GROUPED=0/1 is the A/B switch)
-        self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "0") == "1"
+        # one grouped weight-gradient launch for all res-block convs; TG_WGRAD_GROUPED=0 is the A/B switch
+        # (FRVSR step 4.25 -> 3.91 ms in the same session, profiles/r01o_grouped_wgrad_ab.txt)
+        self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "1") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None):
