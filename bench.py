@@ -1,18 +1,29 @@
 #!/usr/bin/env python
-"""bench.py -- headline metric of BASELINE.json: 4x SR training frames/s of the FRVSR/TecoGAN step on MI355X.
+"""bench.py -- headline metric of BASELINE.json: 4x SR training frames/s of the G+D TecoGAN step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
 
-A "step" is one full training step (forward, backward, [RCCL grad all-reduce], three TF-Adams) over one
+A "step" is one full training step (forward, hand-written backward, [RCCL grad all-reduce], three TF-Adams) over one
 synthetic batch; frames/s follows the reference's own accounting `batch_size * steps/s * frame_len`
-(reference main.py:369,407-411).  Default workload = BASELINE.json configs[1] (FRVSR training, runGan.py 4,
-B=4 x 10 frames of 32x32 LR per GPU, bf16 activations / fp32 master weights); `--config tecogan` runs
-configs[2] (runGan.py 3).  Weak scaling: per-GPU batch is fixed, `value` is the whole-job aggregate.
-Inputs are resident in HBM before the timed region.  rank 0 prints ONE JSON line.
+(reference main.py:369,407-411).  Default workload = BASELINE.json configs[2]: full TecoGAN (runGan.py 3: generator +
+spatio-temporal discriminator + VGG-19 feature loss + ping-pong), B=4 x 10 frames (19 with ping-pong) of 32x32 LR per
+GPU, num_resblock=16, bf16 activations / fp32 master weights.  `--config frvsr` times configs[1] instead.
+Weak scaling: per-GPU batch is fixed, `value` is the whole-job aggregate.  Inputs are resident in HBM before the timed
+region.  rank 0 prints ONE JSON line.
+
+At N=1 the same line carries sub-records (skip with --no-sub): `frvsr` (configs[1]), `inference_fps` (configs[4]:
+480x270 -> 1920x1080, 120 frames, reference accounting main.py:253-270 with the frames already in HBM),
+`fp32_parity_mode` (the mode the 1e-3 parity tests run in) and `bf16_vs_fp32` (error of the timed bf16 mode against the
+fp32 mode at the full BASELINE sizes).  `roofline` comes from the library's launch profiler (dispatch start/stop
+timestamps of every convolution / weight-gradient / warp launch of ONE eager step, csrc/runtime.hip) -- the same
+timestamps the committed rocprofv3 summaries in profiles/ are built from.
+PARITY NOTE: the CPU oracle these kernels are tested against is a restatement of TF1 semantics that was never checked
+against a run of real TensorFlow ("parity unpinned").
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -21,25 +32,36 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK = {"bf16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}    # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                           # HBM3E spec peak (about 6300 achievable), same guide
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--config", choices=["frvsr", "tecogan"], default="frvsr")
+    ap.add_argument("--config", choices=["tecogan", "frvsr"], default="tecogan")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="skip the frvsr / inference / fp32 sub-records")
+    ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=150.0, help="upper bound for the CPU-oracle baseline leg")
     return ap.parse_args()
 
 
 def make_flags(config):
     from tecogan_amd.flags import frvsr_flags, tecogan_flags
     return frvsr_flags() if config == "frvsr" else tecogan_flags()
+
+
+def workload_name(config, F):
+    head = ("configs[1]: FRVSR training (runGan.py 4, no Dst): " if config == "frvsr" else
+            "configs[2]: full TecoGAN training (runGan.py 3: G + spatio-temporal D + VGG + ping-pong): ")
+    return head + "B=%d x %d frames, %dx%d LR -> %dx%d HR per GPU, num_resblock=%d" % (
+        F.batch_size, F.RNN_N, F.crop_size, F.crop_size, 4 * F.crop_size, 4 * F.crop_size, F.num_resblock)
 
 
 def synthetic_batch(F, seed, device):
@@ -49,79 +71,216 @@ def synthetic_batch(F, seed, device):
     return x.to(device), y.to(device)
 
 
-def dominant_kernel_roofline(dtype, device):
-    """Time the generator's 3x3 64->64 convolution (the res-block workhorse: 20 of the 24 convs of every generator_F call,
-    and with mirrored taps their input gradients) at the training shape [4,32,32,64].  The launches are captured in a
-    hipGraph (as the product step is) and the graph is replayed between two HIP events recorded on the launch stream, so the
-    figure is GPU time per launch, not Python/ctypes dispatch time.  `traffic` = HBM-side bytes per launch from the
-    committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by tools/pmc_summary.py), null if absent."""
-    from tecogan_amd import kernels as K
-    from tecogan_amd._lib import ACT_RELU
+def new_engine(config, dtype, device, pg=None, use_graph=True):
+    from tecogan_amd.engine import TrainEngine
+    F = make_flags(config)
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
-    N, H, W, Cc = 4, 32, 32, 64
-    x = torch.randn(N, H, W, Cc, device=device).to(tdt)
-    w = (torch.randn(9, Cc, Cc, device=device) * 0.05).to(tdt)
-    b = torch.zeros(Cc, device=device)
-    out = torch.empty_like(x)
-    d = K.conv_desc(N, H, W, Cc, H, W, Cc, 3, 3, 1, 1, 1, 0, K.dt(x), K.dt(out), ACT_RELU)
-    per_graph, replays = 200, 10
-    side = torch.cuda.Stream(device=device)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(20):
-            K.conv_forward(d, x, w, b, None, None, out)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(per_graph):
-            K.conv_forward(d, x, w, b, None, None, out)
-    g.replay()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(replays):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
-    flops = 2.0 * N * H * W * Cc * 9 * Cc          # algorithmic: 2 * M * N * K = 302 MFLOP per launch
-    ach = flops / (us * 1e-6) / 1e12
-    traffic = None
+    return TrainEngine(F, device, gan=config != "frvsr", act_dtype=tdt, seed=42, process_group=pg, use_graph=use_graph)
+
+
+def time_steps(eng, steps, warmup, fence):
+    for _ in range(warmup):
+        eng.step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def err_stats(a, b):
+    """Error of `a` against `b`: max-norm relative and the per-pixel criterion of the parity tests."""
+    a, b = a.float(), b.float()
+    d = (a - b).abs()
+    mx = b.abs().max().clamp_min(1e-30)
+    per = d / torch.maximum(b.abs(), 1e-3 * mx)
+    return {"max_rel_to_max": float(d.max() / mx), "per_pixel_rel_p50": float(per.median()),
+            "per_pixel_rel_p99": float(per.flatten().kthvalue(max(1, int(per.numel() * 0.99))).values),
+            "per_pixel_rel_max": float(per.max())}
+
+
+# ----------------------------------------------------------------------------------------------------------
+# roofline: launch profiler over one eager step
+# ----------------------------------------------------------------------------------------------------------
+def load_pmc():
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            t = json.load(fh).get("conv3x3_tile_kernel@[4,32,32,64->64]_%s" % dtype)
-        if t:
-            traffic = t["fetch_bytes"] + t["write_bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return {"bound": "mfma", "kernel": "conv3x3_tile_kernel 3x3 64->64 @[4,32,32,64] %s (generator res-block conv)" % dtype,
-            "achieved": round(ach, 3), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK[dtype], 5),
-            "us_per_launch": round(us, 3), "flop_per_launch": flops,
-            "algorithmic_bytes": N * H * W * Cc * 2 * (2 if dtype == "bf16" else 4) + 9 * Cc * Cc * (2 if dtype == "bf16" else 4),
-            "traffic": traffic}
+        with open(PMC_FILE) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
 
 
-def cpu_baseline(config, seconds):
-    """The CPU oracle (torch restatement of the reference TF1 path) timed on this box's host cores."""
+def roofline_entry(e, steps, dtype, pmc):
+    us = e["total_us"] / max(e["calls"], 1)
+    out = {"kernel": e["name"], "calls_per_step": e["calls"] / steps, "us_per_launch": round(us, 3),
+           "us_per_step": round(e["total_us"] / steps, 1)}
+    c = pmc.get(e["name"], {})
+    if e["flops"] > 0:
+        ach = e["flops"] / e["total_us"] / 1e6                          # TFLOP/s
+        out.update(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[dtype], unit="TFLOP/s",
+                   frac=round(ach / PEAK_TFLOPS[dtype], 5), flop_per_launch=e["flops"] / e["calls"])
+    else:
+        ach = e["bytes"] / e["total_us"] / 1e3                          # GB/s
+        out.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 5))
+    out["algorithmic_bytes_per_launch"] = e["bytes"] / e["calls"]
+    out["traffic"] = c.get("hbm_bytes_per_launch")                     # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, or null
+    if "mfma_busy_frac" in c:
+        out["mfma_busy_frac"] = c["mfma_busy_frac"]                    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 * CUs)
+    if "rocprof_avg_us" in c:
+        out["rocprof_avg_us"] = c["rocprof_avg_us"]
+    return out
+
+
+def profile_training(config, dtype, device):
+    """One eager step of the timed workload under the library's launch profiler."""
+    from tecogan_amd import kernels as K
+    eng = new_engine(config, dtype, device, use_graph=False)
+    x, y = synthetic_batch(eng.F, 1234, device)
+    eng.set_batch(x, y)
+    for _ in range(2):
+        eng.step()
+    torch.cuda.synchronize()
+    K.prof_enable(True)
+    nstep = 2
+    for _ in range(nstep):
+        eng.step()
+    torch.cuda.synchronize()
+    K.prof_enable(False)
+    return K.prof_collect(), nstep
+
+
+def profile_inference(device, h=270, w=480, frames=6):
+    from tecogan_amd import kernels as K
+    from tecogan_amd.infer import InferenceEngine
+    eng = InferenceEngine(16, h, w, device, torch.bfloat16, use_graph=False)
+    seq = torch.rand(4, 1, h, w, 3, device=device)
+    for i in range(3):
+        eng.step(seq[i % 4])
+    torch.cuda.synchronize()
+    K.prof_enable(True)
+    for i in range(frames):
+        eng.step(seq[i % 4])
+    torch.cuda.synchronize()
+    K.prof_enable(False)
+    return K.prof_collect(), frames
+
+
+def build_roofline(config, dtype, device, with_inference):
+    pmc = load_pmc()
+    ents, nstep = profile_training(config, dtype, device)
+    tot = sum(e["total_us"] for e in ents)
+    dom = ents[0]
+    r = roofline_entry(dom, nstep, dtype, pmc)
+    r["share_of_profiled_kernel_time"] = round(dom["total_us"] / tot, 4)
+    r["source"] = ("dispatch start/stop timestamps (hipExtLaunchKernel events on the launch stream) of every instrumented "
+                   "launch of %d eager steps of the timed workload; committed rocprofv3 summaries: profiles/r02_*" % nstep)
+    r["top_kernels"] = [roofline_entry(e, nstep, dtype, pmc) for e in ents[1:6]]
+    mf = [e for e in ents if e["flops"] > 0]
+    r["all_mfma_kernels"] = {"flop_per_step": sum(e["flops"] for e in mf) / nstep,
+                             "us_per_step": round(sum(e["total_us"] for e in mf) / nstep, 1),
+                             "achieved_TFLOPs": round(sum(e["flops"] for e in mf) / max(sum(e["total_us"] for e in mf), 1e-9) / 1e6, 2)}
+    if with_inference:
+        ients, nfr = profile_inference(device)
+        hb = [e for e in ients if e["name"].startswith("warp_s2d_fwd")]
+        if hb:
+            h = roofline_entry(hb[0], nfr, "bf16", pmc)
+            h["workload"] = "configs[4] inference 480x270 -> 1920x1080, the fused warp + space-to-depth kernel"
+            r["hbm_kernel"] = h
+        r["inference_top_kernels"] = [roofline_entry(e, nfr, "bf16", pmc) for e in ients[:5]]
+    return r
+
+
+# ----------------------------------------------------------------------------------------------------------
+# sub-records (N = 1)
+# ----------------------------------------------------------------------------------------------------------
+def sub_inference(device, h=270, w=480, frames=120):
+    """configs[4]: the 120-frame stream of reference main.py:253-260 (per-frame FNet + warp + generator, state carried on
+    the device); fps = frames / total time, first (cold-state) frame included as the reference does."""
+    from tecogan_amd.infer import InferenceEngine
+    eng = InferenceEngine(16, h, w, device, torch.bfloat16)
+    seq = torch.rand(8, 1, h, w, 3, device=device)
+    eng.step(seq[0])                                  # captures the hipGraph (not a timed frame; the reference's session
+    eng.reset()                                       # construction is not timed either)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        eng.step(seq[i % 8])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "configs[4]: 4x inference %dx%d -> %dx%d, %d-frame stream, hipGraph step, bf16, num_resblock=16"
+                        % (w, h, 4 * w, 4 * h, frames),
+            "value": round(frames / dt, 2), "unit": "HR frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
+            "frames": frames, "data": "synthetic uniform LR frames resident in HBM; HR frames stay on the device"}
+
+
+def first_step_frames(config, dtype, device):
+    """HR frames of the first training step from damped xavier weights (params.damp_values: the well-conditioned regime
+    the BASELINE-size parity tests use) on the seeded synthetic batch."""
+    from tecogan_amd.params import damp_values
+    e = new_engine(config, dtype, device, use_graph=False)
+    e.ps.load(damp_values(e.ps.state_dict()))
+    x, y = synthetic_batch(e.F, 1234, device)
+    e.step(x, y)
+    torch.cuda.synchronize()
+    return e.gen.clone()
+
+
+def sub_records(device, fence):
+    out = {}
+    # configs[1] FRVSR
+    e = new_engine("frvsr", "bf16", device)
+    x, y = synthetic_batch(e.F, 1234, device)
+    e.set_batch(x, y)
+    dt = time_steps(e, 200, 10, fence)
+    out["frvsr"] = {"workload": workload_name("frvsr", e.F), "value": round(e.B * e.T * 200 / dt, 2), "unit": "frames/s",
+                    "ms_per_step": round(dt / 200 * 1e3, 4), "steps": 200, "dtype": "bf16"}
+    del e
+    # fp32 parity mode of the headline workload
+    e = new_engine("tecogan", "f32", device)
+    x, y = synthetic_batch(e.F, 1234, device)
+    e.set_batch(x, y)
+    dt = time_steps(e, 20, 3, fence)
+    out["fp32_parity_mode"] = {"workload": workload_name("tecogan", e.F), "ms_per_step": round(dt / 20 * 1e3, 4),
+                               "value": round(e.B * e.T * 20 / dt, 2), "unit": "frames/s", "steps": 20,
+                               "note": "fp32 activations + exact-fp32 MFMA: the mode the 1e-3 parity tests run in"}
+    del e
+    # error of the timed bf16 mode against the fp32 mode at the full BASELINE sizes
+    out["bf16_vs_fp32"] = {
+        "C3_tecogan_gen_outputs": err_stats(first_step_frames("tecogan", "bf16", device), first_step_frames("tecogan", "f32", device)),
+        "C2_frvsr_gen_outputs": err_stats(first_step_frames("frvsr", "bf16", device), first_step_frames("frvsr", "f32", device)),
+        "note": "HR frames (all 19 / 10 recurrent frames) of the bf16 mode against the fp32 mode after one step from identical "
+                "damped-xavier weights and batch; per_pixel_rel = |a-b| / max(|b|, 1e-3 max|b|)"}
+    out["inference_fps"] = sub_inference(device)
+    return out
+
+
+def cpu_baseline(config, budget_s):
+    """The CPU oracle (torch restatement of the reference TF1 path; the reference itself needs TF1) timed on this box's
+    host cores: median of 5 steps after 2 warm-ups on a bounded sample of the workload (ONE sequence instead of the
+    batch of 4; same frames, same networks)."""
     from oracle import teco as OT
-    F = OT.frvsr_flags() if config == "frvsr" else OT.default_flags()
     gan = config != "frvsr"
+    F = OT.frvsr_flags(batch_size=1) if not gan else OT.default_flags(batch_size=1)
     S = OT.State(F, seed=42, gan=gan)
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(F.batch_size, F.RNN_N, F.crop_size, F.crop_size, 3, generator=g)
     y = torch.rand(F.batch_size, F.RNN_N, 4 * F.crop_size, 4 * F.crop_size, 3, generator=g) * 2 - 1
     frame_len = 2 * F.RNN_N - 1 if F.pingpang else F.RNN_N
-    OT.train_step(S, x, y)                             # warm-up
-    n, t0 = 0, time.time()
-    while n < 5 and (time.time() - t0) < seconds:
+    t_start = time.time()
+    times = []
+    for i in range(7):
+        t0 = time.time()
         OT.train_step(S, x, y)
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(F.batch_size * frame_len * n / dt, 3), "unit": "frames/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full %s training steps (B=%d, %d frames) of the torch-CPU oracle after 1 warm-up" %
-                      (n, config, F.batch_size, frame_len)}
+        if i >= 2:
+            times.append(time.time() - t0)
+        if len(times) >= 3 and time.time() - t_start > budget_s:
+            break
+    med = statistics.median(times)
+    return {"value": round(F.batch_size * frame_len / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "step_seconds_median": round(med, 3),
+            "sample": "median of %d %s training steps of the torch-CPU oracle after 2 warm-ups, B=1 sequence x %d frames "
+                      "(a quarter of the timed batch), %d torch threads" % (len(times), config, frame_len, torch.get_num_threads())}
 
 
 def main():
@@ -137,6 +296,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     pg = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -146,15 +306,6 @@ def main():
         else:
             dist.init_process_group(backend)
         pg = dist.group.WORLD
-    from tecogan_amd.engine import TrainEngine
-    F = make_flags(a.config)
-    gan = a.config != "frvsr"
-    tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    eng = TrainEngine(F, device, gan=gan, act_dtype=tdt, seed=42, process_group=pg, use_graph=not a.no_graph)
-    x, y = synthetic_batch(F, 1234 + rank, device)
-    eng.set_batch(x, y)
-    for _ in range(a.warmup):
-        eng.step()
 
     def fence():
         torch.cuda.synchronize()
@@ -162,12 +313,11 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        eng.step()
-    fence()
-    dt = time.perf_counter() - t0
+    eng = new_engine(a.config, a.dtype, device, pg, use_graph=not a.no_graph)
+    F = eng.F
+    x, y = synthetic_batch(F, 1234 + rank, device)
+    eng.set_batch(x, y)
+    dt = time_steps(eng, a.steps, a.warmup, fence)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -177,20 +327,27 @@ def main():
     if rank == 0:
         L = eng.losses()
         assert all(v == v for v in L.values()), "NaN in losses: %s" % L
-        line = {"metric": "4x SR train frames/sec (G+D step)", "value": round(value, 2), "unit": "frames/s",
-                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+        cfg = {"workload": workload_name(a.config, F), "global_batch": world * F.batch_size,
+               "frames_per_step": world * F.batch_size * frame_len, "parallelism": "dp%d" % world,
+               "hipgraph": not a.no_graph}
+        if world > 1:
+            cfg["collective_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
+            cfg["ranks"] = torch.distributed.get_world_size()
+            cfg["allreduce_bytes_per_step"] = eng.allreduce_bytes()
+            cfg["exchange"] = eng.exchange_mode
+        line = {"metric": "4x SR train frames/sec (G+D step)" if a.config == "tecogan" else "4x SR train frames/sec (FRVSR step, no D)",
+                "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": a.dtype,
                 "data": "synthetic (uniform LR/HR sequences, seeded xavier weights%s)" %
                         (", He-normal VGG-19 stand-in" if eng.use_vgg else ""),
-                "config": {"workload": ("configs[1]: FRVSR training (runGan.py 4): " if a.config == "frvsr" else
-                                        "configs[2]: TecoGAN training (runGan.py 3: G + Dst + VGG + ping-pong): ") +
-                                       "B=%d x %d frames, %dx%d LR -> %dx%d HR per GPU, num_resblock=%d" %
-                                       (F.batch_size, F.RNN_N, F.crop_size, F.crop_size, 4 * F.crop_size, 4 * F.crop_size,
-                                        F.num_resblock),
-                           "global_batch": world * F.batch_size, "frames_per_step": world * F.batch_size * frame_len,
-                           "parallelism": "dp%d" % world, "hipgraph": not a.no_graph},
+                "config": cfg, "parity": "HIP == CPU oracle (tests/); oracle vs real TensorFlow: unpinned",
                 "losses": {k: round(v, 6) for k, v in L.items() if v != 0.0}}
-        line["roofline"] = dominant_kernel_roofline(a.dtype, device)
+        del eng
+        if world == 1 and not a.no_sub:
+            line["sub"] = sub_records(device, fence)
+        if not a.no_roofline:
+            line["roofline"] = build_roofline(a.config, a.dtype, device, with_inference=(world == 1 and not a.no_sub))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_seconds)
         print(json.dumps(line), flush=True)

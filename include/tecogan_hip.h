@@ -11,7 +11,9 @@
  *     void*), hence hipGraph-capturable;
  *   - every pointer is a caller-owned DEVICE pointer, NHWC-contiguous, 16-byte
  *     aligned; dtype codes: TG_F32 = 0, TG_BF16 = 1;
- *   - re-entrant, no mutable globals except the thread-local last-error string.
+ *   - re-entrant: the only process-wide state is (a) the thread-local last-error string, (b) one-time, call_once-guarded
+ *     kernel attributes, (c) A/B environment switches (TG_*) read once on first use and constant afterwards, and
+ *     (d) the opt-in launch profiler's record list (tg_prof_*, mutex-protected).
  */
 #ifndef TECOGAN_HIP_H
 #define TECOGAN_HIP_H
@@ -39,6 +41,20 @@ extern "C" {
 
 int         tg_version(void);
 const char* tg_last_error_string(void);
+
+/* Built-in launch profiler (measurement mode, off by default; no counterpart in the reference, which only prints
+ * wall-clock rates: main.py:270,407-411).  While enabled, every convolution / weight-gradient / warp launch of this
+ * library carries a start/stop event pair (the dispatch's own timestamps, as rocprofv3 --kernel-trace reads them);
+ * tg_prof_collect synchronises, aggregates per kernel name and clears the record list.  Eager streams only. */
+typedef struct tg_prof_entry {
+  char    name[96];      /* kernel template + tile, e.g. "conv3x3_tile<bf16,bf16,16,64>" */
+  int64_t calls;
+  double  total_us;      /* sum of dispatch durations */
+  double  flops;         /* sum of algorithmic FLOPs (2*M*N*K), 0 for data-movement kernels */
+  double  bytes;         /* sum of algorithmic bytes (inputs + outputs + weights once) */
+} tg_prof_entry;
+int tg_prof_enable(int on);
+int tg_prof_collect(tg_prof_entry* out, int max_entries, int* count /* total distinct kernels */);
 
 /* ------------------------------------------------------------------------ *
  * Convolution engine (implicit GEMM on MFMA).
@@ -147,9 +163,11 @@ int tg_upscale4_backward(const float* d_out, float* d_in, int B, int h, int w, i
 
 /* slim.max_pool2d 2x2 s2 VALID (lib/ops.py:92-93).  bwd routes to the first max in scan order. */
 int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream);
-/* act/alpha: derivative of the activation that produced `in`, fused into the routed gradient. */
+/* act/alpha: derivative of the activation that produced `in`, fused into the routed gradient.
+ * add (nullable, [N,H,W,C]): a second gradient w.r.t. `in` itself (a VGG feature tap, lib/Teco.py:346-352):
+ * d_in = (route(d_out) + add) * act'(in). */
 int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W, int C,
-                         int act, float alpha, void* stream);
+                         int act, float alpha, const void* add, void* stream);
 
 /* tf.image.resize_images x2, legacy bilinear (lib/frvsr.py:21-22). */
 int tg_upsample2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream);
@@ -173,6 +191,12 @@ int tg_act_backward(const void* d_out, const void* y /*nullable*/, void* d_in, i
 int tg_concat2_pad(const float* a, int Ca, const float* b /*nullable*/, int Cb, void* out, int out_dtype, int Cpad,
                    int64_t npix, float scale /*applied to every value*/, void* stream);
 
+/* Frame-major gather of a batch-major sequence: dst[t][b][:] = src[b][idx[t]][:] (src [B][T0][frame_elems],
+ * dst [T][B][frame_elems], idx = HOST array of T <= 64 frame indices): the ping-pong extension
+ * tf.concat(r, r[:, -2::-1]) of lib/Teco.py:80-85 and the [B,T] -> [T,B] layout of this path in one pass. */
+int tg_seq_gather(const float* src, float* dst, int B, int T0, int T, int64_t frame_elems, const int* idx,
+                  void* stream);
+
 /* out (=|+=) alpha*a + beta*b   (loss-gradient seeds: lib/Teco.py:320-331) */
 int tg_lincomb(const float* a, const float* b /*nullable*/, float* out, int64_t n, float alpha, float beta,
                int accumulate, void* stream);
@@ -189,10 +213,11 @@ int tg_schedule_step(double* state, float* hyper, int nopt, int gated_opt, const
 /* slim.batch_norm(train, scale=False, eps) + LeakyReLU (lib/ops.py:88-90, lib/Teco.py:38-39).
  * stats: [2][C] fp32 (mean, biased var) written by forward, read by backward. */
 int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t rows, int C, const float* beta, float eps,
-                        float alpha, float* stats, float* moving /*[2][C] nullable, decay .9*/, void* stream);
+                        float alpha, float* stats, float* moving /*[2][C] nullable, decay .9*/,
+                        int prezeroed /*1: caller guarantees stats == 0 on entry (no memset node)*/, void* stream);
 int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_y, void* d_x, int dtype, int64_t rows, int C,
                          const float* stats, float eps, float alpha, float* d_beta /*+=*/,
-                         float* ws /*[2][C] scratch*/, void* stream);
+                         float* ws /*[2][C] scratch*/, int prezeroed /*1: ws == 0 on entry*/, void* stream);
 
 /* tf.train.AdamOptimizer step over a flat fp32 buffer (lib/Teco.py:425,439-440), TF flavour:
  * p -= lr_t * m / (sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) read from `hyper` = device

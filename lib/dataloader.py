@@ -105,16 +105,18 @@ class SceneSequences:
         return _ops.preprocessLR(lr), tgt
 
 
-def frvsr_gpu_data_loader(FLAGS, useValData_ph=None, device="cuda", synthetic=False):
+def frvsr_gpu_data_loader(FLAGS, useValData_ph=None, device="cuda", synthetic=False, rank=0):
     """reference lib/dataloader.py:276-348.  Returns Data(paths_HR, s_inputs, s_targets, image_count,
     steps_per_epoch) where s_inputs / s_targets hold the first batch and `Data.loader.next_batch()` /
     `Data.val_loader.next_batch()` stream the following ones."""
+    # data-parallel training: every rank draws its OWN stream (seed offset by the rank) -- with identical batches the
+    # averaged gradient would equal a single-GPU step and the extra GPUs would be redundant compute
     if synthetic or FLAGS.input_video_dir == '':
-        train = val = SyntheticSequences(FLAGS, device)
+        train = val = SyntheticSequences(FLAGS, device, seed=1234 + rank)
     else:
-        train = SceneSequences(FLAGS, device, FLAGS.str_dir, FLAGS.end_dir, FLAGS.rand_seed)
+        train = SceneSequences(FLAGS, device, FLAGS.str_dir, FLAGS.end_dir, FLAGS.rand_seed + 1000 * rank)
         try:
-            val = SceneSequences(FLAGS, device, FLAGS.end_dir + 1, FLAGS.end_dir_val, FLAGS.rand_seed + 1)
+            val = SceneSequences(FLAGS, device, FLAGS.end_dir + 1, FLAGS.end_dir_val, FLAGS.rand_seed + 1 + 1000 * rank)
         except ValueError:
             val = train
     x, y = train.next_batch()

@@ -44,7 +44,8 @@ def save_checkpoint(eng, output_dir, step):
     path = os.path.join(output_dir, "model-%d" % step)
     torch.save({"variables": eng.ps.state_dict(), "adam_m": eng.ps.m.cpu(), "adam_v": eng.ps.v.cpu(),
                 "sched": eng.sched.cpu(), "global_step": step}, path)
-    save_bundle(path, eng.ps, step, beta1=eng.F.beta)
+    steps = {scope: int(eng.sched[8 + 2 * k].item()) for k, scope in enumerate(eng.opt_scopes)}
+    save_bundle(path, eng.ps, step, beta1=eng.F.beta, adam_steps=steps, tb_ema=float(eng.sched[1].item()))
     return path
 
 
@@ -62,10 +63,19 @@ def restore_training(eng, FLAGS):
                     eng.ps.view(name, eng.ps.v).copy_(ck["adam_v"][name])
             if "global_step" in ck:
                 eng.sched[0] = float(ck["global_step"])
+            # Adam bias-correction counters (from <scope>/beta1_power) and the t_balance EMA: without them the first
+            # resumed steps would run at lr*sqrt(1-b2)/(1-b1) ~ 0.32 lr against converged moments and the D-gate
+            # would restart from tb = 0 (always open)
+            for k, scope in enumerate(eng.opt_scopes):
+                t = ck.get("adam_steps", {}).get(scope, ck.get("global_step", 0))
+                eng.sched[8 + 2 * k] = float(t)
+            if "tb_ema" in ck:
+                eng.sched[1] = float(ck["tb_ema"])
         else:
             eng.ps.m.copy_(ck["adam_m"])
             eng.ps.v.copy_(ck["adam_v"])
             eng.sched.copy_(ck["sched"])
+        eng.host_step = int(eng.sched[0].item())              # dt_ratio fade-in continues where it stopped (Teco.py:379)
         return
     print('Loading weights from the pre-trained model to start a new training...')
     vals, zero = {}, 0
@@ -133,7 +143,7 @@ def run_training(FLAGS):
         pg = dist.group.WORLD
     gan = FLAGS.ratio > 0                                       # reference main.py:283-286
     tdt = torch.bfloat16 if FLAGS.act_dtype == "bf16" else torch.float32
-    rdata = frvsr_gpu_data_loader(FLAGS, device=dev, synthetic=FLAGS.synthetic)
+    rdata = frvsr_gpu_data_loader(FLAGS, device=dev, synthetic=FLAGS.synthetic, rank=rank)
     eng = TrainEngine(FLAGS, dev, gan=gan, act_dtype=tdt, seed=FLAGS.rand_seed + 41, process_group=pg)
     print('Finish building the network.')
     if FLAGS.checkpoint is not None:

@@ -127,5 +127,30 @@ def main(check_only=False):
         print("wrote", GOLD)
 
 
+def calendar_fixture(check_only=False):
+    """The reference's only real-data fixture: LR/calendar/0001..0041.png (runGan.py case 1, main.py:185-270), decoded
+    to RGB uint8 exactly as the loader does (cv.imread(...)[:, :, ::-1] of lib/dataloader.py:32 == PIL RGB).  The GPU box
+    has no /root/reference, so the decoded clip is committed (tests/golden/calendar_lr.npz, 41 x 144 x 180 x 3)."""
+    import hashlib
+    from PIL import Image
+    d = "/root/reference/LR/calendar"
+    names = sorted(f for f in os.listdir(d) if f.endswith(".png"))
+    names.sort(key=lambda f: int("".join(ch for ch in f if ch.isdigit()) or -1))
+    frames = np.stack([np.asarray(Image.open(os.path.join(d, n)).convert("RGB")) for n in names])
+    png0 = hashlib.sha256(open(os.path.join(d, names[0]), "rb").read()).hexdigest()
+    rgb0 = hashlib.sha256(frames[0].tobytes()).hexdigest()
+    assert frames.shape == (41, 144, 180, 3) and frames.dtype == np.uint8
+    assert png0.startswith("0be6a70a") and png0.endswith("754c35"), png0          # SURVEY.md 8c.10
+    out = os.path.join(GOLD, "calendar_lr.npz")
+    if check_only:
+        got = np.load(out)
+        assert np.array_equal(got["frames"], frames) and str(got["png0_sha256"]) == png0
+        print("calendar fixture matches /root/reference/LR/calendar")
+        return
+    np.savez_compressed(out, frames=frames, names=np.array(names), png0_sha256=np.array(png0), rgb0_sha256=np.array(rgb0))
+    print("wrote", out, frames.shape)
+
+
 if __name__ == "__main__":
     main(check_only="--check" in sys.argv)
+    calendar_fixture(check_only="--check" in sys.argv)

@@ -41,7 +41,8 @@ class State:
         self.P.update(NN.init_params(NN.generator_spec(flags.num_resblock), seed, dtype))
         self.P.update(NN.init_params(NN.fnet_spec(), seed + 1, dtype))
         if gan:
-            self.P.update(NN.init_params(NN.discriminator_spec(), seed + 2, dtype))
+            # Dt_mergeDs=False: temporal-only D on the 9 warped channels (lib/Teco.py:246-250,269-272)
+            self.P.update(NN.init_params(NN.discriminator_spec(27 if flags.Dt_mergeDs else 9), seed + 2, dtype))
         self.vgg = NN.init_params(NN.vgg_spec(), seed + 3, dtype, vgg_he=True) if flags.vgg_scaling > 0 else None
         self.m = {k: torch.zeros_like(v) for k, v in self.P.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.P.items()}

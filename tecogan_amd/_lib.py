@@ -41,7 +41,7 @@ SIGNATURES = {
     "tg_upscale4_forward": [_P, _P, _I, _I, _I, _I, _F, _P],
     "tg_upscale4_backward": [_P, _P, _I, _I, _I, _I, _F, _P],
     "tg_maxpool2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "tg_maxpool2_backward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "tg_maxpool2_backward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P],
     "tg_upsample2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tg_upsample2_backward": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P],
     "tg_bicubic_add_preprocess": [_P, _P, _I, _I, _P, _I, _I, _I, _P],
@@ -50,8 +50,9 @@ SIGNATURES = {
     "tg_lincomb": [_P, _P, _P, _L, _F, _F, _I, _P],
     "tg_affine": [_P, _P, _L, _F, _F, _P],
     "tg_schedule_step": [_P, _P, _I, _I, _P, _F, _F, _F, _P],
-    "tg_bn_lrelu_forward": [_P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P],
-    "tg_bn_lrelu_backward": [_P, _P, _P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P],
+    "tg_bn_lrelu_forward": [_P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _I, _P],
+    "tg_bn_lrelu_backward": [_P, _P, _P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _I, _P],
+    "tg_seq_gather": [_P, _P, _I, _I, _I, _L, _P, _P],
     "tg_adam_tf": [_P, _P, _P, _P, _L, _P, _F, _P],
     "tg_sum_sq_diff": [_P, _P, _I, _L, _F, _P, _P],
     "tg_sum_abs_diff": [_P, _P, _I, _L, _F, _P, _P],
@@ -64,6 +65,16 @@ SIGNATURES = {
     "tg_pack_d_input_forward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "tg_pack_d_input_backward": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
+
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("calls", C.c_int64), ("total_us", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+SIGNATURES["tg_prof_enable"] = [_I]
+SIGNATURES["tg_prof_collect"] = [C.POINTER(ProfEntry), _I, C.POINTER(C.c_int)]
 
 _lib = None
 

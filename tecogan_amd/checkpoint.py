@@ -18,6 +18,11 @@ import torch
 from . import tf_bundle
 
 OPT_SCOPE = {"generator": "generator_train", "fnet": "generator_train", "tdiscriminator": "tdicriminator_train"}
+# TF names of each optimiser's bias-correction accumulators: the generator and FNet AdamOptimizers are both created under
+# variable_scope('generator_train') (lib/Teco.py:438-440), so the second one gets the "_1" suffix.
+POWER_KEY = {"generator": "generator_train/beta1_power", "fnet": "generator_train/beta1_power_1",
+             "tdiscriminator": "tdicriminator_train/beta1_power"}
+TB_EMA_KEY = "tecogan_amd/t_balance_ema"      # this backend's key for the EMA(0.99) shadow of t_balance (Teco.py:415-417)
 
 
 def _is_torch_file(path):
@@ -39,7 +44,23 @@ def load_variables(path):
         raise ValueError("checkpoint %s not found (neither a torch file nor a TensorFlow bundle prefix)" % path)
     r = tf_bundle.BundleReader(path)
     variables, m, v, extra = OrderedDict(), {}, {}, {}
+    import math
+    steps = {}
     for key in r.keys():
+        if key == TB_EMA_KEY:
+            extra["tb_ema"] = float(r.get(key))
+            continue
+        for scope, pk in POWER_KEY.items():
+            if key == pk:                    # TF stores beta1^(t+1) after t updates
+                p1 = float(r.get(key))
+                b1 = float(r.get(TB_EMA_KEY + "/beta1")) if (TB_EMA_KEY + "/beta1") in r.keys() else 0.9
+                if 0.0 < p1 < 1.0:
+                    steps[scope] = max(int(round(math.log(p1) / math.log(b1))) - 1, 0)
+    if steps:
+        extra["adam_steps"] = steps
+    for key in r.keys():
+        if key.startswith(TB_EMA_KEY):
+            continue
         if key.endswith("/Adam") or key.endswith("/Adam_1"):
             base = key.rsplit("/", 1)[0]
             for scope in set(OPT_SCOPE.values()):                     # strip the optimizer's variable scope
@@ -60,8 +81,11 @@ def load_variables(path):
     return variables, extra
 
 
-def save_bundle(prefix, ps, global_step, beta1=0.9, beta2=0.999):
-    """Write the parameter store (variables + Adam slots + global_step) as a TensorFlow tensor bundle."""
+def save_bundle(prefix, ps, global_step, beta1=0.9, beta2=0.999, adam_steps=None, tb_ema=None):
+    """Write the parameter store (variables + Adam slots + global_step) as a TensorFlow tensor bundle.
+    adam_steps: scope -> number of Adam updates applied (the gated discriminator lags global_step); tb_ema: the EMA shadow
+    of t_balance.  Interoperability note: variables (inference / pre_trained_model restore) follow TF's names exactly; the
+    optimiser-state names follow the reference graph as far as it can be read offline (no TF-written file to check against)."""
     out = OrderedDict()
     for name, e in ps.entries.items():
         out[name] = ps.view(name).detach().cpu().numpy()
@@ -70,8 +94,11 @@ def save_bundle(prefix, ps, global_step, beta1=0.9, beta2=0.999):
             out["%s/%s/Adam" % (scope, name)] = ps.view(name, ps.m).detach().cpu().numpy()
             out["%s/%s/Adam_1" % (scope, name)] = ps.view(name, ps.v).detach().cpu().numpy()
     out["global_step"] = np.asarray(int(global_step), dtype=np.int64)
-    t = max(int(global_step), 0)
-    for scope in sorted(set(OPT_SCOPE[e["scope"]] for e in ps.entries.values() if e["scope"] in OPT_SCOPE)):
-        out[scope + "/beta1_power"] = np.asarray(beta1 ** (t + 1), dtype=np.float32)   # TF stores beta^(t+1) after t updates
-        out[scope + "/beta2_power"] = np.asarray(beta2 ** (t + 1), dtype=np.float32)
+    for scope in sorted(set(e["scope"] for e in ps.entries.values() if e["scope"] in POWER_KEY)):
+        t = max(int((adam_steps or {}).get(scope, global_step)), 0)
+        out[POWER_KEY[scope]] = np.asarray(beta1 ** (t + 1), dtype=np.float32)         # TF stores beta^(t+1) after t updates
+        out[POWER_KEY[scope].replace("beta1_power", "beta2_power")] = np.asarray(beta2 ** (t + 1), dtype=np.float32)
+    out[TB_EMA_KEY + "/beta1"] = np.asarray(beta1, dtype=np.float32)
+    if tb_ema is not None:
+        out[TB_EMA_KEY] = np.asarray(tb_ema, dtype=np.float32)
     return tf_bundle.write_bundle(prefix, out)

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libtecogan_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/tecogan_hip.h"
@@ -17,6 +18,18 @@ void tg_set_error(const char* fmt, ...);
       tg_set_error("%s: %s", __func__, msg);                      \
       return TG_EINVAL;                                           \
     }                                                             \
+  } while (0)
+
+// ---- instrumented launch (csrc/runtime.hip): identical to hipLaunchKernelGGL unless tg_prof_enable(1) was called, in
+// which case the dispatch carries a start/stop event pair and is booked under NAME with its algorithmic FLOPs / bytes.
+bool tg_prof_slot(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
+#define TG_LAUNCH(NAME, FLOPS, BYTES, kern, grid, block, lds, st, ...)                                   \
+  do {                                                                                                   \
+    hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                           \
+    if (tg_prof_slot(NAME, (double)(FLOPS), (double)(BYTES), &pe0_, &pe1_))                              \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, pe0_, pe1_, 0, __VA_ARGS__);                     \
+    else                                                                                                 \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                       \
   } while (0)
 
 #define TG_CHECK_LAUNCH()                                         \

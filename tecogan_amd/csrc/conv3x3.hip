@@ -16,6 +16,7 @@
 //     conflict-free; the epilogue (bias, activation, residual, act-grad mask) is the engine's.
 // fp32 uses v_mfma_f32_16x16x4_f32 (exact, K-permuted as in conv_igemm.hip), bf16 v_mfma_f32_16x16x32_bf16.
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -307,12 +308,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
 template <typename TIn, typename TOut, int TH, int BN, int ABL = 0>
 static void launch3(Conv3P p, hipStream_t st) {
   constexpr int LDS = ((TH + 2) * 18 + 9 * BN) * 144;
-  static bool attr_set = false;
   auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN, ABL>;
-  if (!attr_set) {
+  static std::once_flag attr_once;               // one-time, thread-safe: raise the dynamic-LDS limit of this instantiation
+  std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  });
   p.tiles_y = (p.H + TH - 1) / TH;
   p.tiles_x = (p.W + 15) / 16;
   p.ntiles = p.N * p.tiles_y * p.tiles_x;
@@ -320,7 +320,17 @@ static void launch3(Conv3P p, hipStream_t st) {
   int gx = p.ntiles;
   const int per = 256 / nt > 0 ? 256 / nt : 1;        // one workgroup per CU (LDS-bound residency)
   if (gx > per) gx = per;
-  hipLaunchKernelGGL(kern, dim3(gx, nt), dim3(256), LDS, st, p);
+  static const char* const pname = [] {
+    static char b[96];
+    snprintf(b, sizeof(b), "conv3x3_tile<%s,%s,%d,%d>", sizeof(TIn) == 2 ? "bf16" : "f32", sizeof(TOut) == 2 ? "bf16" : "f32",
+             TH, BN);
+    return (const char*)b;
+  }();
+  const double px = (double)p.N * p.H * p.W;
+  TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
+            px * (p.Cin * sizeof(TIn) + p.Cout * sizeof(TOut) * (1 + (p.res != nullptr) + (p.aux != nullptr))) +
+                9.0 * p.Cin * p.Cout * sizeof(TIn),
+            kern, dim3(gx, nt), dim3(256), LDS, st, p);
 }
 
 template <typename TIn, typename TOut>
@@ -368,7 +378,10 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
     else launch3<TIn, TOut, 4, 32>(p, st);
   } else if (p.Cin * (int)sizeof(TIn) > 128) {
     // multi-chunk (Cin > one 128-B chunk): the weight panel is re-staged per (tile, chunk) -> largest pixel tile
-    if (pix * nt64 >= (int64_t)16 * 16 * 256) launch3<TIn, TOut, 16, 64>(p, st);
+    // TG_C3_MAXTH=8 (A/B switch): <8,64> instead of <16,64> -- 109 KB LDS / ~300 registers instead of 130 KB / ~400, which
+    // leaves room on the CU for a co-resident workgroup of the latency-bound <4,16> chain kernel (36 KB / 120 registers)
+    static const int maxth = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
+    if (maxth >= 16 && pix * nt64 >= (int64_t)16 * 16 * 256) launch3<TIn, TOut, 16, 64>(p, st);
     else if (pix * nt64 >= (int64_t)8 * 16 * 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (pix * nt64 >= (int64_t)4 * 16 * 256) launch3<TIn, TOut, 4, 64>(p, st);
     else launch3<TIn, TOut, 2, 64>(p, st);
@@ -379,7 +392,9 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
     auto blocks = [&](int th, int bn) {
       return (int64_t)p.N * ((p.H + th - 1) / th) * ((p.W + 15) / 16) * ((p.Cout + bn - 1) / bn);
     };
-    if (blocks(16, 64) >= 256) launch3<TIn, TOut, 16, 64>(p, st);
+    static const int maxth = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
+    if (maxth >= 16 && blocks(16, 64) >= 256) launch3<TIn, TOut, 16, 64>(p, st);
+    else if (maxth < 16 && blocks(8, 64) >= 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (blocks(16, 32) >= 256) launch3<TIn, TOut, 16, 32>(p, st);
     else if (blocks(8, 32) >= 256) launch3<TIn, TOut, 8, 32>(p, st);
     else if (blocks(8, 16) >= 256) launch3<TIn, TOut, 8, 16>(p, st);
@@ -527,8 +542,11 @@ static int conv3x3_c8_try(const tg_conv_desc* d, const void* in, const void* wei
   p.w_bytes = (unsigned)((int64_t)9 * d->Cout * 16);
   const int64_t blocks = (int64_t)p.N * p.tiles_y * p.tiles_x;
   if (blocks >= ((int64_t)1 << 31)) return 0;
-  if (d->Cout == 32) hipLaunchKernelGGL(conv3x3_c8_kernel<2>, dim3((unsigned)blocks, 1), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(conv3x3_c8_kernel<4>, dim3((unsigned)blocks, d->Cout / 64), dim3(256), 0, st, p);
+  const double px = (double)p.N * p.H * p.W;
+  const double fl = 2.0 * px * p.Cout * 9.0 * 8.0;
+  const double by = px * (16.0 + 2.0 * p.Cout * (1 + (res != nullptr) + (aux != nullptr))) + 9.0 * 16.0 * p.Cout;
+  if (d->Cout == 32) TG_LAUNCH("conv3x3_c8<2>", fl, by, conv3x3_c8_kernel<2>, dim3((unsigned)blocks, 1), dim3(256), 0, st, p);
+  else TG_LAUNCH("conv3x3_c8<4>", fl, by, conv3x3_c8_kernel<4>, dim3((unsigned)blocks, d->Cout / 64), dim3(256), 0, st, p);
   return 1;
 }
 

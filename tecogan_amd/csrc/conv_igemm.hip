@@ -329,10 +329,21 @@ template <typename TIn, typename TOut, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvP& p, int nphase, int mq_max, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   dim3 grid((mq_max + BM - 1) / BM, (p.Cout + BN - 1) / BN, nphase);
+  static const char* const pname = [] {
+    static char b[96];
+    snprintf(b, sizeof(b), "conv_igemm<%s,%s,%d,%d,%d,%d>", sizeof(TIn) == 2 ? "bf16" : "f32",
+             sizeof(TOut) == 2 ? "bf16" : "f32", WM, WN, TM, TN);
+    return (const char*)b;
+  }();
+  // algorithmic MACs: gather = out pixels * taps; transposed stride s = in pixels * taps (no zero MACs)
+  const double opx = (double)p.N * p.Hout * p.Wout, ipx = (double)p.N * p.Hin * p.Win;
+  const double macs = (p.mode == 0 ? opx : ipx) * p.KH * p.KW * (double)p.Cin * p.Cout;
+  const double by = ipx * p.Cin * sizeof(TIn) + opx * p.Cout * sizeof(TOut) * (1 + (p.res != nullptr) + (p.aux != nullptr)) +
+                    (double)p.KH * p.KW * p.Cin * p.Cout * sizeof(TIn);
   if (p.vec && p.in_bytes != 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, p);
+    TG_LAUNCH(pname, 2.0 * macs, by, (conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN, true>), grid, dim3(256), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN, false>), grid, dim3(256), 0, st, p);
+    TG_LAUNCH(pname, 2.0 * macs, by, (conv_igemm_kernel<TIn, TOut, WM, WN, TM, TN, false>), grid, dim3(256), 0, st, p);
 }
 
 template <typename TIn, typename TOut>

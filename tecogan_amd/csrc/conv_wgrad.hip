@@ -12,6 +12,7 @@
 // (weight gradients are accumulated in full fp32 products; the flat fp32 gradient buffer is also
 // the RCCL all-reduce buffer).  grid = (taps, Cx/64 * Cy/64 tiles, pixel chunks).
 #include "common.h"
+#include <mutex>
 #include <math.h>
 #include <stdlib.h>
 
@@ -185,14 +186,17 @@ extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, 
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const double wfl = 2.0 * (double)p.M * d->KH * d->KW * (double)d->Cin * d->Cout;
+  const double wby = (double)d->N * d->Hin * d->Win * p.ldx * (x_dtype == TG_F32 ? 4 : 2) +
+                     (double)p.M * p.ldy * (y_dtype == TG_F32 ? 4 : 2) + 4.0 * d->KH * d->KW * d->Cin * d->Cout;
   if (x_dtype == TG_F32 && y_dtype == TG_F32)
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, float>), grid, dim3(256), 0, st, p);
+    TG_LAUNCH("conv_wgrad<f32,f32>", wfl, wby, (conv_wgrad_kernel<float, float>), grid, dim3(256), 0, st, p);
   else if (x_dtype == TG_BF16 && y_dtype == TG_BF16)
-    hipLaunchKernelGGL((conv_wgrad_kernel<u16, u16>), grid, dim3(256), 0, st, p);
+    TG_LAUNCH("conv_wgrad<bf16,bf16>", wfl, wby, (conv_wgrad_kernel<u16, u16>), grid, dim3(256), 0, st, p);
   else if (x_dtype == TG_BF16 && y_dtype == TG_F32)
-    hipLaunchKernelGGL((conv_wgrad_kernel<u16, float>), grid, dim3(256), 0, st, p);
+    TG_LAUNCH("conv_wgrad<bf16,f32>", wfl, wby, (conv_wgrad_kernel<u16, float>), grid, dim3(256), 0, st, p);
   else if (x_dtype == TG_F32 && y_dtype == TG_BF16)
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, u16>), grid, dim3(256), 0, st, p);
+    TG_LAUNCH("conv_wgrad<f32,bf16>", wfl, wby, (conv_wgrad_kernel<float, u16>), grid, dim3(256), 0, st, p);
   else
     TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
@@ -788,7 +792,9 @@ static int tg_wgrad_row3_launch(const tg_conv_desc* d, int groups, const void* c
   p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   p.nchunk = ksplit;
-  hipLaunchKernelGGL(conv_wgrad_row3_bf16_kernel, dim3((unsigned)(groups * base_blocks * ksplit)), dim3(256), 0, st, p);
+  TG_LAUNCH("conv_wgrad_row3_bf16", 2.0 * groups * (double)M64 * 9.0 * d->Cin * d->Cout,
+            groups * ((double)M64 * (ldx + ldy) * 2.0 + 36.0 * d->Cin * d->Cout), conv_wgrad_row3_bf16_kernel,
+            dim3((unsigned)(groups * base_blocks * ksplit)), dim3(256), 0, st, p);
   return 1;
 }
 
@@ -845,14 +851,15 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   const dim3 grid((unsigned)(d->KH * d->KW * xtiles * p.ytiles * ksplit));   // 1-D: the kernel maps work XCD-aware
   const unsigned lds = 2u * 64u * (128u * pf + 8u);
-  static bool attr_set = false;
-  if (!attr_set) {                                                    // PF = 4 needs 66.5 KB of dynamic LDS
+  static std::once_flag attr_once;                                    // PF = 4 needs 66.5 KB of dynamic LDS
+  std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 4 + 8));
-    attr_set = true;
-  }
-  if (pf == 1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), lds, st, p);
-  else if (pf == 2) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<4>, grid, dim3(256), lds, st, p);
+  });
+  const double wfl = 2.0 * (double)M64 * d->KH * d->KW * (double)d->Cin * d->Cout;
+  const double wby = (double)d->N * d->Hin * d->Win * ldx * 2.0 + (double)M64 * ldy * 2.0 + 4.0 * d->KH * d->KW * d->Cin * d->Cout;
+  if (pf == 1) TG_LAUNCH("conv_wgrad_bf16<1>", wfl, wby, conv_wgrad_bf16_kernel<1>, grid, dim3(256), lds, st, p);
+  else if (pf == 2) TG_LAUNCH("conv_wgrad_bf16<2>", wfl, wby, conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p);
+  else TG_LAUNCH("conv_wgrad_bf16<4>", wfl, wby, conv_wgrad_bf16_kernel<4>, grid, dim3(256), lds, st, p);
   return 1;
 }

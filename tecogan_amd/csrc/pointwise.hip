@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ in, const T* __restrict__ d_out,
                                                            T* __restrict__ d_in, int N, int H, int W, int C, int act,
-                                                           float alpha) {
+                                                           float alpha, const T* __restrict__ add) {
   const int Ho = H / 2, Wo = W / 2;
   const int64_t n = (int64_t)N * H * W * C;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
     const int y = (int)(t % H), b = (int)(t / H);
     float g = 0.f;
     const int oy = y >> 1, ox = x >> 1;
+    // `add`: a second gradient w.r.t. the same (post-activation) tensor, e.g. a VGG feature tap (lib/Teco.py:346-352)
+    if (add) g = Elem<T>::ld(add + e) * act_grad_from_out(Elem<T>::ld(in + e), act, alpha);
     if (oy < Ho && ox < Wo) {
       const T* __restrict__ p = in + ((int64_t)(b * H + 2 * oy) * W + 2 * ox) * C + c;
       const float v[4] = {Elem<T>::ld(p), Elem<T>::ld(p + C), Elem<T>::ld(p + (int64_t)W * C),
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
           am = k;
         }
       if (am == ((y & 1) * 2 + (x & 1)))  // `in` is the activation OUTPUT: fuse its derivative here
-        g = Elem<T>::ld(d_out + ((int64_t)(b * Ho + oy) * Wo + ox) * C + c) * act_grad_from_out(m, act, alpha);
+        g += Elem<T>::ld(d_out + ((int64_t)(b * Ho + oy) * Wo + ox) * C + c) * act_grad_from_out(m, act, alpha);
     }
     Elem<T>::st(d_in + e, g);
   }
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_x8_kernel(const u16* __restr
 // gradients (first-max-wins tie rule of the scalar kernel; odd trailing rows/columns are zeroed by the last windows).
 __global__ __launch_bounds__(256) void maxpool2_bwd_x8_kernel(const u16* __restrict__ in, const u16* __restrict__ d_out,
                                                               u16* __restrict__ d_in, int N, int H, int W, int C, int act,
-                                                              float alpha) {
+                                                              float alpha, const u16* __restrict__ add) {
   const int Ho = H / 2, Wo = W / 2, C8 = C >> 3;
   const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;                // windows incl. the ragged edge
   const int n = N * Hc * Wc * C8;
@@ -93,13 +95,22 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_x8_kernel(const u16* __restr
     t /= Wc;
     const int oy = t % Hc, b = t / Hc;
     const int64_t base = ((int64_t)(b * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+    // gradient arriving directly at this pixel (`add`, nullable) times the activation derivative
+    auto direct = [&](int64_t off) -> uint4 {
+      if (!add) return make_uint4(0, 0, 0, 0);
+      float a[8], xv[8];
+      bf8_unpack(*reinterpret_cast<const uint4*>(add + off), a);
+      bf8_unpack(*reinterpret_cast<const uint4*>(in + off), xv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] *= act_grad_from_out(xv[k], act, alpha);
+      return bf8_pack(a);
+    };
     if (oy >= Ho || ox >= Wo) {                                 // ragged edge: no pooling window covers these pixels
-      *reinterpret_cast<uint4*>(d_in + base) = zero;
-      if (2 * ox + 1 < W) *reinterpret_cast<uint4*>(d_in + base + C) = zero;
+      *reinterpret_cast<uint4*>(d_in + base) = direct(base);
+      if (2 * ox + 1 < W) *reinterpret_cast<uint4*>(d_in + base + C) = direct(base + C);
       if (2 * oy + 1 < H) {
-        *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C) = zero;
-        if (2 * ox + 1 < W) *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C + C) = zero;
+        *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C) = direct(base + (int64_t)W * C);
+        if (2 * ox + 1 < W) *reinterpret_cast<uint4*>(d_in + base + (int64_t)W * C + C) = direct(base + (int64_t)W * C + C);
       }
       continue;
     }
@@ -122,6 +133,16 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_x8_kernel(const u16* __restr
       const float gv = g[k] * act_grad_from_out(m, act, alpha);   // `in` is the activation OUTPUT
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j][k] = am == j ? gv : 0.f;
+    }
+    if (add) {
+      const int64_t offs[4] = {base, base + C, base + (int64_t)W * C, base + (int64_t)W * C + C};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a[8];
+        bf8_unpack(*reinterpret_cast<const uint4*>(add + offs[j]), a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[j][k] += a[k] * act_grad_from_out(v[j][k], act, alpha);
+      }
     }
     *reinterpret_cast<uint4*>(d_in + base) = bf8_pack(o[0]);
     *reinterpret_cast<uint4*>(d_in + base + C) = bf8_pack(o[1]);
@@ -622,19 +643,20 @@ extern "C" int tg_maxpool2_forward(const void* in, void* out, int dtype, int N, 
 }
 
 extern "C" int tg_maxpool2_backward(const void* in, const void* d_out, void* d_in, int dtype, int N, int H, int W,
-                                    int C, int act, float alpha, void* stream) {
+                                    int C, int act, float alpha, const void* add, void* stream) {
   TG_CHECK_ARG(in && d_out && d_in && N > 0 && H > 1 && W > 1 && C > 0, "bad argument");
-  const bool x8 = dtype == TG_BF16 && C % 8 == 0 && ((((uintptr_t)in | (uintptr_t)d_out | (uintptr_t)d_in)) & 15) == 0 &&
+  const bool x8 = dtype == TG_BF16 && C % 8 == 0 &&
+                  ((((uintptr_t)in | (uintptr_t)d_out | (uintptr_t)d_in | (uintptr_t)add)) & 15) == 0 &&
                   (int64_t)N * H * W * C < ((int64_t)1 << 31);
   if (x8) {
     hipLaunchKernelGGL(maxpool2_bwd_x8_kernel,
                        dim3(grid_1d((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8), 256, 1 << 20)), dim3(256), 0,
-                       ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha);
+                       ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha, (const u16*)add);
     TG_CHECK_LAUNCH();
   }
   dim3 grid(grid_1d((int64_t)N * H * W * C, 256));
-  if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (const float*)d_out, (float*)d_in, N, H, W, C, act, alpha);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha);
+  if (dtype == TG_F32) hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (const float*)d_out, (float*)d_in, N, H, W, C, act, alpha, (const float*)add);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((maxpool2_bwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (const u16*)d_out, (u16*)d_in, N, H, W, C, act, alpha, (const u16*)add);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -642,8 +664,9 @@ extern "C" int tg_maxpool2_backward(const void* in, const void* d_out, void* d_i
 extern "C" int tg_upsample2_forward(const void* in, void* out, int dtype, int N, int H, int W, int C, void* stream) {
   TG_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
   dim3 grid(grid_1d((int64_t)N * H * W * 4 * C, 256));
-  if (dtype == TG_F32) hipLaunchKernelGGL((upsample2_fwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (float*)out, N, H, W, C);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((upsample2_fwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
+  const double by = (double)N * H * W * C * 5.0 * (dtype == TG_F32 ? 4.0 : 2.0);
+  if (dtype == TG_F32) TG_LAUNCH("upsample2_fwd<f32>", 0, by, (upsample2_fwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (float*)out, N, H, W, C);
+  else if (dtype == TG_BF16) TG_LAUNCH("upsample2_fwd<bf16>", 0, by, (upsample2_fwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -662,8 +685,9 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
                                          int B, int h, int w, void* stream) {
   TG_CHECK_ARG(conv_out && gen_in && out && B > 0 && h > 0 && w > 0 && Cpad >= 3, "bad argument");
   dim3 grid(grid_1d((int64_t)B * h * w * 16, 256));
-  if (in_dtype == TG_F32) hipLaunchKernelGGL((bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
-  else if (in_dtype == TG_BF16) hipLaunchKernelGGL((bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
+  const double by = (double)B * h * w * (16.0 * 12.0 * 2.0 + 3.0 * (in_dtype == TG_F32 ? 4.0 : 2.0));   // conv_out in, frame out, LR in
+  if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add<f32>", 0, by, (bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
+  else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add<bf16>", 0, by, (bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -693,6 +717,35 @@ extern "C" int tg_concat2_pad(const float* a, int Ca, const float* b, int Cb, vo
   if (out_dtype == TG_F32) hipLaunchKernelGGL((concat2_pad_kernel<float>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (float*)out, Cpad, npix, scale);
   else if (out_dtype == TG_BF16) hipLaunchKernelGGL((concat2_pad_kernel<u16>), grid, dim3(256), 0, ST(stream), a, Ca, b, Cb, (u16*)out, Cpad, npix, scale);
   else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+// Frame-major gather of a batch-major sequence: dst[t][b][:] = src[b][idx[t]][:] -- the ping-pong extension
+// tf.concat(r, r[:, -2::-1]) of reference lib/Teco.py:80-85 plus the [B,T] -> [T,B] re-layout of this path's sequences.
+struct SeqIdx { int v[64]; };
+__global__ __launch_bounds__(256) void seq_gather_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int B, int T0,
+                                                         int T, int E4, SeqIdx idx) {
+  const int n = T * B * E4;                                   // < 2^31 (checked by the host)
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int k = e % E4, tb = e / E4;
+    const int b = tb % B, t = tb / B;
+    dst[e] = src[((int64_t)b * T0 + idx.v[t]) * E4 + k];
+  }
+}
+
+extern "C" int tg_seq_gather(const float* src, float* dst, int B, int T0, int T, int64_t frame_elems, const int* idx,
+                             void* stream) {
+  TG_CHECK_ARG(src && dst && idx && B > 0 && T0 > 0 && T > 0 && T <= 64 && frame_elems > 0, "bad argument");
+  TG_CHECK_ARG(frame_elems % 4 == 0 && ((((uintptr_t)src | (uintptr_t)dst)) & 15) == 0, "frame size must be a multiple of 4 floats");
+  TG_CHECK_ARG((int64_t)T * B * (frame_elems / 4) < ((int64_t)1 << 31), "sequence too large");
+  SeqIdx s;
+  for (int t = 0; t < T; ++t) {
+    TG_CHECK_ARG(idx[t] >= 0 && idx[t] < T0, "frame index out of range");
+    s.v[t] = idx[t];
+  }
+  const int E4 = (int)(frame_elems / 4);
+  hipLaunchKernelGGL(seq_gather_kernel, dim3(grid_1d((int64_t)T * B * E4, 256, 8192)), dim3(256), 0, ST(stream),
+                     (const float4*)src, (float4*)dst, B, T0, T, E4, s);
   TG_CHECK_LAUNCH();
 }
 
@@ -731,10 +784,10 @@ static dim3 reduce_grid(int64_t rows, int C) {
 }
 
 extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t rows, int C, const float* beta, float eps,
-                                   float alpha, float* stats, float* moving, void* stream) {
+                                   float alpha, float* stats, float* moving, int prezeroed, void* stream) {
   TG_CHECK_ARG(x && y && beta && stats && rows > 0 && C > 0, "bad argument");
   TG_CHECK_ARG(dtype == TG_F32 || dtype == TG_BF16, "bad dtype");
-  if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
+  if (!prezeroed && hipMemsetAsync(stats, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
     tg_set_error("tg_bn_lrelu_forward: memset failed");
     return TG_ELAUNCH;
   }
@@ -763,10 +816,10 @@ extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t ro
 
 extern "C" int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_y, void* d_x, int dtype, int64_t rows,
                                     int C, const float* stats, float eps, float alpha, float* d_beta, float* ws,
-                                    void* stream) {
+                                    int prezeroed, void* stream) {
   TG_CHECK_ARG(x && y && d_y && d_x && stats && ws && rows > 0 && C > 0, "bad argument");
   TG_CHECK_ARG(dtype == TG_F32 || dtype == TG_BF16, "bad dtype");
-  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
+  if (!prezeroed && hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
     tg_set_error("tg_bn_lrelu_backward: memset failed");
     return TG_ELAUNCH;
   }

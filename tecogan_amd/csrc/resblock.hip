@@ -19,6 +19,7 @@
 // W2's loads are issued up front and land during stage 1.  (Staging the two full 83 KB panels through LDS, as the
 // unfused kernel does, made the fused kernel slower than two narrow-tile launches.)  64 channels only.
 #include "common.h"
+#include <mutex>
 
 struct ResP {
   const u16* x;
@@ -222,12 +223,11 @@ __global__ __launch_bounds__(256, 1) void resblock_fused_kernel(ResP p) {
 template <int TH>
 static void launch_res(ResP p, hipStream_t st) {
   constexpr int LDS = ((TH + 4) * 20 + (TH + 2) * 18 + TH * 16) * 144;
-  static bool attr_set = false;
   auto kern = resblock_fused_kernel<TH>;
-  if (!attr_set) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  });
   p.tiles_y = (p.H + TH - 1) / TH;
   p.tiles_x = (p.W + 15) / 16;
   hipLaunchKernelGGL(kern, dim3(p.N * p.tiles_y * p.tiles_x), dim3(256), LDS, st, p);

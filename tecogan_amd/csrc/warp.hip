@@ -179,12 +179,16 @@ extern "C" int tg_warp_s2d_forward(const float* pre, const float* flow_lr, const
   const int64_t work = (int64_t)B * h * w * 16;
   const int grid = grid_1d(work, 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // algorithmic bytes: previous HR frame + LR flow + LR frame read once, generator input written once
+  const double px = (double)B * h * w;
+  const double by = px * ((pre ? 16.0 * 12.0 : 0.0) + (pre ? (double)hf * wf / ((double)h * w) * 8.0 : 0.0) + 12.0 +
+                          Cpad * (out_dtype == TG_F32 ? 4.0 : 2.0));
   if (out_dtype == TG_F32)
-    hipLaunchKernelGGL((warp_s2d_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, pre, flow_lr, lr, (float*)out, B, h,
-                       w, hf, wf, Cpad, scale, shift, warped);
+    TG_LAUNCH("warp_s2d_fwd<f32>", 0, by, (warp_s2d_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, pre, flow_lr, lr,
+              (float*)out, B, h, w, hf, wf, Cpad, scale, shift, warped);
   else if (out_dtype == TG_BF16)
-    hipLaunchKernelGGL((warp_s2d_fwd_kernel<u16>), dim3(grid), dim3(256), 0, st, pre, flow_lr, lr, (u16*)out, B, h, w,
-                       hf, wf, Cpad, scale, shift, warped);
+    TG_LAUNCH("warp_s2d_fwd<bf16>", 0, by, (warp_s2d_fwd_kernel<u16>), dim3(grid), dim3(256), 0, st, pre, flow_lr, lr,
+              (u16*)out, B, h, w, hf, wf, Cpad, scale, shift, warped);
   else
     TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
@@ -197,12 +201,13 @@ extern "C" int tg_warp_s2d_backward(const void* d_out, int dtype, const float* p
   const int64_t work = (int64_t)B * h * w * 16;
   const int grid = grid_1d(work, 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const double by = (double)B * h * w * (Cpad * (dtype == TG_F32 ? 4.0 : 2.0) + 16.0 * 12.0 * 3.0 + 16.0);
   if (dtype == TG_F32)
-    hipLaunchKernelGGL((warp_s2d_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)d_out, pre, flow_lr,
-                       d_pre, d_flow_lr, B, h, w, Cpad, scale);
+    TG_LAUNCH("warp_s2d_bwd<f32>", 0, by, (warp_s2d_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)d_out, pre,
+              flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale);
   else if (dtype == TG_BF16)
-    hipLaunchKernelGGL((warp_s2d_bwd_kernel<u16>), dim3(grid), dim3(256), 0, st, (const u16*)d_out, pre, flow_lr,
-                       d_pre, d_flow_lr, B, h, w, Cpad, scale);
+    TG_LAUNCH("warp_s2d_bwd<bf16>", 0, by, (warp_s2d_bwd_kernel<u16>), dim3(grid), dim3(256), 0, st, (const u16*)d_out, pre,
+              flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale);
   else
     TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();

@@ -14,8 +14,9 @@ from collections import OrderedDict
 import torch
 
 from . import kernels as K
-from .nets import DIS_CPAD, FNET_CPAD, GEN_CPAD, VGG_CPAD, VGG_TAPS, Discriminator, FNet, Generator, VGG19
-from .params import (ParamStore, discriminator_spec, fnet_spec, generator_spec, init_values, vgg_spec)
+from .nets import FNET_CPAD, GEN_CPAD, VGG_CPAD, VGG_TAPS, Discriminator, FNet, Generator, VGG19
+from .params import (DIS_BLOCKS, ParamStore, discriminator_spec, fnet_spec, generator_spec, init_values, pad8,
+                     vgg_spec)
 
 LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_loss_3", "vgg_loss_4", "vgg_loss_5",
               "t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output", "t_discrim_fake_output",
@@ -30,14 +31,25 @@ class TrainEngine:
         self.dev, self.gan, self.act_dtype = torch.device(device), gan, act_dtype
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # Gradient exchange.  "captured": the RCCL all-reduces are nodes of the step's hipGraph, issued on a
+        # side stream as soon as a scope's gradients are final (D right after its backward passes, G after the
+        # sequence-wide weight gradients) so they overlap the rest of the backward pass; "eager-split": compute graph,
+        # eager collectives, update graph (any backend that cannot be captured, e.g. gloo in the plumbing tests).
+        self.exchange_mode = "none"
+        if self.world > 1:
+            backend = torch.distributed.get_backend(process_group)
+            want = os.environ.get("TG_EXCHANGE", "captured" if backend == "nccl" else "eager")
+            self.exchange_mode = "captured" if (want == "captured" and backend == "nccl") else "eager-split"
         self.B, self.T0, self.cs = F.batch_size, F.RNN_N, F.crop_size
         self.T = 2 * self.T0 - 1 if F.pingpang else self.T0
         self.use_vgg = F.vgg_scaling > 0
         specs = OrderedDict()
         specs["generator"] = generator_spec(F.num_resblock)
         specs["fnet"] = fnet_spec()
+        # Dt_mergeDs=False: temporal-only D on the 9 warped channels, centre-cropped (lib/Teco.py:246-250,269-272)
+        self.d_cin = 27 if F.Dt_mergeDs else 9
         if gan:
-            specs["tdiscriminator"] = discriminator_spec()
+            specs["tdiscriminator"] = discriminator_spec(self.d_cin)
         self.ps = ParamStore(specs, self.dev, act_dtype,
                              bpad=("generator/generator_unit/output_stage/conv/Conv/weights",))
         vals = OrderedDict()
@@ -61,18 +73,23 @@ class TrainEngine:
         st[7] = 1.0 if F.Dt_mergeDs else 0.3                     # lib/Teco.py:423-424
         self.sched = st.to(self.dev)
         self.hyper = torch.zeros(nopt, 8, device=self.dev)
-        self.loss = torch.zeros(len(LOSS_NAMES), device=self.dev)
+        # one fp32 scratch, zeroed by ONE fill per step: the loss slots, then the batch-norm statistics / backward sums
+        # of the 2 forward + 3 backward discriminator passes
+        nbn = 5 * 2 * sum(co for _, _, co in DIS_BLOCKS) if gan else 0
+        self.zbuf = torch.zeros(len(LOSS_NAMES) + nbn, device=self.dev)
+        self.loss = self.zbuf[:len(LOSS_NAMES)]
+        self.bn_pool = self.zbuf[len(LOSS_NAMES):]
         h = self.cs
         self.in_lr = torch.zeros(self.B, self.T0, h, h, 3, device=self.dev)
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
-        idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
-        self.seq_idx = torch.tensor(idx, device=self.dev)
+        self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self.graph = None
         # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
         self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
         self.host_step = 0
         self.gen = None
         self.side_stream = torch.cuda.Stream(device=self.dev)
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
 
     # ------------------------------------------------------------------------------------------
     def set_batch(self, r_inputs, r_targets):
@@ -90,7 +107,7 @@ class TrainEngine:
         if self.graph is None:
             self._capture()
         self.graph.replay()
-        if self.world > 1:          # RCCL exchange stays outside the captured graphs (eager, same stream)
+        if self.exchange_mode == "eager-split":      # collectives between the two captured halves (same stream)
             self._allreduce()
             self.graph_update.replay()
 
@@ -110,6 +127,17 @@ class TrainEngine:
             m.copy_(c)
         self.ps.repack()
         torch.cuda.synchronize()
+        if self.exchange_mode == "captured":
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._program()
+                return
+            except Exception as e:           # a collective backend that cannot be stream-captured: split the step instead
+                import warnings
+                warnings.warn("captured RCCL exchange failed (%s): falling back to the eager-split exchange" % (e,))
+                self.exchange_mode = "eager-split"
+                torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         if self.world == 1:
             with torch.cuda.graph(self.graph):
@@ -124,17 +152,43 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
-        if self.world > 1:
+        if self.exchange_mode == "eager-split":
             self._allreduce()
+        elif self.exchange_mode == "captured":
+            torch.cuda.current_stream().wait_stream(self.comm_stream)      # join: all scopes reduced
         self._program_update()
+
+    def _exchange_async(self, scopes, with_balance=False):
+        """captured mode: all-reduce `scopes` of the flat gradient buffer on the communication stream, ordered after
+        everything enqueued so far on the compute stream; the compute stream runs on (fork), `_program` joins."""
+        if self.exchange_mode != "captured":
+            return
+        import torch.distributed as dist
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            if with_balance and self.gan:            # every rank must take the same D-gate branch (lib/Teco.py:493-494)
+                tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
+                dist.all_reduce(tb, group=self.pg)
+                K.affine(tb, tb, 1.0 / self.world, 0.0)
+            for scope in scopes:
+                a, b = self.ps.scope_range[scope]
+                dist.all_reduce(self.ps.grad[a:b], group=self.pg)
+
+    def allreduce_bytes(self):
+        """Bytes every rank contributes to the gradient exchange of one step (fp32 flat buffers + the balance scalar)."""
+        n = sum(self.ps.scope_range[s][1] - self.ps.scope_range[s][0] for s in self.opt_scopes)
+        return 4 * n + (4 if self.gan else 0)
 
     def _program_compute(self):
         F, ps, B, T, h = self.F, self.ps, self.B, self.T, self.cs
         H = 4 * h
         ps.grad.zero_()
-        self.loss.zero_()
-        lr_seq = self.in_lr.transpose(0, 1).index_select(0, self.seq_idx).contiguous()      # [T,B,h,h,3]
-        hr_seq = self.in_hr.transpose(0, 1).index_select(0, self.seq_idx).contiguous()      # [T,B,H,H,3]
+        self.zbuf.zero_()
+        if self.gan:
+            self.D.set_scratch(self.bn_pool)
+        # ping-pong extension (lib/Teco.py:80-85) + [B,T] -> frame-major [T,B] in one gather each
+        lr_seq = K.seq_gather(self.in_lr, torch.empty(T, B, h, h, 3, device=self.dev), self.seq_idx)
+        hr_seq = K.seq_gather(self.in_hr, torch.empty(T, B, H, H, 3, device=self.dev), self.seq_idx)
         npair = (T - 1) * B
         # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
         pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
@@ -189,9 +243,11 @@ class TrainEngine:
             side.wait_stream(main)
         with torch.cuda.stream(side):
             self.G.wgrad_sequence(0, half if (half > 0 and side is not main) else T)
-        self.Fn.backward(fsaved, d_flow)
         if side is not main:
             main.wait_stream(side)
+        self._exchange_async(["generator"])             # overlaps the FNet backward pass below
+        self.Fn.backward(fsaved, d_flow)
+        self._exchange_async(["fnet"])
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""
@@ -259,22 +315,22 @@ class TrainEngine:
                                     torch.empty(tb, h, h, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
             flow_back, _ = self.Fn.forward(back_in, keep=False)       # stop_gradient (Teco.py:214)
             flow_nxt, idx_nxt = flow_back.view(nt, B, h, h, 2), list(range(nt))
+        # merge: [before | warped (zero border) | bilinear LR context] = 27 channels at full size (lib/Teco.py:234-245);
+        # otherwise only the 9 warped channels, cropped to (4h - 2 off)^2 (lib/Teco.py:231-232,249-250)
         merge = bool(F.Dt_mergeDs)
-        if not merge:
-            raise NotImplementedError("Dt_mergeDs=False (temporal-only D) needs a 9-channel discriminator input conv")
         Ho = H if merge else H - 2 * off
         args = (flow_t, flow_nxt, idx_pre, idx_nxt)
-        real = K.pack_d_input_forward(hr_seq, lr_seq, *args, torch.empty(tb, Ho, Ho, DIS_CPAD, device=self.dev, dtype=self.act_dtype), B, h, h, off, merge)
+        real = K.pack_d_input_forward(hr_seq, lr_seq, *args, torch.empty(tb, Ho, Ho, pad8(self.d_cin), device=self.dev, dtype=self.act_dtype), B, h, h, off, merge)
         fake = K.pack_d_input_forward(gen, lr_seq, *args, torch.empty_like(real), B, h, h, off, merge)
         p_real, l_real, sv_real = self.D.forward(real)
         p_fake, l_fake, sv_fake = self.D.forward(fake)
         dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * (self.host_step - 1))   # Teco.py:379-380
         d_real_D, d_fake_D, d_fake_G = (torch.empty_like(p_real) for _ in range(3))
-        out5 = torch.empty(5, device=self.dev)
-        K.gan_losses(p_real, p_fake, F.EPS, F.ratio * dt_ratio, out5, d_real_D, d_fake_D, d_fake_G)
-        for i, name in enumerate(("t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output",
-                                  "t_discrim_fake_output")):
-            self._slot(name).copy_(out5[i:i + 1])
+        # the five scalars land straight in their (contiguous) loss slots
+        i0 = LI["t_adversarial_loss"]
+        assert LOSS_NAMES[i0:i0 + 5] == ["t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output",
+                                         "t_discrim_fake_output"]
+        K.gan_losses(p_real, p_fake, F.EPS, F.ratio * dt_ratio, self.loss[i0:i0 + 5], d_real_D, d_fake_D, d_fake_G)
         d_layers = None
         if F.D_LAYERLOSS:                                             # Teco.py:275-313,389-390
             d_layers = []
@@ -287,6 +343,8 @@ class TrainEngine:
         # discriminator's own gradients (t_discrim_loss) from both passes
         self.D.backward(sv_real, d_real_D, None, wgrad=True, need_dx=False)
         self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False)
+        # D's gradients and t_balance are final: their all-reduce overlaps the generator-side D pass and the whole BPTT
+        self._exchange_async(["tdiscriminator"], with_balance=True)
         # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
         dx = self.D.backward(sv_fake, d_fake_G, d_layers, wgrad=False, need_dx=True)
         K.pack_d_input_backward(dx, gen, flow_t, flow_nxt, idx_pre, idx_nxt, d_gen, B, h, h, off, merge)

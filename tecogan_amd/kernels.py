@@ -119,9 +119,9 @@ def maxpool2_forward(x, out):
     return out
 
 
-def maxpool2_backward(x, d_out, d_in, act=0, alpha=0.0):
+def maxpool2_backward(x, d_out, d_in, act=0, alpha=0.0, add=None):
     N, H, W, Cn = x.shape
-    check(lib().tg_maxpool2_backward(_p(x), _p(d_out), _p(d_in), dt(x), N, H, W, Cn, act, alpha, _stream()),
+    check(lib().tg_maxpool2_backward(_p(x), _p(d_out), _p(d_in), dt(x), N, H, W, Cn, act, alpha, _p(add), _stream()),
           "tg_maxpool2_backward")
     return d_in
 
@@ -169,17 +169,17 @@ def schedule_step(state, hyper, nopt, gated_opt, t_balance, beta1, beta2, eps):
           "tg_schedule_step")
 
 
-def bn_lrelu_forward(x, y, beta, eps, alpha, stats, moving):
+def bn_lrelu_forward(x, y, beta, eps, alpha, stats, moving, prezeroed=False):
     Cn = x.shape[-1]
     check(lib().tg_bn_lrelu_forward(_p(x), _p(y), dt(x), x.numel() // Cn, Cn, _p(beta), eps, alpha, _p(stats),
-                                    _p(moving), _stream()), "tg_bn_lrelu_forward")
+                                    _p(moving), int(prezeroed), _stream()), "tg_bn_lrelu_forward")
     return y
 
 
-def bn_lrelu_backward(x, y, d_y, d_x, stats, eps, alpha, d_beta, ws):
+def bn_lrelu_backward(x, y, d_y, d_x, stats, eps, alpha, d_beta, ws, prezeroed=False):
     Cn = x.shape[-1]
     check(lib().tg_bn_lrelu_backward(_p(x), _p(y), _p(d_y), _p(d_x), dt(x), x.numel() // Cn, Cn, _p(stats), eps,
-                                     alpha, _p(d_beta), _p(ws), _stream()), "tg_bn_lrelu_backward")
+                                     alpha, _p(d_beta), _p(ws), int(prezeroed), _stream()), "tg_bn_lrelu_backward")
     return d_x
 
 
@@ -249,6 +249,14 @@ def pack_d_input_backward(d_out, frames, flow_pre, flow_nxt, idx_pre, idx_nxt, d
                                          int(merge), d_out.shape[-1], _stream()), "tg_pack_d_input_backward")
 
 
+def seq_gather(src, dst, idx):
+    """src [B,T0,...] -> dst [T,B,...] with dst[t] = src[:, idx[t]] (ping-pong order + frame-major layout)."""
+    B, T0 = src.shape[0], src.shape[1]
+    T = len(idx)
+    check(lib().tg_seq_gather(_p(src), _p(dst), B, T0, T, src[0, 0].numel(), _int_array(idx), _stream()), "tg_seq_gather")
+    return dst
+
+
 def affine(x, out, scale, shift):
     check(lib().tg_affine(_p(x), _p(out), x.numel(), scale, shift, _stream()), "tg_affine")
     return out
@@ -260,4 +268,20 @@ def resblock_fused(x, w1, b1, m1, mid, w2, b2, m2, out, flip, relu1):
         raise L.TecoHipError("resblock_fused: bf16, 64 channels only")
     check(lib().tg_resblock_fused(_p(x), _p(w1), _p(b1), _p(m1), _p(mid), _p(w2), _p(b2), _p(m2), _p(out), N, H, W,
                                   int(flip), int(relu1), _stream()), "tg_resblock_fused")
+    return out
+
+
+# ---- built-in launch profiler (csrc/runtime.hip) -----------------------------------------------------
+def prof_enable(on=True):
+    check(lib().tg_prof_enable(int(bool(on))), "tg_prof_enable")
+
+
+def prof_collect(max_entries=256):
+    """Synchronise, aggregate and clear the launch records: list of dicts sorted by total time (descending)."""
+    buf = (L.ProfEntry * max_entries)()
+    n = C.c_int(0)
+    check(lib().tg_prof_collect(buf, max_entries, C.byref(n)), "tg_prof_collect")
+    out = [dict(name=buf[i].name.decode(), calls=int(buf[i].calls), total_us=float(buf[i].total_us),
+                flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(min(n.value, max_entries))]
+    out.sort(key=lambda e: -e["total_us"])
     return out

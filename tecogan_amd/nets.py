@@ -341,18 +341,33 @@ class Discriminator:
         dev = ps.device
         # [mean, var] moving statistics per block ([TF1] A.7; updated, never read by the path)
         self.moving = [torch.stack((torch.zeros(co), torch.ones(co))).to(dev).contiguous() for _, _, co in DIS_BLOCKS]
+        self.scratch, self._cursor = None, 0
+
+    def set_scratch(self, buf):
+        """Give the BN statistics / backward sums a caller-owned fp32 pool that the caller zeroes ONCE per step
+        (one fill node instead of one hipMemset per batch-norm call: 20 per TecoGAN step)."""
+        self.scratch, self._cursor = buf, 0
+
+    def _ws(self, co, like):
+        """[2][co] fp32 accumulator: a slice of the pre-zeroed pool, or a fresh tensor the C side zeroes itself."""
+        if self.scratch is None:
+            return _empty((2, co), _F32, like), False
+        a = self._cursor
+        self._cursor += 2 * co
+        assert self._cursor <= self.scratch.numel(), "BN scratch pool too small"
+        return self.scratch[a:a + 2 * co].view(2, co), True
 
     def forward(self, x, keep=True, update_moving=True):
-        """x [tb,H,W,32] -> (prob [tb,H/16,W/16,1] fp32, [4 layer maps], saved)."""
+        """x [tb,H,W,32|16] -> (prob [tb,H/16,W/16,1] fp32, [4 layer maps], saved)."""
         ps, p = self.ps, self.P
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x, 1, ACT_LRELU, 0.2)
         saved, layers, net = [], [], a
         for bi, (name, _, co) in enumerate(DIS_BLOCKS):
             c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2)
             y = torch.empty_like(c)
-            stats = _empty((2, co), _F32, c)
+            stats, pz = self._ws(co, c)
             K.bn_lrelu_forward(c, y, ps.view(p + name + "/BatchNorm/beta"), 1e-3, 0.2, stats,
-                               self.moving[bi] if update_moving else None)
+                               self.moving[bi] if update_moving else None, prezeroed=pz)
             saved.append((net, c, y, stats))
             layers.append(y)
             net = y
@@ -374,9 +389,9 @@ class Discriminator:
         for bi in range(len(DIS_BLOCKS) - 1, -1, -1):
             name, _, co = DIS_BLOCKS[bi]
             net_in, c, y, stats = saved[bi]
-            ws = _empty((2, co), _F32, c)
+            ws, pz = self._ws(co, c)
             dbeta = ps.gview(p + name + "/BatchNorm/beta") if wgrad else None
-            dcv = K.bn_lrelu_backward(c, y, g, torch.empty_like(c), stats, 1e-3, 0.2, dbeta, ws)
+            dcv = K.bn_lrelu_backward(c, y, g, torch.empty_like(c), stats, 1e-3, 0.2, dbeta, ws, prezeroed=pz)
             if wgrad:
                 conv_wgrad(ps, p + name + "/conv1/Conv/weights", None, net_in, dcv, 2)
             if bi > 0:
@@ -433,11 +448,13 @@ class VGG19:
         for idx in range(len(acts) - 1, -1, -1):
             key, inp, out = acts[idx]
             if key.startswith("pool"):
-                g = K.maxpool2_backward(inp, g, torch.empty_like(inp), ACT_RELU, 0.0)
+                # the pooled tensor `inp` is a tap when the conv before it is one: its loss gradient joins the routed
+                # pool gradient inside the same kernel, (route(g) + d_tap) * relu'(inp)
+                tap = d_taps.get(acts[idx - 1][0]) if idx > 0 else None
+                g = K.maxpool2_backward(inp, g, torch.empty_like(inp), ACT_RELU, 0.0, add=tap)
                 continue
-            if key in d_taps:                      # every tap is followed by a pool or is the last layer
-                t = K.act_backward(d_taps[key], out, torch.empty_like(out), ACT_RELU)
-                g = t if g is None else g.add_(t)
+            if key in d_taps and g is None:        # the last tap (conv5_4) has no pool behind it
+                g = K.act_backward(d_taps[key], out, torch.empty_like(out), ACT_RELU)
             producer_is_conv = idx > 0 and not acts[idx - 1][0].startswith("pool")
             g = conv_bwd_data(ps, key + "/weights", g, inp.shape[1:3], 1, aux=inp if producer_is_conv else None,
                               mask_act=ACT_RELU if producer_is_conv else ACT_NONE)

@@ -151,6 +151,34 @@ def test_parameter_store_round_trips_through_a_bundle(tmp_path):
         assert torch.equal(got[n], ps.view(n)), n
         assert torch.equal(extra["adam_m"][n], ps.view(n, ps.m)) and torch.equal(extra["adam_v"][n], ps.view(n, ps.v)), n
     assert abs(float(r.get("generator_train/beta2_power")) - 0.999 ** 13) < 1e-7
+    assert extra["adam_steps"] == {"generator": 12, "fnet": 12}
+
+
+def test_bundle_resume_carries_adam_counters_and_balance_ema(tmp_path):
+    """A full resume needs each optimiser's Adam step count (the gated discriminator lags global_step) and the
+    t_balance EMA (reference lib/Teco.py:415-417,425,493-494): written as TF's beta1_power accumulators + one own key."""
+    from collections import OrderedDict
+    from tecogan_amd import params as P
+    from tecogan_amd.checkpoint import load_variables, save_bundle
+    specs = OrderedDict(generator=P.generator_spec(1), fnet=P.fnet_spec(), tdiscriminator=P.discriminator_spec())
+    ps = P.ParamStore(specs, "cpu")
+    prefix = str(tmp_path / "model-40")
+    save_bundle(prefix, ps, 40, beta1=0.9, adam_steps={"tdiscriminator": 17, "generator": 40, "fnet": 40}, tb_ema=0.3125)
+    _, extra = load_variables(prefix)
+    assert extra["global_step"] == 40
+    assert extra["adam_steps"] == {"tdiscriminator": 17, "generator": 40, "fnet": 40}
+    assert abs(extra["tb_ema"] - 0.3125) < 1e-7
+
+
+def test_data_parallel_ranks_draw_different_batches():
+    """Every rank of a data-parallel run must see its own data stream (otherwise the averaged gradient equals a
+    single-GPU step): the loader's seed is offset by the rank."""
+    from lib.dataloader import SyntheticSequences
+    from tecogan_amd.flags import frvsr_flags
+    F = frvsr_flags(batch_size=1, RNN_N=2, crop_size=8)
+    a = SyntheticSequences(F, "cpu", seed=1234 + 0).next_batch()
+    b = SyntheticSequences(F, "cpu", seed=1234 + 1).next_batch()
+    assert not torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])
 
 
 def _v1_file(path, tensors):

@@ -562,3 +562,244 @@ def test_resblock_fused_forward_and_backward(shape):
                      dout, flip=True, relu1=False)
     close(dmid, dr_ref, 1e-2, "fused bwd mid")
     close(dout, dx_ref, 1e-2, "fused bwd out")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: kernel-level parity of the loss / packing / schedule entry points (previously only covered by the
+# end-to-end step), per-element tolerance (tests/util.py)
+# ---------------------------------------------------------------------------------------------------------
+from util import assert_close_per_elem  # noqa: E402
+
+
+def _triplet_setup(B=2, h=8, T=7, seed=3, zero_flow=False):
+    """Frame-major sequences + LR flows as the engine holds them (lib/Teco.py:180-214)."""
+    H = 4 * h
+    frames = rnd(T, B, H, H, 3, seed=seed)
+    lr = (rnd(T, B, h, h, 3, seed=seed + 1) + 1) * 0.5
+    flow = rnd(T - 1, B, h, h, 2, seed=seed + 2, scale=0.0 if zero_flow else 1.5)
+    t_size = 3 * (T // 3)
+    nt = t_size // 3
+    idx_pre = list(range(0, t_size, 3))
+    idx_nxt = list(range(T - 1))[-2:-1 - t_size:-3]
+    return frames, lr, flow, t_size, nt, idx_pre, idx_nxt
+
+
+def _oracle_d_input(frames, lr, flow, t_size, nt, idx_pre, idx_nxt, B, h, off, merge):
+    """oracle/teco.py d_input on batch-major tensors -> [tb,Ho,Ho,9|27] with tb index = b*nt + k."""
+    H = 4 * h
+    fr = frames[:t_size].transpose(0, 1)                                  # [B,t_size,H,H,3]
+    gen_flow = O.upscale_four(flow.reshape(-1, h, h, 2) * 4.0).reshape(flow.shape[0], B, H, H, 2).transpose(0, 1)
+    v_pre, v_nxt = gen_flow[:, idx_pre], gen_flow[:, idx_nxt]
+    T_vel = torch.stack((v_pre, torch.zeros_like(v_pre), v_nxt), 2).reshape(B * t_size, H, H, 2)
+    tb = B * nt
+    flat = fr.reshape(B * t_size, H, H, 3)
+    warped = O.crop_pad_dt(O.pack_triplets(O.dense_image_warp(flat, T_vel), tb), off)
+    if not merge:
+        return warped[:, off:H - off, off:H - off] if off else warped
+    t_input = O.pack_triplets(lr[:t_size].transpose(0, 1).reshape(B * t_size, h, h, 3), tb)
+    hi = O.resize_bilinear_legacy(t_input, H, H)
+    return torch.cat((O.pack_triplets(flat, tb), warped, hi), -1)
+
+
+def _to_engine_tb(x, B, nt):
+    """oracle tb index b*nt+k -> engine tb index k*B+b."""
+    return x.reshape(B, nt, *x.shape[1:]).transpose(0, 1).reshape(B * nt, *x.shape[1:])
+
+
+@pytest.mark.parametrize("merge", [True, False])
+def test_pack_d_input_zero_flow_is_bit_exact(merge):
+    """Zero flow: the warp is the identity, so the before/warped blocks are pure index shuffles (channel = c*3+t,
+    lib/Teco.py:227-229) and the crop/pad border is exact zeros -> bit-exact against oracle.ops.pack_triplets/crop_pad_dt."""
+    B, h, off = 2, 8, 4
+    frames, lr, flow, t_size, nt, ip, inx = _triplet_setup(B, h, zero_flow=True)
+    ref = _to_engine_tb(_oracle_d_input(frames, lr, flow, t_size, nt, ip, inx, B, h, off, merge), B, nt)
+    Ho = 4 * h if merge else 4 * h - 2 * off
+    Cpad = 32 if merge else 16
+    out = torch.full((B * nt, Ho, Ho, Cpad), 7.0, device=DEV)
+    K.pack_d_input_forward(frames.to(DEV), lr.to(DEV), flow.to(DEV), flow.to(DEV), ip, inx, out, B, h, h, off, merge)
+    C = 27 if merge else 9
+    got = out.cpu()
+    nshuf = 18 if merge else 9                                            # before | warped blocks: exact
+    assert torch.equal(got[..., :nshuf], ref[..., :nshuf]), "index shuffle / crop-pad not bit-exact"
+    assert torch.equal(got[..., C:], torch.zeros_like(got[..., C:])), "channel padding not zero"
+    if merge:
+        assert_close_per_elem(got[..., 18:27], ref[..., 18:27], 1e-5, what="bilinear LR context")
+
+
+@pytest.mark.parametrize("merge", [True, False])
+def test_pack_d_input_forward_backward_vs_oracle(merge):
+    B, h, off = 2, 8, 4
+    frames, lr, flow, t_size, nt, ip, inx = _triplet_setup(B, h, seed=11)
+    fr = frames.clone().requires_grad_()
+    ref = _to_engine_tb(_oracle_d_input(fr, lr, flow, t_size, nt, ip, inx, B, h, off, merge), B, nt)
+    C = 27 if merge else 9
+    Ho = ref.shape[1]
+    Cpad = 32 if merge else 16
+    out = torch.empty(B * nt, Ho, Ho, Cpad, device=DEV)
+    K.pack_d_input_forward(frames.to(DEV), lr.to(DEV), flow.to(DEV), flow.to(DEV), ip, inx, out, B, h, h, off, merge)
+    assert_close_per_elem(out[..., :C], ref, 1e-4, what="pack_d fwd")
+    g = rnd(B * nt, Ho, Ho, Cpad, seed=5)
+    g[..., C:] = 0
+    (ref * g[..., :C]).sum().backward()
+    d_frames = torch.zeros_like(frames, device=DEV)
+    K.pack_d_input_backward(g.to(DEV), frames.to(DEV), flow.to(DEV), flow.to(DEV), ip, inx, d_frames, B, h, h, off, merge)
+    assert_close_per_elem(d_frames, fr.grad, 1e-4, what="pack_d bwd")
+
+
+def test_pingpong_loss_and_gradient():
+    """lib/Teco.py:362-370: mean |gen[k] - gen[T-1-k]| over k < RNN_N-1; gradient accumulates into d_gen."""
+    T0, B, H = 4, 2, 8
+    T = 2 * T0 - 1
+    gen = rnd(T, B, H, H, 3, seed=21).requires_grad_()
+    first, last_rev = gen[0:T0 - 1], gen[list(range(T))[-1:-T0:-1]]
+    pp = (first - last_rev).abs().mean()
+    (0.5 * pp).backward()
+    seed_grad = rnd(T, B, H, H, 3, seed=22)
+    d_gen = seed_grad.clone().to(DEV)
+    loss = torch.zeros(1, device=DEV)
+    cnt = float((T0 - 1) * gen[0].numel())
+    K.pingpong(gen.detach().to(DEV), d_gen, T, T0 - 1, 1.0 / cnt, 0.5 / cnt, loss)
+    assert_close_per_elem(loss, pp.detach().reshape(1), 1e-5, what="pingpong loss")
+    assert_close_per_elem(d_gen.cpu() - seed_grad, gen.grad, 1e-4, what="pingpong grad")
+
+
+def test_gan_losses_values_and_gradients():
+    """lib/Teco.py:374-399 on sigmoid outputs incl. values near 0 and 1 (EPS = 1e-12)."""
+    n, eps, w = 300, 1e-12, 0.01
+    g = torch.Generator().manual_seed(31)
+    real = torch.rand(n, generator=g).clamp(1e-4, 1 - 1e-4).requires_grad_()
+    fake = torch.rand(n, generator=g).clamp(1e-4, 1 - 1e-4).requires_grad_()
+    t_adv = (-torch.log(fake + eps)).mean()
+    t_dis = (-(torch.log(1 - fake + eps) + torch.log(real + eps))).mean()
+    t_bal = torch.log(real + eps).mean() + t_adv
+    out = torch.zeros(5, device=DEV)
+    d_r, d_f, d_g = (torch.empty(n, device=DEV) for _ in range(3))
+    K.gan_losses(real.detach().to(DEV), fake.detach().to(DEV), eps, w, out, d_r, d_f, d_g)
+    ref = torch.stack((t_adv, t_dis, t_bal, real.mean(), fake.mean())).detach()
+    assert_close_per_elem(out, ref, 1e-5, what="gan loss scalars")
+    gr, gf = torch.autograd.grad(t_dis, (real, fake), retain_graph=True)
+    (gg,) = torch.autograd.grad(w * t_adv, (fake,))
+    assert_close_per_elem(d_r, gr, 1e-5, what="d t_discrim / d real")
+    assert_close_per_elem(d_f, gf, 1e-5, what="d t_discrim / d fake")
+    assert_close_per_elem(d_g, gg, 1e-5, what="d adv / d fake")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_l1_layer_loss(dtype):
+    """lib/Teco.py:291-302: mean over pixels of sum_c |r - f|; d_f = -grad_scale * sign(r - f)."""
+    r, f = rnd(3, 6, 6, 64, seed=41).to(dtype).float(), rnd(3, 6, 6, 64, seed=42).to(dtype).float()
+    npix = 3 * 6 * 6
+    loss = torch.zeros(1, device=DEV)
+    d = torch.empty(3, 6, 6, 64, device=DEV, dtype=dtype)
+    K.l1_loss(r.to(DEV, dtype), f.to(DEV, dtype), 1.0 / npix, 0.25 / npix, loss, d)
+    ref = (r - f).abs().sum(3).mean()
+    assert_close_per_elem(loss, ref.reshape(1), 1e-5, what="l1 loss")
+    gref = -(0.25 / npix) * torch.sign(r - f)
+    assert_close_per_elem(d.float(), gref.to(dtype).float(), 1e-6, what="l1 grad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vgg_preprocess_forward_backward(dtype):
+    """lib/Teco.py:9-10: deprocess * 255 - VGG_MEAN (RGB 123.68, 116.78, 103.94), zero channel padding; d_x += 127.5 d_out."""
+    x = rnd(2, 9, 7, 3, seed=51)
+    out = torch.full((2, 9, 7, 8), 3.0, device=DEV, dtype=dtype)
+    K.vgg_preprocess_forward(x.to(DEV), out)
+    ref = O.vgg_preprocess(x)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert_close_per_elem(out[..., :3].float(), ref, tol, what="vgg preprocess")
+    assert torch.equal(out[..., 3:].float().cpu(), torch.zeros(2, 9, 7, 5))
+    g = rnd(2, 9, 7, 8, seed=52).to(dtype)
+    acc0 = rnd(2, 9, 7, 3, seed=53)
+    d_x = acc0.clone().to(DEV)
+    K.vgg_preprocess_backward(g.to(DEV), d_x)
+    assert_close_per_elem(d_x.cpu() - acc0, 127.5 * g[..., :3].float(), 1e-4, floor=1e-2, what="vgg preprocess bwd")
+
+
+def test_schedule_step_lr_decay_ema_and_gate():
+    """lib/Teco.py:95-99 (exponential_decay, staircase), :415-417 (EMA 0.99 from 0, no debias), :493-494 (gate on the OLD
+    average), per-optimiser Adam bias correction; D learning rate x0.3 when Dt_mergeDs is off (:423-424)."""
+    import math
+    st = torch.zeros(8 + 2 * 3, dtype=torch.float64)
+    st[0], st[2], st[3], st[4], st[5], st[6], st[7] = 9.0, 1e-3, 4.0, 0.5, 1.0, 0.4, 0.3
+    state = st.to(DEV)
+    hyper = torch.zeros(3, 8, device=DEV)
+    tb, t_counts = 0.0, [0, 0, 0]
+    for step, bal in enumerate((50.0, 10.0, -3.0)):
+        K.schedule_step(state, hyper, 3, 0, torch.tensor([bal], device=DEV), 0.9, 0.999, 1e-8)
+        gstep = 9 + step
+        lr = O.exponential_decay(1e-3, gstep, 4, 0.5, True)
+        gate = tb < 0.4
+        tb = O.ema_tf(tb, bal)
+        hs = hyper.cpu()
+        for k in range(3):
+            on = gate if k == 0 else True
+            t_counts[k] += 1 if on else 0
+            lrk = lr * 0.3 if k == 0 else lr
+            t = t_counts[k]
+            lr_t = lrk * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) if t > 0 else float("nan")
+            assert hs[k, 4].item() == (1.0 if on else 0.0), (step, k)
+            if on:
+                assert abs(hs[k, 0].item() - lr_t) <= 1e-6 * lr_t, (step, k, hs[k, 0].item(), lr_t)
+            assert abs(hs[k, 5].item() - lrk) <= 1e-6 * lrk
+        s = state.cpu()
+        assert s[0].item() == gstep + 1 and abs(s[1].item() - tb) < 1e-9
+    assert t_counts[0] < 3, "the gate never closed in this scenario"
+
+
+def test_concat2_pad_lincomb_affine_seq_gather():
+    a, b = rnd(2, 5, 7, 3, seed=61), rnd(2, 5, 7, 3, seed=62)
+    out = torch.full((2, 5, 7, 8), 9.0, device=DEV)
+    K.concat2_pad(a.to(DEV), b.to(DEV), out)
+    ref = torch.cat((a, b, torch.zeros(2, 5, 7, 2)), -1)
+    assert torch.equal(out.cpu(), ref), "concat2_pad is a pure copy: bit-exact"
+    o2 = torch.empty(2, 5, 7, 3, device=DEV)
+    K.lincomb(a.to(DEV), b.to(DEV), o2, 0.25, -1.5)
+    assert_close_per_elem(o2, 0.25 * a - 1.5 * b, 1e-6, what="lincomb")
+    K.lincomb(a.to(DEV), None, o2, 2.0, 0.0, accumulate=True)
+    assert_close_per_elem(o2, 2.25 * a - 1.5 * b, 1e-6, what="lincomb accumulate")
+    K.affine(a.to(DEV), o2, 0.5, 0.5)
+    assert torch.equal(o2.cpu(), a * 0.5 + 0.5), "deprocess (x+1)/2 == x*0.5+0.5 bit for bit"
+    # ping-pong order + [B,T] -> [T,B] (lib/Teco.py:80-85): bit-exact gather
+    src = rnd(3, 4, 6, 6, 3, seed=63)
+    idx = [0, 1, 2, 3, 2, 1, 0]
+    dst = torch.empty(7, 3, 6, 6, 3, device=DEV)
+    K.seq_gather(src.to(DEV), dst, idx)
+    assert torch.equal(dst.cpu(), src.transpose(0, 1)[idx].contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_backward_with_tap_gradient(dtype):
+    """VGG taps sit right before a pool (lib/ops.py:319-327, lib/Teco.py:176): d_in = (route(d_out) + d_tap) * relu'(x)."""
+    x = rnd(2, 9, 8, 16, seed=71).to(dtype).float()
+    xr = torch.relu(x).requires_grad_()                    # the pooled tensor is a ReLU output
+    pooled = O.maxpool(xr)
+    g = rnd(*pooled.shape, seed=72).to(dtype).float()
+    d_tap = rnd(*x.shape, seed=73).to(dtype).float()
+    (gx,) = torch.autograd.grad((pooled * g).sum() + (xr * d_tap).sum(), (xr,))
+    ref = gx * (xr.detach() > 0).float()
+    out = torch.empty(*x.shape, device=DEV, dtype=dtype)
+    K.maxpool2_backward(xr.detach().to(DEV, dtype), g.to(DEV, dtype), out, ACT_RELU, 0.0, add=d_tap.to(DEV, dtype))
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert_close_per_elem(out.float(), ref, tol, floor=1e-2, what="maxpool bwd + tap")
+
+
+def test_launch_profiler_counts_and_flops():
+    """tg_prof_*: every instrumented launch is booked with its algorithmic FLOPs; disabled -> nothing recorded."""
+    x = rnd(1, 16, 16, 64, seed=81).to(DEV, torch.bfloat16)
+    w = rnd(9, 64, 64, seed=82, scale=0.05).to(DEV, torch.bfloat16)
+    out = torch.empty_like(x)
+    d = K.conv_desc(1, 16, 16, 64, 16, 16, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_RELU)
+    K.conv_forward(d, x, w, None, None, None, out)
+    torch.cuda.synchronize()
+    K.prof_collect()
+    K.prof_enable(True)
+    for _ in range(3):
+        K.conv_forward(d, x, w, None, None, None, out)
+    K.prof_enable(False)
+    K.conv_forward(d, x, w, None, None, None, out)
+    ents = K.prof_collect()
+    assert len(ents) == 1 and ents[0]["calls"] == 3, ents
+    assert ents[0]["name"].startswith("conv3x3_tile<bf16,bf16")
+    assert ents[0]["flops"] == 3 * 2.0 * 16 * 16 * 64 * 9 * 64
+    assert 0.5 < ents[0]["total_us"] / 3 < 200.0, ents
+    assert K.prof_collect() == []

@@ -2,6 +2,8 @@
 
 Tolerance (fp32 mode): 1e-3 relative per tensor (north-star bar), in practice ~1e-5.  bf16 mode reports
 its own measured error against the fp32 oracle with a looser, stated bound."""
+import os
+
 import pytest
 import torch
 
@@ -28,8 +30,11 @@ def frame_major(gen_outputs):          # oracle [B,T,...] -> engine [T,B,...]
     return gen_outputs.transpose(0, 1)
 
 
-def run_pair(F, gan, steps=1, act_dtype=torch.float32, use_graph=False):
+def run_pair(F, gan, steps=1, act_dtype=torch.float32, use_graph=False, damp=False):
     S = OT.State(F, seed=42, gan=gan)
+    if damp:        # a well-conditioned recurrence (tecogan_amd.params.damp_values): see check_full_config
+        from tecogan_amd.params import damp_values
+        S.P = damp_values(S.P)
     eng = TrainEngine(F, DEV, gan=gan, act_dtype=act_dtype, seed=7, use_graph=use_graph)
     eng.ps.load(S.P)
     if eng.use_vgg:
@@ -136,3 +141,146 @@ def test_tecogan_no_pingpong_backward_flow_branch():
     # 3e-3: with only 2x3 tiny frames a handful of ReLU pre-activations sit within fp32 rounding of 0 and their
     # 0/1 masks flip between summation orders -- a discrete effect on the conv_tran2 weight gradient (1.2e-3).
     check_step(S, eng, Rs[-1], 3e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: parity at the BASELINE configurations (C2 = configs[1], C3 = configs[2]) with the per-pixel criterion,
+# the temporal-only discriminator (Dt_mergeDs=False), and the data-parallel engine itself
+# ---------------------------------------------------------------------------------------------------------
+from util import assert_close_per_elem, max_rel_err, per_elem_err  # noqa: E402
+
+
+def check_full_config(F, gan, tag):
+    """One fp32 step at a full BASELINE size against the oracle.
+    HR frames (the path's OUTPUT): north_star's per-pixel bar, |a-b| <= 1e-3 * max(|b|, 1e-3 max|b|) for EVERY pixel.
+    Losses: 1e-3 relative.  Gradients (sums over up to 3e5 pixel products in a different summation order, split-K with
+    fp32 atomics): relative L2 <= 1e-3 per tensor AND per-element |a-b| <= 1e-3 * max(|b|, 2e-2 max|b|) -- an element
+    that is ~0 by cancellation cannot be asked to agree to 1e-6 of the tensor's scale in fp32.
+    Weights: seeded xavier, damped (params.damp_values) so that the 10/19-frame recurrence is well conditioned -- with the
+    raw xavier init the frame maximum doubles per frame and the fp32 ORACLE itself is 1.6e-2 away from its own fp64 run
+    at frame 18 (tests/oracle_conditioning.py), so no fp32 implementation can be held to 1e-3 there."""
+    S, eng, Rs = run_pair(F, gan=gan, damp=True)
+    R = Rs[-1]
+    worst = assert_close_per_elem(eng.gen, frame_major(R["gen_outputs"]), 1e-3, 1e-3, what=tag + " gen_outputs")
+    L = eng.losses()
+    for name, val in zip(R["names"], R["vals"]):
+        if name in L:
+            assert abs(L[name] - float(val)) <= 1e-3 * max(1e-6, abs(float(val))), (tag, name, L[name], float(val))
+    stats = []
+    for name, g in R["grads"].items():
+        mine = eng.ps.gview(name).detach().cpu().double()
+        ref = g.detach().double()
+        l2 = ((mine - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        assert l2 < 1e-3, "%s gradient %s relative L2 error %g" % (tag, name, l2)
+        pe = per_elem_err(mine, ref, floor=2e-2).max().item()
+        assert pe < 1e-3, "%s gradient %s per-element error %g" % (tag, name, pe)
+        stats.append((l2, pe))
+    print("\n[%s] gen per-pixel err %.2e; %d gradient tensors: worst L2 %.2e, worst per-element %.2e" %
+          (tag, worst, len(stats), max(s[0] for s in stats), max(s[1] for s in stats)))
+    return S, eng, R
+
+
+def test_frvsr_step_fp32_parity_at_baseline_config_C2():
+    """BASELINE.json configs[1]: runGan.py 4, B=4, RNN_N=10, 32x32 LR, num_resblock=10."""
+    check_full_config(OT.frvsr_flags(), gan=False, tag="C2")
+
+
+def test_tecogan_step_fp32_parity_at_baseline_config_C3():
+    """BASELINE.json configs[2]: runGan.py 3, B=4, RNN_N=10 (19 frames with ping-pong), num_resblock=16, Dst + VGG."""
+    S, eng, R = check_full_config(OT.default_flags(), gan=True, tag="C3")
+    assert R["with_D"] is True and int(eng.sched[8].item()) == 1
+
+
+def test_bf16_mode_error_at_baseline_config_C2():
+    """The timed bf16 mode at the full C2 size: measured, stated bound (not parity): HR frames within 3e-2 of the oracle
+    relative to the frame maximum, content loss within 2 %."""
+    F = OT.frvsr_flags()
+    S, eng, Rs = run_pair(F, gan=False, act_dtype=torch.bfloat16, damp=True)
+    e = max_rel_err(eng.gen, frame_major(Rs[-1]["gen_outputs"]))
+    ref = float(dict(zip(Rs[-1]["names"], Rs[-1]["vals"]))["l2_content_loss"])
+    print("\n[C2 bf16] gen max-rel err %.3e, content loss %.5f vs %.5f" % (e, eng.losses()["l2_content_loss"], ref))
+    assert e < 3e-2, e
+    assert abs(eng.losses()["l2_content_loss"] - ref) < 2e-2 * ref
+
+
+def test_tecogan_temporal_only_discriminator_Dt_mergeDs_false():
+    """lib/Teco.py:246-250,269-272,423-424: D sees only the 9 warped channels, centre-cropped to (4h - 2 off)^2, and its
+    learning rate is 0.3 x.  (The reference's own branch cannot run -- discriminator_F returns a tuple there and the layer
+    loss reads undefined names -- so the oracle states the evident intent: same D, 9-channel input, layer loss on.)"""
+    F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=1, Dt_mergeDs=False)
+    S, eng, Rs = run_pair(F, gan=True)
+    assert eng.ps.entries["tdiscriminator/discriminator_unit/input_stage/conv/Conv/weights"]["shape"] == (3, 3, 9, 64)
+    check_step(S, eng, Rs[-1], 3e-3)
+    assert abs(float(eng.hyper[0, 5].item()) - 0.3 * F.learning_rate) < 1e-9     # D's base learning rate
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F = OT.frvsr_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=2)
+    eng = TrainEngine(F, "cuda:0", gan=False, act_dtype=torch.float32, seed=42, process_group=dist.group.WORLD, use_graph=True)
+    x, y = make_batch(2, F.RNN_N, F.crop_size, seed=77)
+    for _ in range(2):
+        eng.step(x[rank:rank + 1].cuda(), y[rank:rank + 1].cuda())
+    torch.cuda.synchronize()
+    q.put((rank, eng.exchange_mode, {k: v.clone() for k, v in eng.ps.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_engine_world2_equals_single_process_double_batch():
+    """TrainEngine(process_group=...) with two ranks (sharing this GPU, gloo): per-rank batch 1 each, gradient all-reduce
+    with 1/world folded into Adam, two-graph split.  After two steps both ranks hold the weights of ONE process
+    stepping on the concatenated batch of 2 (every FRVSR loss is a batch mean, lib/Teco.py:322,331)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == "eager-split"
+    F = OT.frvsr_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=2)
+    ref = TrainEngine(F, DEV, gan=False, act_dtype=torch.float32, seed=42, use_graph=True)
+    x, y = make_batch(2, F.RNN_N, F.crop_size, seed=77)
+    for _ in range(2):
+        ref.step(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    lr = F.learning_rate
+    for name, w in ref.ps.state_dict().items():
+        for rank in (0, 1):
+            d = (res[rank][2][name] - w).abs().max().item()
+            # Adam's +-lr sign noise on ~0 gradients (see check_step): 2 steps x 2 lr, plus 1e-3 of the tensor's scale
+            assert d <= 1e-3 * w.abs().max().item() + 4.0 * lr, (name, rank, d)
+        assert torch.equal(res[0][2][name], res[1][2][name]), "ranks diverged on " + name
+
+
+def test_captured_rccl_exchange_single_rank_group():
+    """The captured-exchange path (RCCL all-reduce nodes inside the step's hipGraph, issued on the communication stream)
+    on a one-rank RCCL group: same result as the engine without a process group."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31000 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        F = OT.default_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=1)
+        x, y = make_batch(1, F.RNN_N, F.crop_size, seed=5)
+        a = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True)
+        b = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True, process_group=dist.group.WORLD)
+        b.world, b.exchange_mode = 1, "captured"            # force the collective nodes although world == 1
+        b.comm_stream = torch.cuda.Stream()
+        for _ in range(2):
+            a.step(x.to(DEV), y.to(DEV))
+            b.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        assert b.exchange_mode == "captured", "capture of the RCCL collectives fell back to the eager split"
+        for name, w in a.ps.state_dict().items():
+            d = (b.ps.view(name).cpu() - w).abs().max().item()
+            assert d <= 1e-3 * w.abs().max().item() + 4.0 * F.learning_rate, (name, d)
+    finally:
+        dist.destroy_process_group()
