@@ -1,0 +1,257 @@
+// 3x3 stride-1 SAME convolution, "weights in registers" variant for one-chunk layers (Cin <= 64, bf16) -- gfx950.
+//
+// Covers the throughput-regime 64->64 convolutions of the path: the generator's res-block convs at inference
+// resolution (reference lib/frvsr.py:50-57 through main.py:204, 33 launches per 1080p frame), VGG-19 conv1_2
+// (lib/ops.py:319), the discriminator's input conv (lib/Teco.py:48), FNet's 64-channel layers (lib/frvsr.py:9-31), and
+// -- taps mirrored -- their input gradients.  conv3x3.hip keeps the latency regime (small tiles) and Cin > 64.
+//
+// Why a second kernel.  conv3x3_tile_kernel<16,64> holds the 9x64x64 weight panel in LDS (83 KB) next to one halo tile
+// (47 KB): one workgroup per CU, one wave per SIMD, a single LDS buffer -- so halo staging (register prefetch ->
+// ds_write_b128 -> barrier), the LDS-staged epilogue (2 more barriers) and the MFMA block run strictly one after the
+// other on each SIMD (measured 6.4 us per 256-pixel tile for 1.9 us of MFMA work).  Here:
+//   * the weights live in REGISTERS: a wave owns 32 output channels, 9 taps x 2 K-steps x 2 channel groups = 36
+//     fragments = 144 VGPRs, loaded once per workgroup (persistent over tiles).  No weight LDS, no weight re-staging;
+//   * the input halo tile ((8+2) x 18 pixels x 64 channels, 144-byte pixel pitch: the conflict-free layout of
+//     conv3x3.hip) arrives by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass; lanes
+//     outside the image get an out-of-range offset and the hardware writes zeros) into a DOUBLE buffer: the next
+//     tile's DMA is issued right after the one barrier of a tile and flies during its MFMA block and epilogue;
+//   * each halo fragment is read from LDS ONCE per (row, kw, K-step) and reused by the three vertical taps and both
+//     channel groups: 36 ds_read_b128 per 144 MFMAs (the tile kernel: 144 per 288);
+//   * the MFMA operands are swapped (A = weights, B = pixels), so a lane's four accumulator rows are four CONSECUTIVE
+//     OUTPUT CHANNELS of one pixel: the epilogue is bias/activation/residual/mask in registers and one 8-byte store per
+//     accumulator -- no LDS staging, no epilogue barriers;
+//   * 52 KB of LDS and <= 256 registers per wave: TWO workgroups per CU (2 waves per SIMD), so one workgroup's
+//     barrier, DMA wait and epilogue hide under the other's MFMA block.
+#include "common.h"
+#include <mutex>
+#include <stdlib.h>
+
+struct ConvWsP {
+  const void* in;
+  const void* w;      // [9][Cout][Cin]
+  const float* bias;
+  const void* res;
+  const void* aux;
+  void* out;
+  int N, H, W, Cin, Cout;
+  int flip;           // 1: taps mirrored (input-gradient form)
+  float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
+  float mslope;       // act-grad mask: aux > 0 ? 1 : mslope
+  int tiles_y, tiles_x, ntiles;
+  unsigned in_bytes, w_bytes, out_bytes;
+};
+
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+constexpr int WS_TH = 8, WS_HALO = (WS_TH + 2) * 18, WS_ROWB = 144;
+constexpr int WS_SLOTS = WS_HALO * 9;                      // 16-byte slots of one halo tile (8 data + 1 pad per pixel)
+constexpr int WS_NDMA = (WS_SLOTS + 63) / 64;              // wave-wide DMA instructions per tile (26)
+constexpr int WS_BUF = WS_NDMA * 1024;                     // bytes per halo buffer (26624)
+constexpr int WS_KPW = (WS_NDMA + 3) / 4;                  // DMA instructions per wave (7)
+constexpr unsigned WS_OOB = 0x80000000u;
+}  // namespace
+
+template <bool HAS_RES, bool HAS_AUX>
+__global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                  // 2 x 2 waves: 4 pixel rows x 32 channels each
+  const int frow = lane & 15, fg = lane >> 4;
+  const int cbase = blockIdx.y * 64 + wn * 32;
+  const int row_bytes = p.Cin * 2;
+
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  const auto rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_RES ? p.res : p.out), 0, (int)p.out_bytes, 0x00020000);
+  const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.out), 0, (int)p.out_bytes, 0x00020000);
+
+  // ---- LDS-DMA slot descriptors of this lane (tile-independent): slot S = (wave + 4k)*64 + lane holds 16-byte chunk
+  //      c = S % 9 of halo pixel S / 9 (chunk 8 = row padding; chunks past Cin and slots past the tile read zeros).
+  int code[WS_KPW];
+#pragma unroll
+  for (int k = 0; k < WS_KPW; ++k) {
+    const int S = (wave + 4 * k) * 64 + lane;
+    const int pix = S / 9, c = S - 9 * pix;
+    const int dy = pix / 18, dx = pix - 18 * dy;
+    const bool valid = S < WS_SLOTS && c * 8 < p.Cin;
+    code[k] = dy | (dx << 8) | (c << 16) | (valid ? (1 << 24) : 0);
+  }
+
+  auto issue_dma = [&](int tile, int buf) {
+    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+    const int y0 = ty * WS_TH - 1, x0 = tx * 16 - 1;
+    const int base = ((n * p.H + y0) * p.W + x0) * row_bytes;               // wave-uniform
+#pragma unroll
+    for (int k = 0; k < WS_KPW; ++k) {
+      const int inst = wave + 4 * k;
+      if (inst < WS_NDMA) {                                                 // wave-uniform
+        const int dy = code[k] & 255, dx = (code[k] >> 8) & 255, c = (code[k] >> 16) & 255;
+        const bool ok = (code[k] >> 24) && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)(base + (dy * p.W + dx) * row_bytes + c * 16) : WS_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(smem + buf * WS_BUF + inst * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.ntiles) return;
+  issue_dma(tile, 0);
+
+  // ---- weights -> registers: lane (frow, fg) of fragment (tap, kk, j) holds w[tap][cbase + 16 j + frow][32 kk + 8 fg .. +7]
+  u32x4w wf[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int wt = p.flip ? 8 - tap : tap;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
+        const bool ok = co < p.Cout && ci < p.Cin;
+        wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
+      }
+  }
+  float bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cbase + j * 16 + fg * 4 + r;
+      bv[j][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+
+  int buf = 0;
+  while (tile < p.ntiles) {
+    const int ntile = tile + gridDim.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA slots of the current tile (and, first time, its weights)
+    __syncthreads();                                        // every wave's slots landed; nobody still reads the other buffer
+    if (ntile < p.ntiles) issue_dma(ntile, buf ^ 1);        // flies during the MFMA block and the epilogue below
+    __builtin_amdgcn_sched_barrier(0);
+
+    const unsigned char* Afrag = smem + buf * WS_BUF + ((wm * 4) * 18 + frow) * WS_ROWB + fg * 16;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4w af[6];                                       // halo rows 0..5 of this wave at column offset kw
+#pragma unroll
+        for (int r = 0; r < 6; ++r) af[r] = *reinterpret_cast<const u32x4w*>(Afrag + (r * 18 + kw) * WS_ROWB + kk * 64);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kh * 3 + kw][kk][j]),
+                                                                  __builtin_bit_cast(bf16x8, af[i + kh]), acc[i][j], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue in registers: accumulator r of lane (frow, fg) = pixel column frow, output channel cbase+16j+4fg+r
+    {
+      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+      const int x = tx * 16 + frow;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int y = ty * WS_TH + wm * 4 + i;
+        const bool pok = y < p.H && x < p.W;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = cbase + j * 16 + fg * 4;
+          const unsigned off = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : WS_OOB;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r] + bv[j][r];
+            v[r] = fmaxf(v[r], v[r] * p.nslope);
+          }
+          if constexpr (HAS_RES) {
+            const u32x2w rr = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)off, 0, 0);
+            v[0] += __uint_as_float(rr.x << 16);
+            v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16);
+            v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+          if constexpr (HAS_AUX) {
+            const u32x2w aa = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)off, 0, 0);
+            v[0] *= __uint_as_float(aa.x << 16) > 0.f ? 1.f : p.mslope;
+            v[1] *= __uint_as_float(aa.x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+            v[2] *= __uint_as_float(aa.y << 16) > 0.f ? 1.f : p.mslope;
+            v[3] *= __uint_as_float(aa.y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+          }
+          u32x2w o;
+          o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)off, 0, 0);
+        }
+      }
+    }
+    tile = ntile;
+    buf ^= 1;
+  }
+}
+
+template <bool HAS_RES, bool HAS_AUX>
+static void launch_ws(const ConvWsP& p, hipStream_t st) {
+  auto kern = conv3x3_ws_kernel<HAS_RES, HAS_AUX>;
+  constexpr int LDS = 2 * WS_BUF;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  const int nt = p.Cout / 64;
+  int gx = p.ntiles;
+  const int cap = 512 / nt > 0 ? 512 / nt : 1;             // two workgroups per CU
+  if (gx > cap) gx = cap;
+  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_ws<res,aux>" : "conv3x3_ws<res>")
+                                           : (HAS_AUX ? "conv3x3_ws<aux>" : "conv3x3_ws<>");
+  const double px = (double)p.N * p.H * p.W;
+  TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
+            px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(256),
+            LDS, st, p);
+}
+
+// Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
+int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                      const void* aux, void* out, hipStream_t st) {
+  static const bool enabled = getenv("TG_NO_C3WS") == nullptr;            // A/B switch
+  static const int min_tiles = getenv("TG_C3WS_MIN_TILES") ? atoi(getenv("TG_C3WS_MIN_TILES")) : 256;
+  if (!enabled) return 0;
+  if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
+  if (d->Cin % 8 != 0 || d->Cin > 64 || d->Cin < 16 || d->Cout % 64 != 0) return 0;
+  if (d->act >= TG_ACT_TANH) return 0;
+  if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15)) return 0;
+  const int64_t px = (int64_t)d->N * d->Hin * d->Win;
+  const int64_t in_bytes = px * d->Cin * 2, out_bytes = px * d->Cout * 2, w_bytes = (int64_t)9 * d->Cout * d->Cin * 2;
+  if (in_bytes >= ((int64_t)1 << 31) || out_bytes >= ((int64_t)1 << 31)) return 0;
+  ConvWsP p;
+  p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
+  p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
+  p.flip = d->mode == 1;
+  p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
+  p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
+  p.tiles_y = (p.H + WS_TH - 1) / WS_TH;
+  p.tiles_x = (p.W + 15) / 16;
+  const int64_t ntiles = (int64_t)p.N * p.tiles_y * p.tiles_x;
+  if (ntiles < min_tiles || ntiles >= ((int64_t)1 << 30)) return 0;
+  p.ntiles = (int)ntiles;
+  p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
+  if (res && aux) launch_ws<true, true>(p, st);
+  else if (res) launch_ws<true, false>(p, st);
+  else if (aux) launch_ws<false, true>(p, st);
+  else launch_ws<false, false>(p, st);
+  return 1;
+}
