@@ -85,7 +85,13 @@ typedef struct tg_conv_desc {
   int32_t in_dtype, out_dtype;     /* weights share in_dtype; res/aux share out_dtype */
   int32_t act;  float act_alpha;
   int32_t mask_act; float mask_alpha;
+  int32_t flags;                   /* TG_CONV_* scheduling hints; 0 = default (results never depend on them) */
 } tg_conv_desc;
+
+/* The launch will run beside the latency-bound recurrent chain on another stream: pick tile shapes whose LDS /
+ * register footprint leaves room for a co-resident chain workgroup (3x3: <8,64> = 109 KB / ~300 registers instead of
+ * <16,64> = 130 KB / ~400; measured: 87 % of the chain hides under VGG-sized convs, profiles/r02a_overlap.txt). */
+#define TG_CONV_COEXIST 1
 
 int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*[KH*KW][Cout][Cin]*/,
                     const float* bias /*nullable*/, const void* res /*nullable*/,

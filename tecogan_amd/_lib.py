@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libtecogan_hip.so")
 
 TG_F32, TG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+CONV_COEXIST = 1
 
 
 class ConvDesc(C.Structure):
@@ -20,7 +21,7 @@ class ConvDesc(C.Structure):
                 ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("mode", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
                 ("act", C.c_int32), ("act_alpha", C.c_float),
-                ("mask_act", C.c_int32), ("mask_alpha", C.c_float)]
+                ("mask_act", C.c_int32), ("mask_alpha", C.c_float), ("flags", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -20,6 +20,9 @@
 #include <type_traits>
 #include <stdlib.h>
 
+int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                      const void* aux, void* out, hipStream_t st);        // conv3x3_ws.hip
+
 struct Conv3P {
   const void* in;
   const void* w;      // [9][Cout][Cin]
@@ -35,6 +38,7 @@ struct Conv3P {
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope (ReLU 0, LeakyReLU alpha, none 1)
   int tiles_y, tiles_x, ntiles;
   int direct_epi;     // A/B switch (TG_C3_DIRECT_EPI): per-lane stores instead of the LDS-staged rows
+  int prio;           // A/B switch (TG_C3_PRIO): s_setprio for the small-tile (latency-bound chain) instantiations
   unsigned in_bytes, w_bytes;   // extents of `in` / `w` for the bounds-checked buffer loads (< 2^31)
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -63,6 +67,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   const int frow = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.y * BN;
   const int nchunk = (p.Cin + BK - 1) / BK;
+  // The recurrent chain's launches are latency bound; when throughput kernels of another stream share the CU
+  // (engine.py overlap schedule) the chain's waves should win the issue arbitration.
+  if constexpr (TH <= 4) {
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
+  }
   const bool b_stationary = nchunk == 1;
 
   TOut* __restrict__ gout = static_cast<TOut*>(p.out);
@@ -334,7 +343,7 @@ static void launch3(Conv3P p, hipStream_t st) {
 }
 
 template <typename TIn, typename TOut>
-static void launch3_typed(const Conv3P& p, hipStream_t st) {
+static void launch3_typed(const Conv3P& p, hipStream_t st, bool coexist) {
   const int64_t pix = (int64_t)p.N * p.H * p.W;
   const int nt64 = (p.Cout + 63) / 64;
   static const char* force = getenv("TG_C3_FORCE");       // experiment switch: "TH,BN" e.g. "4,32"
@@ -380,7 +389,8 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
     // multi-chunk (Cin > one 128-B chunk): the weight panel is re-staged per (tile, chunk) -> largest pixel tile
     // TG_C3_MAXTH=8 (A/B switch): <8,64> instead of <16,64> -- 109 KB LDS / ~300 registers instead of 130 KB / ~400, which
     // leaves room on the CU for a co-resident workgroup of the latency-bound <4,16> chain kernel (36 KB / 120 registers)
-    static const int maxth = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
+    static const int maxth_env = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
+    const int maxth = coexist ? 8 : maxth_env;             // TG_CONV_COEXIST: leave room for a chain workgroup
     if (maxth >= 16 && pix * nt64 >= (int64_t)16 * 16 * 256) launch3<TIn, TOut, 16, 64>(p, st);
     else if (pix * nt64 >= (int64_t)8 * 16 * 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (pix * nt64 >= (int64_t)4 * 16 * 256) launch3<TIn, TOut, 4, 64>(p, st);
@@ -392,7 +402,8 @@ static void launch3_typed(const Conv3P& p, hipStream_t st) {
     auto blocks = [&](int th, int bn) {
       return (int64_t)p.N * ((p.H + th - 1) / th) * ((p.W + 15) / 16) * ((p.Cout + bn - 1) / bn);
     };
-    static const int maxth = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
+    static const int maxth_env = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
+    const int maxth = coexist ? 8 : maxth_env;
     if (maxth >= 16 && blocks(16, 64) >= 256) launch3<TIn, TOut, 16, 64>(p, st);
     else if (maxth < 16 && blocks(8, 64) >= 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (blocks(16, 32) >= 256) launch3<TIn, TOut, 16, 32>(p, st);
@@ -563,6 +574,7 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   if (in_bytes >= ((int64_t)1 << 31) || w_bytes >= ((int64_t)1 << 31)) return 0;   // 32-bit buffer offsets
   if (aux && d->mask_act != TG_ACT_RELU && d->mask_act != TG_ACT_LRELU) return 0;   // generic engine handles others
   if (conv3x3_c8_try(d, in, weight, bias, res, aux, out, st)) return 1;
+  if (tg_conv3x3_ws_try(d, in, weight, bias, res, aux, out, st)) return 1;       // one-chunk layers in the throughput regime
   Conv3P p;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
@@ -571,10 +583,13 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   p.act = d->act; p.act_alpha = d->act_alpha;
   static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
   p.direct_epi = direct;
+  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 0;
+  p.prio = prio;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
-  if (d->in_dtype == TG_F32) launch3_typed<float, float>(p, st);
-  else if (d->out_dtype == TG_BF16) launch3_typed<u16, u16>(p, st);
-  else launch3_typed<u16, float>(p, st);
+  const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;
+  if (d->in_dtype == TG_F32) launch3_typed<float, float>(p, st, coexist);
+  else if (d->out_dtype == TG_BF16) launch3_typed<u16, u16>(p, st, coexist);
+  else launch3_typed<u16, float>(p, st, coexist);
   return 1;
 }

@@ -205,16 +205,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
 }
 
 template <bool HAS_RES, bool HAS_AUX>
-static void launch_ws(const ConvWsP& p, hipStream_t st) {
+static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   auto kern = conv3x3_ws_kernel<HAS_RES, HAS_AUX>;
-  constexpr int LDS = 2 * WS_BUF;
+  constexpr int LDS_MAX = 2 * WS_BUF + 32768;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
   });
+  // TG_CONV_COEXIST: ONE workgroup per CU (32 KB of unused LDS push the request past half the CU) -- two of them would
+  // take 480 of the SIMD's 512 registers and lock the latency-bound chain kernel out of the CU
+  const int LDS = coexist ? LDS_MAX : 2 * WS_BUF;
+  const int per_cu = coexist ? 1 : 2;
   const int nt = p.Cout / 64;
   int gx = p.ntiles;
-  const int cap = 512 / nt > 0 ? 512 / nt : 1;             // two workgroups per CU
+  const int cap = 256 * per_cu / nt > 0 ? 256 * per_cu / nt : 1;
   if (gx > cap) gx = cap;
   static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_ws<res,aux>" : "conv3x3_ws<res>")
                                            : (HAS_AUX ? "conv3x3_ws<aux>" : "conv3x3_ws<>");
@@ -249,9 +253,10 @@ int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight,
   if (ntiles < min_tiles || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-  if (res && aux) launch_ws<true, true>(p, st);
-  else if (res) launch_ws<true, false>(p, st);
-  else if (aux) launch_ws<false, true>(p, st);
-  else launch_ws<false, false>(p, st);
+  const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;
+  if (res && aux) launch_ws<true, true>(p, st, coexist);
+  else if (res) launch_ws<true, false>(p, st, coexist);
+  else if (aux) launch_ws<false, true>(p, st, coexist);
+  else launch_ws<false, false>(p, st, coexist);
   return 1;
 }

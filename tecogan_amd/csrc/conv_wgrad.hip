@@ -792,9 +792,12 @@ static int tg_wgrad_row3_launch(const tg_conv_desc* d, int groups, const void* c
   p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   p.nchunk = ksplit;
+  // TG_CONV_COEXIST: 24 KB of unused dynamic LDS cap the residency at 2 workgroups per CU (instead of 4), so that a
+  // workgroup of the latency-bound chain still finds registers on every CU while this launch runs beside it
+  const unsigned pad_lds = (d->flags & TG_CONV_COEXIST) ? 24576u : 0u;
   TG_LAUNCH("conv_wgrad_row3_bf16", 2.0 * groups * (double)M64 * 9.0 * d->Cin * d->Cout,
             groups * ((double)M64 * (ldx + ldy) * 2.0 + 36.0 * d->Cin * d->Cout), conv_wgrad_row3_bf16_kernel,
-            dim3((unsigned)(groups * base_blocks * ksplit)), dim3(256), 0, st, p);
+            dim3((unsigned)(groups * base_blocks * ksplit)), dim3(256), pad_lds, st, p);
   return 1;
 }
 
@@ -850,7 +853,7 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   const dim3 grid((unsigned)(d->KH * d->KW * xtiles * p.ytiles * ksplit));   // 1-D: the kernel maps work XCD-aware
-  const unsigned lds = 2u * 64u * (128u * pf + 8u);
+  const unsigned lds = 2u * 64u * (128u * pf + 8u) + ((d->flags & TG_CONV_COEXIST) && pf <= 2 ? 24576u : 0u);  // see row3
   static std::once_flag attr_once;                                    // PF = 4 needs 66.5 KB of dynamic LDS
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<4>),

@@ -89,6 +89,9 @@ class TrainEngine:
         self.host_step = 0
         self.gen = None
         self.side_stream = torch.cuda.Stream(device=self.dev)
+        # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
+        self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
+        self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
 
     # ------------------------------------------------------------------------------------------
@@ -158,13 +161,17 @@ class TrainEngine:
             torch.cuda.current_stream().wait_stream(self.comm_stream)      # join: all scopes reduced
         self._program_update()
 
-    def _exchange_async(self, scopes, with_balance=False):
+    def _exchange_async(self, scopes, with_balance=False, after=None):
         """captured mode: all-reduce `scopes` of the flat gradient buffer on the communication stream, ordered after
-        everything enqueued so far on the compute stream; the compute stream runs on (fork), `_program` joins."""
+        the event `after` (default: everything enqueued so far on the compute stream); the compute stream runs on
+        (fork), `_program` joins."""
         if self.exchange_mode != "captured":
             return
         import torch.distributed as dist
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            self.comm_stream.wait_event(after)
+        else:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
             if with_balance and self.gan:            # every rank must take the same D-gate branch (lib/Teco.py:493-494)
                 tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
@@ -180,8 +187,36 @@ class TrainEngine:
         return 4 * n + (4 if self.gan else 0)
 
     def _program_compute(self):
+        """Forward + backward of one step as a two-stream program (both streams are branches of one hipGraph).
+
+        The recurrent generator chain (T frames x ~38 dependent launches forward, as many backward) is latency bound:
+        each launch keeps one wave per SIMD busy for ~3.5 us, a third of the step during which >90 % of the chip's issue
+        slots idle.  Everything that does not depend on the chain's current position runs on the SIDE stream meanwhile,
+        with tile shapes whose LDS / register footprint lets a chain workgroup co-reside on the same CU
+        (TG_CONV_COEXIST; profiles/r02a_overlap.txt: 87 % of the chain hides under VGG-sized convolutions):
+            forward chain   ||  VGG target features, D real pass, VGG gen pass (fwd + dX) of the early frames
+            backward chain  ||  D's own-gradient passes, generator weight gradients of the late frames
+        TG_OVERLAP=0 runs the identical program on one stream (A/B switch; the results are the same either way)."""
         F, ps, B, T, h = self.F, self.ps, self.B, self.T, self.cs
         H = 4 * h
+        main = torch.cuda.current_stream()
+        ov = self.overlap
+        side = self.side_stream if ov else main
+        cx = K.CONV_COEXIST if ov else 0
+        hold = self._hold = []                  # tensors that cross streams stay referenced until the next step
+
+        forked = [False]
+
+        def after_main():                       # side continues after everything enqueued on main so far
+            if ov:
+                side.wait_stream(main)
+                forked[0] = True
+
+        def event(stream):
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
         ps.grad.zero_()
         self.zbuf.zero_()
         if self.gan:
@@ -189,12 +224,36 @@ class TrainEngine:
         # ping-pong extension (lib/Teco.py:80-85) + [B,T] -> frame-major [T,B] in one gather each
         lr_seq = K.seq_gather(self.in_lr, torch.empty(T, B, h, h, 3, device=self.dev), self.seq_idx)
         hr_seq = K.seq_gather(self.in_hr, torch.empty(T, B, H, H, 3, device=self.dev), self.seq_idx)
+        hold += [lr_seq, hr_seq]
         npair = (T - 1) * B
+        # ---- side: VGG-19 features of the targets (lib/Teco.py:177-178; needs hr_seq only) ---------------------
+        taps_t = ev_vggt = None
+        if self.use_vgg:
+            after_main()
+            with torch.cuda.stream(side):
+                xt = K.vgg_preprocess_forward(hr_seq.view(T * B, H, H, 3),
+                                              torch.empty(T * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+                taps_t, _ = self.V.forward(xt, keep=False, flags=cx)
+                ev_vggt = event(side)
+            hold += [xt, taps_t]
         # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
         pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
         cur_lr = lr_seq[1:].reshape(npair, h, h, 3)
         fnet_in = K.concat2_pad(pre_lr, cur_lr, torch.empty(npair, h, h, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
         flow, fsaved = self.Fn.forward(fnet_in)                                              # [npair,h,h,2] fp32
+        flow_t = flow.view(T - 1, B, h, h, 2)
+        hold += [flow, fsaved]
+        # ---- side: discriminator on the real triplets (needs the flows, not the generator) -----------------
+        gd = None
+        if self.gan:
+            gd = self._gan_setup(lr_seq, flow_t)
+            after_main()
+            with torch.cuda.stream(side):
+                gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
+                                                    gd["merge"])
+                gd["p_real"], gd["l_real"], gd["sv_real"] = self.D.forward(gd["real"], flags=cx)
+                gd["ev_real"] = event(side)
+            hold.append(gd)
         # ---- LR warp loss (lib/Teco.py:120-122,329-333) and its gradient to the flow ----------------
         warped_lr = K.warp_forward(pre_lr, flow, torch.empty_like(pre_lr))
         npx = float(npair * h * h)
@@ -203,48 +262,55 @@ class TrainEngine:
         d_wl = K.lincomb(warped_lr, cur_lr, torch.empty_like(warped_lr), c, -c)
         d_flow = torch.empty_like(flow)
         K.warp_backward(d_wl, pre_lr, flow, None, d_flow)
-        # ---- recurrent generator (lib/Teco.py:125-155) ------------------------------------------------
+        # ---- recurrent generator (lib/Teco.py:125-155); side: VGG pass of the early frames ----------------------
         gen = torch.empty(T, B, H, H, 3, device=self.dev)
-        flow_t = flow.view(T - 1, B, h, h, 2)
-        seq = self.G.begin_sequence(T, B, h, h, self.dev)
+        self.G.begin_sequence(T, B, h, h, self.dev)
+        seq = self.G.seq
+        tc = (T + 1) // 2 if T > 1 else T                # frames [0, tc): early chunk (side), [tc, T): late chunk (main)
+        d_vgg = ev_vgg_early = None
+        if self.use_vgg:
+            d_vgg = torch.empty(tc, B, H, H, 3, device=self.dev)        # VGG gradient w.r.t. the early frames (added to d_gen below)
+            hold.append(d_vgg)
         for t in range(T):
             K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], seq["x_in"][t], 0.5, 0.5)
             self.G.forward_t(t, gen[t])
+            if self.use_vgg and t == tc - 1:
+                after_main()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev_vggt)
+                    self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx, zero=True)
+                    ev_vgg_early = event(side)
         self.gen = gen
         # ---- generator losses seeded into d_gen -------------------------------------------------------
         nhr = float(T * B * H * H)
         K.sum_sq_diff(gen, hr_seq, 1.0 / nhr, self.loss[LI["l2_content_loss"]:LI["l2_content_loss"] + 1])
         d_gen = K.lincomb(gen, hr_seq, torch.empty_like(gen), 2.0 / nhr, -2.0 / nhr)         # lib/Teco.py:320-322
+        hold.append(d_gen)
         if F.pingpang:
             self._pingpong(gen, d_gen)
-        if self.use_vgg:
-            self._vgg(gen, hr_seq, d_gen)
         if self.gan:
-            self._gan(gen, hr_seq, lr_seq, flow_t, d_gen)
-        # ---- backward through the recurrence ------------------------------------------------------------
+            ev_dgrad = self._gan_fake_and_losses(gd, gen, lr_seq, d_gen, side, cx)
+            # D's gradients and t_balance are final after its own-gradient passes: their all-reduce overlaps the BPTT
+            self._exchange_async(["tdiscriminator"], with_balance=True, after=ev_dgrad)
+        if self.use_vgg:
+            if tc < T:                                               # late frames: straight into d_gen
+                main.wait_event(ev_vggt)
+                self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
+            main.wait_event(ev_vgg_early)                            # early frames: computed beside the forward chain
+            K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)
+        # ---- backward through the recurrence; side: weight gradients of the late frames ---------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
-        # The BPTT chain is strictly sequential and each of its launches fills at most half the chip; the
-        # weight gradients (shared weights: one launch per layer over many frames) and the FNet backward are
-        # independent of it, so they run on a side stream (parallel branches of the captured hipGraph).
-        main = torch.cuda.current_stream()
-        # measured on MI355X (same-session A/B): the parallel branches slow the latency-critical chain more than they hide
-        # (6.16 vs 6.00 ms FRVSR, 26.8 vs 25.8 ms TecoGAN), so the overlap is opt-in: TG_OVERLAP=1
-        side = self.side_stream if os.environ.get("TG_OVERLAP") else main
-        half = T // 2
         for t in range(T - 1, -1, -1):
             dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
-            if t == half and half > 0 and side is not main:
-                side.wait_stream(main)
+            if ov and t == tc and 0 < tc < T:
+                after_main()
                 with torch.cuda.stream(side):
-                    self.G.wgrad_sequence(half, T)
-        if side is not main:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.G.wgrad_sequence(0, half if (half > 0 and side is not main) else T)
-        if side is not main:
-            main.wait_stream(side)
+                    self.G.wgrad_sequence(tc, T, flags=cx)
+        if ov and forked[0]:
+            main.wait_stream(side)                                   # join: everything the side stream did is visible
+        self.G.wgrad_sequence(0, tc if (ov and 0 < tc < T) else T)
         self._exchange_async(["generator"])             # overlaps the FNet backward pass below
         self.Fn.backward(fsaved, d_flow)
         self._exchange_async(["fnet"])
@@ -276,28 +342,32 @@ class TrainEngine:
         K.pingpong(gen, d_gen, self.T, npair, 1.0 / cnt, (self.F.pp_scaling if self.F.pp_scaling > 0 else 0.0) / cnt,
                    self._slot("PingPang"))
 
-    def _vgg(self, gen, hr_seq, d_gen):
-        """lib/Teco.py:174-178,339-359: cosine distance of 4 L2-normalised VGG-19 taps, target pass forward only,
-        generated pass forward + dX backward (weights frozen).  The loss slots hold mean cos; losses() reports 1-cos."""
+    def _vgg_chunk(self, gen, taps_t, t0, t1, dst, flags, zero):
+        """lib/Teco.py:174-178,339-359 for frames [t0, t1): VGG-19 forward of the generated frames, cosine distance of the
+        four L2-normalised taps against the target taps (means over ALL T*B frames: the scales use the full count), dX
+        backward (weights frozen) accumulated into dst[t0:t1] (zero=True: dst is a scratch tensor, cleared first).  The loss slots hold mean cos; losses() reports 1 - cos."""
         F, T, B, H = self.F, self.T, self.B, 4 * self.cs
-        n = T * B
-        xg = K.vgg_preprocess_forward(gen.view(n, H, H, 3), torch.empty(n, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
-        xt = K.vgg_preprocess_forward(hr_seq.view(n, H, H, 3), torch.empty_like(xg))
-        taps_t, _ = self.V.forward(xt, keep=False)
-        taps_g, acts = self.V.forward(xg)
+        n = (t1 - t0) * B
+        xg = K.vgg_preprocess_forward(gen[t0:t1].view(n, H, H, 3),
+                                      torch.empty(n, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+        taps_g, acts = self.V.forward(xg, flags=flags)
         d_taps = {}
         for i, key in enumerate(VGG_TAPS):
-            g, t = taps_g[key], taps_t[key]
-            npix = float(g.numel() // g.shape[-1])
+            g = taps_g[key]
+            t = taps_t[key][t0 * B:t1 * B]
+            npix = float(T * B * g.shape[1] * g.shape[2])
             d = torch.empty_like(g)
             K.cosine_loss(g, t, 1.0 / npix, -F.vgg_scaling / npix, self._slot("vgg_loss_%d" % (i + 2)), d)
             d_taps[key] = d
-        del taps_t
-        dx = self.V.backward(acts, d_taps)
-        K.vgg_preprocess_backward(dx, d_gen)
+        dx = self.V.backward(acts, d_taps, flags=flags)
+        dv = dst[t0:t1]
+        if zero:
+            dv.zero_()
+        K.vgg_preprocess_backward(dx, dv)
+        self._hold += [xg, taps_g, acts, d_taps, dx]
 
-    def _gan(self, gen, hr_seq, lr_seq, flow_t, d_gen):
-        """lib/Teco.py:180-313,374-417: spatio-temporal discriminator on warped frame triplets."""
+    def _gan_setup(self, lr_seq, flow_t):
+        """Triplet bookkeeping of lib/Teco.py:180-220."""
         F, T, B, h = self.F, self.T, self.B, self.cs
         H = 4 * h
         t_size = 3 * (T // 3)
@@ -318,12 +388,22 @@ class TrainEngine:
         # merge: [before | warped (zero border) | bilinear LR context] = 27 channels at full size (lib/Teco.py:234-245);
         # otherwise only the 9 warped channels, cropped to (4h - 2 off)^2 (lib/Teco.py:231-232,249-250)
         merge = bool(F.Dt_mergeDs)
-        Ho = H if merge else H - 2 * off
-        args = (flow_t, flow_nxt, idx_pre, idx_nxt)
-        real = K.pack_d_input_forward(hr_seq, lr_seq, *args, torch.empty(tb, Ho, Ho, pad8(self.d_cin), device=self.dev, dtype=self.act_dtype), B, h, h, off, merge)
-        fake = K.pack_d_input_forward(gen, lr_seq, *args, torch.empty_like(real), B, h, h, off, merge)
-        p_real, l_real, sv_real = self.D.forward(real)
+        return dict(tb=tb, off=off, merge=merge, Ho=H if merge else H - 2 * off, args=(flow_t, flow_nxt, idx_pre, idx_nxt),
+                    flow_nxt=flow_nxt)
+
+    def _d_input_buf(self, gd):
+        return torch.empty(gd["tb"], gd["Ho"], gd["Ho"], pad8(self.d_cin), device=self.dev, dtype=self.act_dtype)
+
+    def _gan_fake_and_losses(self, gd, gen, lr_seq, d_gen, side, cx):
+        """lib/Teco.py:252-313,374-417: fake pass, losses, the generator-side gradient through D into d_gen (main stream);
+        D's own-gradient passes go to the side stream (they feed no gradient of the recurrence).  Returns the event after
+        which D's weight gradients are final."""
+        F, B, h = self.F, self.B, self.cs
+        main = torch.cuda.current_stream()
+        fake = K.pack_d_input_forward(gen, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"], gd["merge"])
         p_fake, l_fake, sv_fake = self.D.forward(fake)
+        main.wait_event(gd["ev_real"])
+        p_real, l_real, sv_real = gd["p_real"], gd["l_real"], gd["sv_real"]
         dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * (self.host_step - 1))   # Teco.py:379-380
         d_real_D, d_fake_D, d_fake_G = (torch.empty_like(p_real) for _ in range(3))
         # the five scalars land straight in their (contiguous) loss slots
@@ -340,14 +420,20 @@ class TrainEngine:
                 d = torch.empty_like(f)
                 K.l1_loss(r, f, 1.0 / npix, 0.02 / norm * dt_ratio / npix, self._slot("D_layer_%d_loss" % i), d)
                 d_layers.append(d)
-        # discriminator's own gradients (t_discrim_loss) from both passes
-        self.D.backward(sv_real, d_real_D, None, wgrad=True, need_dx=False)
-        self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False)
-        # D's gradients and t_balance are final: their all-reduce overlaps the generator-side D pass and the whole BPTT
-        self._exchange_async(["tdiscriminator"], with_balance=True)
+        # discriminator's own gradients (t_discrim_loss) from both passes: side stream (it was forked for the real pass)
+        if self.overlap:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.D.backward(sv_real, d_real_D, None, wgrad=True, need_dx=False, flags=cx)
+            self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False, flags=cx)
+            ev = torch.cuda.Event()
+            ev.record(side)
         # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
         dx = self.D.backward(sv_fake, d_fake_G, d_layers, wgrad=False, need_dx=True)
-        K.pack_d_input_backward(dx, gen, flow_t, flow_nxt, idx_pre, idx_nxt, d_gen, B, h, h, off, merge)
+        K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
+                                gd["off"], gd["merge"])
+        self._hold += [fake, p_fake, l_fake, sv_fake, d_real_D, d_fake_D, d_fake_G, d_layers, dx]
+        return ev
 
     # ------------------------------------------------------------------------------------------
     def losses(self):

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ConvDesc, TG_BF16, TG_F32, check, lib
+from ._lib import CONV_COEXIST, ConvDesc, TG_BF16, TG_F32, check, lib  # noqa: F401
 
 
 def _stream():
@@ -37,9 +37,9 @@ def same_pad(size, k, s):
 
 
 def conv_desc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, mode, in_dt, out_dt,
-              act=0, act_alpha=0.0, mask_act=0, mask_alpha=0.0):
+              act=0, act_alpha=0.0, mask_act=0, mask_alpha=0.0, flags=0):
     return ConvDesc(N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad_t, pad_l, mode, in_dt, out_dt,
-                    act, act_alpha, mask_act, mask_alpha)
+                    act, act_alpha, mask_act, mask_alpha, flags)
 
 
 def conv_forward(desc, x, w, bias, res, aux, out):

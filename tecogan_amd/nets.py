@@ -28,7 +28,7 @@ def _empty(shape, dtype, like):
 # --------------------------------------------------------------------------------------------------
 # layer primitives
 # --------------------------------------------------------------------------------------------------
-def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None, out=None):
+def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None, out=None, flags=0):
     """slim.conv2d SAME (reference lib/ops.py:47-56) + fused epilogue.  x [N,H,W,Cin_pad]."""
     e = ps.entries[wname]
     N, H, W, Cp = x.shape
@@ -38,12 +38,13 @@ def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, o
     Wo, pl = K.same_pad(W, k, stride)
     if out is None:
         out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
-    d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha)
+    d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha, flags=flags)
     K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
     return out
 
 
-def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, out=None):
+def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, out=None,
+                  flags=0):
     """Input gradient of conv_fwd: transposed mode over the natural (HWIO) copy.  -> [N,H,W,Cin_pad]."""
     e = ps.entries[wname]
     N, Ho, Wo, Co = dy.shape
@@ -53,12 +54,12 @@ def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=A
     _, pl = K.same_pad(W, k, stride)
     dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, Ho, Wo, Co, H, W, e["Apad"], k, k, stride, pt, pl, 1, K.dt(dy), K.dt(dx), 0, 0.0,
-                    mask_act, mask_alpha)
+                    mask_act, mask_alpha, flags=flags)
     K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)
     return dx
 
 
-def conv_wgrad(ps, wname, bname, x, dy, stride=1):
+def conv_wgrad(ps, wname, bname, x, dy, stride=1, flags=0):
     """dW (HWIO) and dbias accumulated into the flat gradient buffer."""
     e = ps.entries[wname]
     N, H, W, Cp = x.shape
@@ -66,7 +67,7 @@ def conv_wgrad(ps, wname, bname, x, dy, stride=1):
     k = e["k"]
     _, pt = K.same_pad(H, k, stride)
     _, pl = K.same_pad(W, k, stride)
-    d = K.conv_desc(N, H, W, e["A"], Ho, Wo, e["B"], k, k, stride, pt, pl, 0, 0, 0)     # logical channel counts
+    d = K.conv_desc(N, H, W, e["A"], Ho, Wo, e["B"], k, k, stride, pt, pl, 0, 0, 0, flags=flags)     # logical channel counts
     K.conv_wgrad(d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, ldx=Cp, ldy=Co)
 
 
@@ -93,12 +94,12 @@ def deconv_bwd_data(ps, wname, dy, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, 
     return dx
 
 
-def deconv_wgrad(ps, wname, bname, x, dy):
+def deconv_wgrad(ps, wname, bname, x, dy, flags=0):
     """dW in TF [kh,kw,Cout,Cin] layout: X := dy (gathered, stride 2), Y := x; dbias = colsum(dy)."""
     e = ps.entries[wname]
     N, H2, W2, Co = dy.shape
     k = e["k"]
-    d = K.conv_desc(N, H2, W2, Co, H2 // 2, W2 // 2, e["B"], k, k, 2, 0, 0, 0, 0, 0)
+    d = K.conv_desc(N, H2, W2, Co, H2 // 2, W2 // 2, e["B"], k, k, 2, 0, 0, 0, 0, 0, flags=flags)
     K.conv_wgrad(d, dy, x, ps.gview(wname), None)
     K.colsum(dy, dy.numel() // Co, Co, ps.gview(bname))
 
@@ -225,8 +226,9 @@ class Generator:
             return None
         return conv_bwd_data(ps, p + "input_stage/conv/Conv/weights", g, (h, w), 1, out=q["dx_in"])
 
-    def wgrad_sequence(self, t0=0, t1=None):
-        """Weight / bias gradients of frames [t0, t1): one launch per layer over the (t1-t0)*B frames."""
+    def wgrad_sequence(self, t0=0, t1=None, flags=0):
+        """Weight / bias gradients of frames [t0, t1): one launch per layer over the (t1-t0)*B frames.
+        flags: K.CONV_COEXIST when the launches run beside the BPTT chain (capped residency)."""
         ps, p, q, n = self.ps, self.P, self.seq, self.nres
         t1 = q["T"] if t1 is None else t1
         if t1 <= t0:
@@ -237,7 +239,7 @@ class Generator:
             return x.reshape(-1, *x.shape[2:])
 
         conv_wgrad(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", flat(q["x_in"]),
-                   flat(q["g_in"]))
+                   flat(q["g_in"]), flags=flags)
         if self.grouped_wgrad and n >= 1:
             # the 2n res-block convs have one geometry and their gradients are all due here: ONE grouped launch
             # (tg_conv_wgrad_grouped) instead of 2n -- the per-launch fixed cost is paid once
@@ -251,7 +253,7 @@ class Generator:
             N, H, W, Cp = xs[0].shape
             _, pt = K.same_pad(H, e["k"], 1)
             _, pl = K.same_pad(W, e["k"], 1)
-            d = K.conv_desc(N, H, W, e["A"], H, W, e["B"], e["k"], e["k"], 1, pt, pl, 0, 0, 0)
+            d = K.conv_desc(N, H, W, e["A"], H, W, e["B"], e["k"], e["k"], 1, pt, pl, 0, 0, 0, flags=flags)
             for g0 in range(0, len(names), 40):                     # TG_WGRAD_MAX_GROUPS per call
                 sl = slice(g0, g0 + 40)
                 K.conv_wgrad_grouped(d, xs[sl], dys[sl], [ps.gview(nm + "weights") for nm in names[sl]],
@@ -259,13 +261,15 @@ class Generator:
         else:
             for i in range(1, n + 1):
                 sc = p + "resblock_%d/" % i
-                conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", flat(q["a"][i - 1]), flat(q["g_c1"][i]))
-                conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", flat(q["r"][i]), flat(q["g_c2"][i]))
+                conv_wgrad(ps, sc + "conv_1/Conv/weights", sc + "conv_1/Conv/biases", flat(q["a"][i - 1]), flat(q["g_c1"][i]),
+                           flags=flags)
+                conv_wgrad(ps, sc + "conv_2/Conv/weights", sc + "conv_2/Conv/biases", flat(q["r"][i]), flat(q["g_c2"][i]),
+                           flags=flags)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
-        deconv_wgrad(ps, s % 1 + "weights", s % 1 + "biases", flat(q["a"][n]), flat(q["g_t1"]))
-        deconv_wgrad(ps, s % 2 + "weights", s % 2 + "biases", flat(q["t1"]), flat(q["g_t2"]))
+        deconv_wgrad(ps, s % 1 + "weights", s % 1 + "biases", flat(q["a"][n]), flat(q["g_t1"]), flags=flags)
+        deconv_wgrad(ps, s % 2 + "weights", s % 2 + "biases", flat(q["t1"]), flat(q["g_t2"]), flags=flags)
         conv_wgrad(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", flat(q["t2"]),
-                   flat(q["g_out"]))
+                   flat(q["g_out"]), flags=flags)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -357,13 +361,14 @@ class Discriminator:
         assert self._cursor <= self.scratch.numel(), "BN scratch pool too small"
         return self.scratch[a:a + 2 * co].view(2, co), True
 
-    def forward(self, x, keep=True, update_moving=True):
+    def forward(self, x, keep=True, update_moving=True, flags=0):
         """x [tb,H,W,32|16] -> (prob [tb,H/16,W/16,1] fp32, [4 layer maps], saved)."""
         ps, p = self.ps, self.P
-        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x, 1, ACT_LRELU, 0.2)
+        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x, 1, ACT_LRELU, 0.2,
+                     flags=flags)
         saved, layers, net = [], [], a
         for bi, (name, _, co) in enumerate(DIS_BLOCKS):
-            c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2)
+            c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2, flags=flags)
             y = torch.empty_like(c)
             stats, pz = self._ws(co, c)
             K.bn_lrelu_forward(c, y, ps.view(p + name + "/BatchNorm/beta"), 1e-3, 0.2, stats,
@@ -375,7 +380,7 @@ class Discriminator:
                         out_dtype=_F32)
         return prob, layers, ((x, a, saved, prob) if keep else None)
 
-    def backward(self, saved_all, d_prob, d_layers=None, wgrad=True, need_dx=False):
+    def backward(self, saved_all, d_prob, d_layers=None, wgrad=True, need_dx=False, flags=0):
         """d_prob fp32 [tb,h,w,1]; d_layers: optional list of 4 gradients (act dtype) w.r.t. the layer maps.
         wgrad=False leaves the discriminator's own gradients untouched (generator-side pass)."""
         ps, p = self.ps, self.P
@@ -384,8 +389,8 @@ class Discriminator:
         wn, bn = p + "dense_layer_2/dense/kernel", p + "dense_layer_2/dense/bias"
         y_last = saved[-1][2]
         if wgrad:
-            conv_wgrad(ps, wn, bn, y_last, g)
-        g = conv_bwd_data(ps, wn, g, y_last.shape[1:3], 1, res=d_layers[3] if d_layers else None)
+            conv_wgrad(ps, wn, bn, y_last, g, flags=flags)
+        g = conv_bwd_data(ps, wn, g, y_last.shape[1:3], 1, res=d_layers[3] if d_layers else None, flags=flags)
         for bi in range(len(DIS_BLOCKS) - 1, -1, -1):
             name, _, co = DIS_BLOCKS[bi]
             net_in, c, y, stats = saved[bi]
@@ -393,17 +398,17 @@ class Discriminator:
             dbeta = ps.gview(p + name + "/BatchNorm/beta") if wgrad else None
             dcv = K.bn_lrelu_backward(c, y, g, torch.empty_like(c), stats, 1e-3, 0.2, dbeta, ws, prezeroed=pz)
             if wgrad:
-                conv_wgrad(ps, p + name + "/conv1/Conv/weights", None, net_in, dcv, 2)
+                conv_wgrad(ps, p + name + "/conv1/Conv/weights", None, net_in, dcv, 2, flags=flags)
             if bi > 0:
                 g = conv_bwd_data(ps, p + name + "/conv1/Conv/weights", dcv, net_in.shape[1:3], 2,
-                                  res=d_layers[bi - 1] if d_layers else None)
+                                  res=d_layers[bi - 1] if d_layers else None, flags=flags)
             else:   # net_in = a = lrelu(input conv)
                 g = conv_bwd_data(ps, p + name + "/conv1/Conv/weights", dcv, net_in.shape[1:3], 2, aux=a,
-                                  mask_act=ACT_LRELU, mask_alpha=0.2)
+                                  mask_act=ACT_LRELU, mask_alpha=0.2, flags=flags)
         wn, bn = p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases"
         if wgrad:
-            conv_wgrad(ps, wn, bn, x, g)
-        return conv_bwd_data(ps, wn, g, x.shape[1:3], 1) if need_dx else None
+            conv_wgrad(ps, wn, bn, x, g, flags=flags)
+        return conv_bwd_data(ps, wn, g, x.shape[1:3], 1, flags=flags) if need_dx else None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -417,7 +422,7 @@ class VGG19:
     def __init__(self, ps):
         self.ps = ps
 
-    def forward(self, x, keep=True):
+    def forward(self, x, keep=True, flags=0):
         """x [N,H,W,8]: VGG-preprocessed image (lib/Teco.py:9-10) zero-padded to 8 channels.
         Returns the four post-ReLU taps (un-normalised) and the activations for backward."""
         ps = self.ps
@@ -426,7 +431,7 @@ class VGG19:
             for j in range(1, reps + 1):
                 key = "vgg_19/conv%d/conv%d_%d" % (blk, blk, j)
                 inp = net
-                net = conv_fwd(ps, key + "/weights", key + "/biases", inp, 1, ACT_RELU)
+                net = conv_fwd(ps, key + "/weights", key + "/biases", inp, 1, ACT_RELU, flags=flags)
                 acts.append((key, inp, net))
                 if key in VGG_TAPS:
                     taps[key] = net
@@ -438,7 +443,7 @@ class VGG19:
             net = pooled
         return taps, (acts if keep else None)
 
-    def backward(self, acts, d_taps):
+    def backward(self, acts, d_taps, flags=0):
         """d_taps: key -> gradient w.r.t. the (post-ReLU) tap.  Returns d x [N,H,W,8] (dX only: the VGG
         weights are frozen).  `g` is always the gradient w.r.t. a conv's PRE-activation: the ReLU
         derivative of the producing layer is fused into the consumer's bwd_data epilogue (conv -> conv)
@@ -457,5 +462,5 @@ class VGG19:
                 g = K.act_backward(d_taps[key], out, torch.empty_like(out), ACT_RELU)
             producer_is_conv = idx > 0 and not acts[idx - 1][0].startswith("pool")
             g = conv_bwd_data(ps, key + "/weights", g, inp.shape[1:3], 1, aux=inp if producer_is_conv else None,
-                              mask_act=ACT_RELU if producer_is_conv else ACT_NONE)
+                              mask_act=ACT_RELU if producer_is_conv else ACT_NONE, flags=flags)
         return g

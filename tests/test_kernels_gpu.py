@@ -805,3 +805,58 @@ def test_launch_profiler_counts_and_flops():
     assert ents[0]["flops"] == 3 * 2.0 * 16 * 16 * 64 * 9 * 64
     assert 0.5 < ents[0]["total_us"] / 3 < 200.0, ents
     assert K.prof_collect() == []
+
+
+# ---- conv3x3_ws.hip: weights-in-registers / LDS-DMA kernel for one-chunk layers (>= 256 tiles of 8x16 pixels) -----
+WS_CASES = [
+    # N, H, W, Cin, Cout, flip(bwd_data form), res, aux(mask), act
+    (1, 270, 250, 64, 64, False, False, False, ACT_RELU),     # ragged right/bottom edges, persistent tile loop
+    (2, 128, 128, 64, 64, False, True, False, ACT_NONE),      # residual epilogue (res-block conv_2)
+    (1, 135, 240, 56, 64, False, False, False, ACT_RELU),     # Cin = 56 (generator input conv): zero-filled chunk
+    (3, 64, 96, 64, 128, False, False, False, ACT_LRELU),     # two channel tiles (grid.y = 2)
+    (2, 128, 128, 64, 64, True, True, True, ACT_NONE),        # input-gradient form: mirrored taps + residual + ReLU mask
+    (1, 200, 170, 32, 64, True, False, True, ACT_NONE),       # Cin = 32, LeakyReLU mask
+    (1, 1080, 1920, 16, 64, False, False, False, ACT_RELU),   # > 2^16 tiles per image row block; Cin = 16
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+@pytest.mark.parametrize("coexist", [0, 1])
+def test_conv3x3_weights_in_registers_kernel(case, coexist):
+    N, H, W, Cin, Cout, flip, has_res, has_aux, act = case
+    if coexist and H * W > 300 * 300:
+        pytest.skip("one size is enough for the residency-capped launch")
+    x = rnd(N, H, W, Cin, seed=1).bfloat16()
+    w = rnd(3, 3, Cin, Cout, seed=2, scale=0.1).bfloat16()               # HWIO, as conv2 sees it
+    b = None if flip else rnd(Cout, seed=3)
+    res = rnd(N, H, W, Cout, seed=4).bfloat16() if has_res else None
+    aux = rnd(N, H, W, Cout, seed=5).bfloat16() if has_aux else None
+    alpha = 0.2 if act == ACT_LRELU else 0.0
+    mask_act = ACT_LRELU if (has_aux and Cin == 32) else (ACT_RELU if has_aux else ACT_NONE)
+    mask_alpha = 0.2 if mask_act == ACT_LRELU else 0.0
+    # reference: mirrored taps == conv with the spatially flipped kernel
+    wr = w.float().flip(0, 1) if flip else w.float()
+    ref = O.conv2(x.float(), wr, b, 1)
+    if act == ACT_RELU:
+        ref = torch.relu(ref)
+    elif act == ACT_LRELU:
+        ref = torch.where(ref > 0, ref, ref * alpha)
+    if has_res:
+        ref = ref + res.float()
+    if has_aux:
+        ref = ref * torch.where(aux.float() > 0, torch.ones(()), torch.full((), 1.0 if mask_act == ACT_NONE else mask_alpha))
+    wt = w.permute(0, 1, 3, 2).reshape(9, Cout, Cin).contiguous().to(DEV)     # [tap][Cout][Cin]
+    out = torch.full((N, H, W, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
+    d = K.conv_desc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1 if flip else 0, TG_BF16, TG_BF16, act, alpha, mask_act,
+                    mask_alpha, flags=coexist)
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_forward(d, x.to(DEV), wt, None if b is None else b.to(DEV), None if res is None else res.to(DEV),
+                   None if aux is None else aux.to(DEV), out)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"].startswith("conv3x3_ws"), "the weights-in-registers kernel was not selected: %s" % ents
+    # bf16 output rounding: 2^-8 relative per element, against values that reach a few units
+    close(out, ref, 8e-3, "conv3x3_ws %s" % (case,))
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 8e-3 * ref.abs() + 2e-2).all(), "per-element: max %g" % err.max().item()
