@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
 #pragma unroll
     for (int k = 0; k < WS_KPW; ++k) {
       const int inst = wave + 4 * k;
-      if (inst < WS_NDMA) {                                                 // wave-uniform
+      // only the last round is partial (26 instructions over 4 waves): the others issue unconditionally, branch-free
+      if (4 * k + 3 < WS_NDMA || inst < WS_NDMA) {                          // wave-uniform
         const int dy = code[k] & 255, dx = (code[k] >> 8) & 255, c = (code[k] >> 16) & 255;
         const bool ok = (code[k] >> 24) && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
         const unsigned off = ok ? (unsigned)(base + (dy * p.W + dx) * row_bytes + c * 16) : WS_OOB;
@@ -127,11 +128,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
       bv[j][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
     }
 
+  // Loop-carried synchronisation.  Per tile and wave the VMEM queue holds, in issue order: the next tile's DMA slots,
+  // [the residual / mask loads, consumed by the epilogue], the 8 epilogue stores.  Before reading the next tile only the
+  // DMA has to have landed, so the wait at the bottom of the loop is vmcnt(8): everything but the 8 youngest operations
+  // (vmcnt retires in issue order on gfx9-family parts) -- draining the stores too (vmcnt(0), or the vmcnt(0) that
+  // __syncthreads() adds while a DMA is in flight) exposed a full store round trip per tile.  Hence also the raw s_barrier.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first tile: this wave's DMA slots and its weight fragments
   int buf = 0;
-  while (tile < p.ntiles) {
+  while (true) {
     const int ntile = tile + gridDim.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA slots of the current tile (and, first time, its weights)
-    __syncthreads();                                        // every wave's slots landed; nobody still reads the other buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // every wave's slots landed; nobody still reads the other buffer
     if (ntile < p.ntiles) issue_dma(ntile, buf ^ 1);        // flies during the MFMA block and the epilogue below
     __builtin_amdgcn_sched_barrier(0);
 
@@ -200,7 +207,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
       }
     }
     tile = ntile;
+    if (tile >= p.ntiles) break;
     buf ^= 1;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // the DMA of the tile we turn to has landed (stores may still fly)
   }
 }
 
@@ -214,8 +223,9 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   });
   // TG_CONV_COEXIST: ONE workgroup per CU (32 KB of unused LDS push the request past half the CU) -- two of them would
   // take 480 of the SIMD's 512 registers and lock the latency-bound chain kernel out of the CU
-  const int LDS = coexist ? LDS_MAX : 2 * WS_BUF;
-  const int per_cu = coexist ? 1 : 2;
+  static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 2;      // A/B switch
+  const int per_cu = (coexist || per_cu_env < 2) ? 1 : 2;
+  const int LDS = per_cu == 1 ? LDS_MAX : 2 * WS_BUF;
   const int nt = p.Cout / 64;
   int gx = p.ntiles;
   const int cap = 256 * per_cu / nt > 0 ? 256 * per_cu / nt : 1;

@@ -91,6 +91,9 @@ class TrainEngine:
         self.side_stream = torch.cuda.Stream(device=self.dev)
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
+        # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
+        # frames, 8 D's own-gradient passes, 16 generator weight gradients of the late frames
+        self.ov_parts = int(os.environ.get("TG_OVERLAP_PARTS", "15")) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
 
@@ -201,16 +204,17 @@ class TrainEngine:
         H = 4 * h
         main = torch.cuda.current_stream()
         ov = self.overlap
-        side = self.side_stream if ov else main
-        cx = K.CONV_COEXIST if ov else 0
         hold = self._hold = []                  # tensors that cross streams stay referenced until the next step
-
         forked = [False]
 
-        def after_main():                       # side continues after everything enqueued on main so far
-            if ov:
-                side.wait_stream(main)
-                forked[0] = True
+        def part(bit):
+            """(stream, conv footprint flag) for schedule piece `bit`: the side stream, forked after everything enqueued
+            on main so far, or main itself when the piece is not overlapped."""
+            if not (self.ov_parts & bit):
+                return main, 0
+            self.side_stream.wait_stream(main)
+            forked[0] = True
+            return self.side_stream, K.CONV_COEXIST
 
         def event(stream):
             e = torch.cuda.Event()
@@ -229,7 +233,7 @@ class TrainEngine:
         # ---- side: VGG-19 features of the targets (lib/Teco.py:177-178; needs hr_seq only) ---------------------
         taps_t = ev_vggt = None
         if self.use_vgg:
-            after_main()
+            side, cx = part(1)
             with torch.cuda.stream(side):
                 xt = K.vgg_preprocess_forward(hr_seq.view(T * B, H, H, 3),
                                               torch.empty(T * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
@@ -247,7 +251,7 @@ class TrainEngine:
         gd = None
         if self.gan:
             gd = self._gan_setup(lr_seq, flow_t)
-            after_main()
+            side, cx = part(2)
             with torch.cuda.stream(side):
                 gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
                                                     gd["merge"])
@@ -275,7 +279,7 @@ class TrainEngine:
             K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], seq["x_in"][t], 0.5, 0.5)
             self.G.forward_t(t, gen[t])
             if self.use_vgg and t == tc - 1:
-                after_main()
+                side, cx = part(4)
                 with torch.cuda.stream(side):
                     side.wait_event(ev_vggt)
                     self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx, zero=True)
@@ -289,7 +293,7 @@ class TrainEngine:
         if F.pingpang:
             self._pingpong(gen, d_gen)
         if self.gan:
-            ev_dgrad = self._gan_fake_and_losses(gd, gen, lr_seq, d_gen, side, cx)
+            ev_dgrad = self._gan_fake_and_losses(gd, gen, lr_seq, d_gen, part)
             # D's gradients and t_balance are final after its own-gradient passes: their all-reduce overlaps the BPTT
             self._exchange_async(["tdiscriminator"], with_balance=True, after=ev_dgrad)
         if self.use_vgg:
@@ -304,13 +308,13 @@ class TrainEngine:
             dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
             if t > 0:
                 K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
-            if ov and t == tc and 0 < tc < T:
-                after_main()
+            if (self.ov_parts & 16) and t == tc and 0 < tc < T:
+                side, cx = part(16)
                 with torch.cuda.stream(side):
                     self.G.wgrad_sequence(tc, T, flags=cx)
-        if ov and forked[0]:
-            main.wait_stream(side)                                   # join: everything the side stream did is visible
-        self.G.wgrad_sequence(0, tc if (ov and 0 < tc < T) else T)
+        if forked[0]:
+            main.wait_stream(self.side_stream)                       # join: everything the side stream did is visible
+        self.G.wgrad_sequence(0, tc if ((self.ov_parts & 16) and 0 < tc < T) else T)
         self._exchange_async(["generator"])             # overlaps the FNet backward pass below
         self.Fn.backward(fsaved, d_flow)
         self._exchange_async(["fnet"])
@@ -394,7 +398,7 @@ class TrainEngine:
     def _d_input_buf(self, gd):
         return torch.empty(gd["tb"], gd["Ho"], gd["Ho"], pad8(self.d_cin), device=self.dev, dtype=self.act_dtype)
 
-    def _gan_fake_and_losses(self, gd, gen, lr_seq, d_gen, side, cx):
+    def _gan_fake_and_losses(self, gd, gen, lr_seq, d_gen, part):
         """lib/Teco.py:252-313,374-417: fake pass, losses, the generator-side gradient through D into d_gen (main stream);
         D's own-gradient passes go to the side stream (they feed no gradient of the recurrence).  Returns the event after
         which D's weight gradients are final."""
@@ -420,9 +424,8 @@ class TrainEngine:
                 d = torch.empty_like(f)
                 K.l1_loss(r, f, 1.0 / npix, 0.02 / norm * dt_ratio / npix, self._slot("D_layer_%d_loss" % i), d)
                 d_layers.append(d)
-        # discriminator's own gradients (t_discrim_loss) from both passes: side stream (it was forked for the real pass)
-        if self.overlap:
-            side.wait_stream(main)
+        # discriminator's own gradients (t_discrim_loss) from both passes: side stream
+        side, cx = part(8)
         with torch.cuda.stream(side):
             self.D.backward(sv_real, d_real_D, None, wgrad=True, need_dx=False, flags=cx)
             self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False, flags=cx)

@@ -67,6 +67,7 @@ def wgrad_case(N, H, W, Cin, Cout, k=3, s=1, dtype=torch.bfloat16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="", help="substring filter on the case name")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cases = [
@@ -83,6 +84,9 @@ def main():
         ("conv3x3 vgg  [76,16,16,512->512]", conv_case(76, 16, 16, 512, 512, dtype=dt)),
         ("conv4x4s2 D  [24,128,128,64->64]", conv_case(24, 128, 128, 64, 64, 4, 2, 0, dt)),
         ("conv3x3 inf  [1,270,480,64->64]", conv_case(1, 270, 480, 64, 64, dtype=dt)),
+        ("conv3x3 inf  [1,270,480,56->64]", conv_case(1, 270, 480, 56, 64, dtype=dt)),
+        ("conv3x3 D-in [24,128,128,32->64]", conv_case(24, 128, 128, 32, 64, dtype=dt)),
+        ("conv3x3 fnet [72,32,32,64->64]", conv_case(72, 32, 32, 64, 64, dtype=dt)),
         ("conv3x3 inf  [1,1080,1920,64->3]", conv_case(1, 1080, 1920, 64, 3, dtype=dt)),
         ("wgrad gen    [40,32,32,64->64]", wgrad_case(40, 32, 32, 64, 64, dtype=dt)),
         ("wgrad tran2  [40,128,128,64] s2", wgrad_case(40, 128, 128, 64, 64, 3, 2, dtype=dt)),
@@ -92,6 +96,8 @@ def main():
     ]
     print("%-52s %10s %10s %10s" % ("case (%s)" % a.dtype, "eager us", "graph us", "TFLOP/s"))
     for name, (fn, flops) in cases:
+        if a.only and a.only not in name:
+            continue
         t1 = timeit(fn)
         t2 = graph_timeit(fn)
         print("%-52s %10.2f %10.2f %10.1f" % (name, t1, t2, flops / t2 / 1e6))
