@@ -182,9 +182,12 @@ int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, int N, int H
                           void* stream);
 
 /* out = (conv_out + bicubic_four(lr)) * 2 - 1   (lib/frvsr.py:81-87, lib/ops.py:166-212).
- * lr is read from the first 3 channels of the generator input buffer [B,h,w,Cpad]. */
+ * lr is read from the first 3 channels of the generator input buffer [B,h,w,Cpad].
+ * state (nullable): also write deprocess(out) = (out + 1) / 2, the recurrent state of the inference loop (main.py:207);
+ * out may then be NULL (the inference step keeps only the state). */
 int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void* gen_in, int in_dtype, int Cpad,
-                              float* out, int B, int h, int w, void* stream);
+                              float* out /*nullable if state*/, float* state /*nullable*/, int B, int h, int w,
+                              void* stream);
 
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.

@@ -117,9 +117,9 @@ def forward_losses(P, vggP, r_inputs, r_targets, F, gan, bn_state=None, global_s
 
         def d_input(frames):                                     # Teco.py:224-245 / 254-269
             warped = O.pack_triplets(O.dense_image_warp(frames, T_vel), tb)
+            if not F.Dt_mergeDs:                                 # Teco.py:231-232,249-250: cropped, NOT padded back
+                return warped[:, off:H - off, off:H - off] if off else warped
             warped = O.crop_pad_dt(warped, off)
-            if not F.Dt_mergeDs:
-                return warped
             return torch.cat((O.pack_triplets(frames, tb), warped, input_hi), -1)
 
         real_out, real_layers = NN.discriminator_F(P, d_input(t_tar), bn_state)

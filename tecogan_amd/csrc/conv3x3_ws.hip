@@ -54,6 +54,20 @@ constexpr int WS_KPW = (WS_NDMA + 3) / 4;                  // DMA instructions p
 constexpr unsigned WS_OOB = 0x80000000u;
 }  // namespace
 
+// Cycle stamps (tools/trace_ws.py builds a private -DTG_WS_TRACE copy of the library; the product build has none of it).
+#ifdef TG_WS_TRACE
+__device__ unsigned long long tg_ws_trace_buf[64];
+#define WS_STAMP(i)                                                                                         \
+  do {                                                                                                      \
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && (i) < 64) tg_ws_trace_buf[(i)] = (unsigned long long)clock64(); \
+  } while (0)
+extern "C" int tg_debug_ws_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_ws_trace_buf), sizeof(unsigned long long) * 64);
+}
+#else
+#define WS_STAMP(i) do { } while (0)
+#endif
+
 template <bool HAS_RES, bool HAS_AUX>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF
@@ -102,7 +116,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
 
   int tile = blockIdx.x;
   if (tile >= p.ntiles) return;
+  WS_STAMP(0);
   issue_dma(tile, 0);
+  WS_STAMP(1);
 
   // ---- weights -> registers: lane (frow, fg) of fragment (tap, kk, j) holds w[tap][cbase + 16 j + frow][32 kk + 8 fg .. +7]
   u32x4w wf[9][2][2];
@@ -133,14 +149,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   // DMA has to have landed, so the wait at the bottom of the loop is vmcnt(8): everything but the 8 youngest operations
   // (vmcnt retires in issue order on gfx9-family parts) -- draining the stores too (vmcnt(0), or the vmcnt(0) that
   // __syncthreads() adds while a DMA is in flight) exposed a full store round trip per tile.  Hence also the raw s_barrier.
+  WS_STAMP(2);                                              // weight loads issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first tile: this wave's DMA slots and its weight fragments
+  WS_STAMP(3);
   int buf = 0;
+  [[maybe_unused]] int it = 0;
   while (true) {
     const int ntile = tile + gridDim.x;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                           // every wave's slots landed; nobody still reads the other buffer
+    WS_STAMP(4 + 5 * it);
     if (ntile < p.ntiles) issue_dma(ntile, buf ^ 1);        // flies during the MFMA block and the epilogue below
     __builtin_amdgcn_sched_barrier(0);
+    WS_STAMP(5 + 5 * it);
 
     const unsigned char* Afrag = smem + buf * WS_BUF + ((wm * 4) * 18 + frow) * WS_ROWB + fg * 16;
     f32x4 acc[4][2];
@@ -166,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
       }
     }
 
+    WS_STAMP(6 + 5 * it);                                   // MFMA block issued (the last results may still be in the pipe)
     // ---- epilogue in registers: accumulator r of lane (frow, fg) = pixel column frow, output channel cbase+16j+4fg+r
     {
       const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
@@ -206,11 +228,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
         }
       }
     }
+    WS_STAMP(7 + 5 * it);                                   // epilogue stores issued
     tile = ntile;
     if (tile >= p.ntiles) break;
     buf ^= 1;
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // the DMA of the tile we turn to has landed (stores may still fly)
+    WS_STAMP(8 + 5 * it);
+    ++it;
   }
+#ifdef TG_WS_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WS_STAMP(63);
+#endif
 }
 
 template <bool HAS_RES, bool HAS_AUX>

@@ -174,6 +174,35 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict_
   }
 }
 
+// bf16, C % 8 == 0: one thread per (output pixel, channel octet), 16-byte loads / stores, 32-bit index math; the same
+// lerp expressions as the scalar kernel (bit-identical results).
+__global__ __launch_bounds__(256) void upsample2_fwd_x8_kernel(const u16* __restrict__ in, u16* __restrict__ out, int N, int H,
+                                                               int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W, C8 = C >> 3;
+  const int n = N * Ho * Wo * C8;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int c8 = e % C8;
+    int t = e / C8;
+    const int X = t % Wo;
+    t /= Wo;
+    const int Y = t % Ho, b = t / Ho;
+    const int i = Y >> 1, j = X >> 1, i1 = min(i + 1, H - 1), j1 = min(j + 1, W - 1);
+    const float ya = 0.5f * (Y & 1), xa = 0.5f * (X & 1);
+    const u16* __restrict__ base = in + (int64_t)b * H * W * C + c8 * 8;
+    float tl[8], tr[8], bl[8], br[8], o[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)i * W + j) * C), tl);
+    bf8_unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)i * W + j1) * C), tr);
+    bf8_unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)i1 * W + j) * C), bl);
+    bf8_unpack(*reinterpret_cast<const uint4*>(base + ((int64_t)i1 * W + j1) * C), br);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float top = tl[k] + (tr[k] - tl[k]) * xa, bot = bl[k] + (br[k] - bl[k]) * xa;
+      o[k] = top + (bot - top) * ya;
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)e * 8) = bf8_pack(o);
+  }
+}
+
 // contributions of output index o to input index i along one axis: list (o, weight)
 __device__ __forceinline__ int up2_terms(int i, int n, int* o, float* wgt) {
   int k = 0;
@@ -251,6 +280,69 @@ __global__ __launch_bounds__(256) void bicubic_add_kernel(const float* __restric
       }
       const float bic = wx[0] * col[0] + wx[1] * col[1] + wx[2] * col[2] + wx[3] * col[3];
       out[pix * 3 + c] = (conv_out[pix * 3 + c] + bic) * 2.f - 1.f;
+    }
+  }
+}
+
+// Row-quad form: one thread per (HR row Y, LR column j) = four horizontally adjacent HR pixels.  They share the 4x4 LR
+// neighbourhood (fetched once: 16 pixels instead of 64) and the four row-interpolated columns (the weights of the row pass
+// depend on Y & 3 only); conv_out arrives and the frame leaves as 3 x 16-byte vectors.  Optionally also writes the
+// deprocessed frame (x + 1) / 2 -- the recurrent state of the inference loop (main.py:207) -- so that pass disappears.
+// Same operation order as the per-pixel kernel: rows first, then columns (lib/ops.py:190-210).
+template <typename TI>
+__global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __restrict__ conv_out,
+                                                               const TI* __restrict__ gen_in, int Cpad,
+                                                               float* __restrict__ out, float* __restrict__ state, int B,
+                                                               int h, int w) {
+  const int H = 4 * h;
+  const int n = B * H * w;                                  // < 2^31 (checked by the host)
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int j = e % w, Y = (e / w) % H, b = e / (w * H);
+    const int i = Y >> 2;
+    const float* wy = kBicubic[Y & 3];
+    int ry[4], rx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ry[k] = min(max(i + k - 1, 0), h - 1);   // replicate pad: 1 top/left, 2 bottom/right
+      rx[k] = min(max(j + k - 1, 0), w - 1);
+    }
+    const TI* __restrict__ base = gen_in + (int64_t)b * h * w * Cpad;
+    float col[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float p[4][3];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[m][c] = Elem<TI>::ld(base + ((int64_t)ry[m] * w + rx[k]) * Cpad + c);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[k][c] = wy[0] * p[0][c] + wy[1] * p[1][c] + wy[2] * p[2][c] + wy[3] * p[3][c];
+    }
+    const int64_t o = ((int64_t)(b * H + Y) * (4 * w) + 4 * j) * 3;          // 12 consecutive floats, 48-byte aligned
+    float v[12];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(conv_out + o);
+    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(conv_out + o + 4);
+    *reinterpret_cast<float4*>(v + 8) = *reinterpret_cast<const float4*>(conv_out + o + 8);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const float* wx = kBicubic[x];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float bic = wx[0] * col[0][c] + wx[1] * col[1][c] + wx[2] * col[2][c] + wx[3] * col[3][c];
+        v[x * 3 + c] = (v[x * 3 + c] + bic) * 2.f - 1.f;
+      }
+    }
+    if (out) {
+      *reinterpret_cast<float4*>(out + o) = *reinterpret_cast<float4*>(v);
+      *reinterpret_cast<float4*>(out + o + 4) = *reinterpret_cast<float4*>(v + 4);
+      *reinterpret_cast<float4*>(out + o + 8) = *reinterpret_cast<float4*>(v + 8);
+    }
+    if (state) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] = v[k] * 0.5f + 0.5f;
+      *reinterpret_cast<float4*>(state + o) = *reinterpret_cast<float4*>(v);
+      *reinterpret_cast<float4*>(state + o + 4) = *reinterpret_cast<float4*>(v + 4);
+      *reinterpret_cast<float4*>(state + o + 8) = *reinterpret_cast<float4*>(v + 8);
     }
   }
 }
@@ -665,6 +757,12 @@ extern "C" int tg_upsample2_forward(const void* in, void* out, int dtype, int N,
   TG_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C > 0, "bad argument");
   dim3 grid(grid_1d((int64_t)N * H * W * 4 * C, 256));
   const double by = (double)N * H * W * C * 5.0 * (dtype == TG_F32 ? 4.0 : 2.0);
+  if (dtype == TG_BF16 && C % 8 == 0 && ((((uintptr_t)in | (uintptr_t)out)) & 15) == 0 &&
+      (int64_t)N * H * W * C * 4 < ((int64_t)1 << 31)) {
+    TG_LAUNCH("upsample2_fwd_x8", 0, by, upsample2_fwd_x8_kernel, dim3(grid_1d((int64_t)N * H * W * 4 * (C / 8), 256, 1 << 20)),
+              dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
+    TG_CHECK_LAUNCH();
+  }
   if (dtype == TG_F32) TG_LAUNCH("upsample2_fwd<f32>", 0, by, (upsample2_fwd_kernel<float>), grid, dim3(256), 0, ST(stream), (const float*)in, (float*)out, N, H, W, C);
   else if (dtype == TG_BF16) TG_LAUNCH("upsample2_fwd<bf16>", 0, by, (upsample2_fwd_kernel<u16>), grid, dim3(256), 0, ST(stream), (const u16*)in, (u16*)out, N, H, W, C);
   else TG_CHECK_ARG(false, "bad dtype");
@@ -682,10 +780,21 @@ extern "C" int tg_upsample2_backward(const void* d_out, void* d_in, int dtype, i
 }
 
 extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_in, int in_dtype, int Cpad, float* out,
-                                         int B, int h, int w, void* stream) {
-  TG_CHECK_ARG(conv_out && gen_in && out && B > 0 && h > 0 && w > 0 && Cpad >= 3, "bad argument");
+                                         float* state, int B, int h, int w, void* stream) {
+  TG_CHECK_ARG(conv_out && gen_in && (out || state) && B > 0 && h > 0 && w > 0 && Cpad >= 3, "bad argument");
   dim3 grid(grid_1d((int64_t)B * h * w * 16, 256));
-  const double by = (double)B * h * w * (16.0 * 12.0 * 2.0 + 3.0 * (in_dtype == TG_F32 ? 4.0 : 2.0));   // conv_out in, frame out, LR in
+  const double by = (double)B * h * w * (16.0 * 12.0 * (1 + (out != nullptr) + (state != nullptr)) +
+                                         3.0 * (in_dtype == TG_F32 ? 4.0 : 2.0));   // conv_out in, frame / state out, LR in
+  static const bool no_quad = getenv("TG_NO_BICUBIC_QUAD") != nullptr;                 // A/B switch
+  if (!no_quad && ((((uintptr_t)conv_out | (uintptr_t)out | (uintptr_t)state)) & 15) == 0 &&
+      (int64_t)B * h * w * 4 < ((int64_t)1 << 31)) {
+    dim3 gq(grid_1d((int64_t)B * h * w * 4, 256, 1 << 20));
+    if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add_quad<f32>", 0, by, (bicubic_add_quad_kernel<float>), gq, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, state, B, h, w);
+    else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add_quad<bf16>", 0, by, (bicubic_add_quad_kernel<u16>), gq, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, state, B, h, w);
+    else TG_CHECK_ARG(false, "bad dtype");
+    TG_CHECK_LAUNCH();
+  }
+  TG_CHECK_ARG(out != nullptr, "the per-pixel fallback needs `out`");
   if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add<f32>", 0, by, (bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
   else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add<bf16>", 0, by, (bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
   else TG_CHECK_ARG(false, "bad dtype");

@@ -172,7 +172,7 @@ class TrainEngine:
             return
         import torch.distributed as dist
         if after is not None:
-            self.comm_stream.wait_event(after)
+            self.comm_stream.wait_event(after[0])
         else:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
@@ -219,7 +219,15 @@ class TrainEngine:
         def event(stream):
             e = torch.cuda.Event()
             e.record(stream)
-            return e
+            return (e, stream)
+
+        def wait(stream, ev):
+            """stream waits for ev -- unless ev was recorded on that very stream (stream order already holds, and a
+            forked stream waiting on its own event crashes hipStreamEndCapture on this stack: tools/mb_capture.py P5)."""
+            if ev is not None and ev[1] is not stream:
+                stream.wait_event(ev[0])
+
+        self._wait = wait
 
         ps.grad.zero_()
         self.zbuf.zero_()
@@ -281,7 +289,7 @@ class TrainEngine:
             if self.use_vgg and t == tc - 1:
                 side, cx = part(4)
                 with torch.cuda.stream(side):
-                    side.wait_event(ev_vggt)
+                    wait(side, ev_vggt)
                     self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx, zero=True)
                     ev_vgg_early = event(side)
         self.gen = gen
@@ -298,9 +306,9 @@ class TrainEngine:
             self._exchange_async(["tdiscriminator"], with_balance=True, after=ev_dgrad)
         if self.use_vgg:
             if tc < T:                                               # late frames: straight into d_gen
-                main.wait_event(ev_vggt)
+                wait(main, ev_vggt)
                 self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
-            main.wait_event(ev_vgg_early)                            # early frames: computed beside the forward chain
+            wait(main, ev_vgg_early)                                 # early frames: computed beside the forward chain
             K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)
         # ---- backward through the recurrence; side: weight gradients of the late frames ---------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
@@ -406,7 +414,7 @@ class TrainEngine:
         main = torch.cuda.current_stream()
         fake = K.pack_d_input_forward(gen, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"], gd["merge"])
         p_fake, l_fake, sv_fake = self.D.forward(fake)
-        main.wait_event(gd["ev_real"])
+        self._wait(main, gd["ev_real"])
         p_real, l_real, sv_real = gd["p_real"], gd["l_real"], gd["sv_real"]
         dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * (self.host_step - 1))   # Teco.py:379-380
         d_real_D, d_fake_D, d_fake_G = (torch.empty_like(p_real) for _ in range(3))
@@ -431,6 +439,7 @@ class TrainEngine:
             self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False, flags=cx)
             ev = torch.cuda.Event()
             ev.record(side)
+            ev = (ev, side)
         # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
         dx = self.D.backward(sv_fake, d_fake_G, d_layers, wgrad=False, need_dx=True)
         K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,

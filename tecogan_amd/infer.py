@@ -50,8 +50,9 @@ class InferenceEngine:
         flow, _ = self.Fn.forward(fin, keep=False)                                # [B, h-h%8, w-w%8, 2]
         x_in = torch.empty(B, h, w, GEN_CPAD, device=self.dev, dtype=self.act_dtype)
         K.warp_s2d_forward(self.pre_gen, flow, self.frame, x_in, 1.0, 0.0)        # state already in [0,1]
-        out, _ = self.G.forward(x_in, keep=False)                                 # [-1,1]
-        K.affine(out, self.pre_gen, 0.5, 0.5)                                     # deprocess -> new state
+        # generator; the fused bicubic / preprocess epilogue writes deprocess(frame) straight into the recurrent state
+        # (the warp kernel above has consumed the old state by then: stream order)
+        self.G.forward(x_in, keep=False, out=False, state=self.pre_gen)
         self.pre_inputs.copy_(self.frame)
 
     def step(self, frame=None):

@@ -139,11 +139,12 @@ def upsample2_backward(d_out, d_in, y=None, act=0, alpha=0.0):
     return d_in
 
 
-def bicubic_add_preprocess(conv_out, gen_in, out):
+def bicubic_add_preprocess(conv_out, gen_in, out, state=None):
+    """out = (conv_out + bicubic_four(LR)) * 2 - 1; state (optional) = (out + 1) / 2; `out` may be None with a state."""
     B, h, w, Cpad = gen_in.shape
-    check(lib().tg_bicubic_add_preprocess(_p(conv_out), _p(gen_in), dt(gen_in), Cpad, _p(out), B, h, w, _stream()),
-          "tg_bicubic_add_preprocess")
-    return out
+    check(lib().tg_bicubic_add_preprocess(_p(conv_out), _p(gen_in), dt(gen_in), Cpad, _p(out), _p(state), B, h, w,
+                                          _stream()), "tg_bicubic_add_preprocess")
+    return out if out is not None else state
 
 
 def act_backward(d_out, y, d_in, act=0, alpha=0.0, scale=1.0):

@@ -133,8 +133,10 @@ class Generator:
         self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "1") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
-    def forward(self, x_in, keep=False, out=None):
-        """x_in [B,h,w,56] (LR frame | s2d(warped prev HR) | 0-pad) -> HR frame [B,4h,4w,3] fp32 in [-1,1]."""
+    def forward(self, x_in, keep=False, out=None, state=None):
+        """x_in [B,h,w,56] (LR frame | s2d(warped prev HR) | 0-pad) -> HR frame [B,4h,4w,3] fp32 in [-1,1].
+        state: optional fp32 [B,4h,4w,3] that receives deprocess(frame) in the same pass (the inference loop's recurrent
+        state, main.py:207); with a state and out=False the [-1,1] frame itself is not written at all."""
         assert not keep, "training uses begin_sequence/forward_t"
         ps, p = self.ps, self.P
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU)
@@ -147,7 +149,10 @@ class Generator:
         t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU)
         c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1,
                      out_dtype=_F32)
-        out = K.bicubic_add_preprocess(c, x_in, torch.empty_like(c) if out is None else out)  # (c+bicubic(LR))*2-1
+        if out is False:
+            assert state is not None
+            return K.bicubic_add_preprocess(c, x_in, None, state), None
+        out = K.bicubic_add_preprocess(c, x_in, torch.empty_like(c) if out is None else out, state)  # (c+bicubic(LR))*2-1
         return out, None
 
     # ---- training recurrence -----------------------------------------------------------------------

@@ -741,7 +741,8 @@ def test_schedule_step_lr_decay_ema_and_gate():
             lr_t = lrk * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) if t > 0 else float("nan")
             assert hs[k, 4].item() == (1.0 if on else 0.0), (step, k)
             if on:
-                assert abs(hs[k, 0].item() - lr_t) <= 1e-6 * lr_t, (step, k, hs[k, 0].item(), lr_t)
+                # 2e-5: the kernel takes beta1/beta2 as float32 (0.999f), as TF's float32 beta-power variables do
+                assert abs(hs[k, 0].item() - lr_t) <= 2e-5 * lr_t, (step, k, hs[k, 0].item(), lr_t)
             assert abs(hs[k, 5].item() - lrk) <= 1e-6 * lrk
         s = state.cpu()
         assert s[0].item() == gstep + 1 and abs(s[1].item() - tb) < 1e-9
@@ -756,9 +757,9 @@ def test_concat2_pad_lincomb_affine_seq_gather():
     assert torch.equal(out.cpu(), ref), "concat2_pad is a pure copy: bit-exact"
     o2 = torch.empty(2, 5, 7, 3, device=DEV)
     K.lincomb(a.to(DEV), b.to(DEV), o2, 0.25, -1.5)
-    assert_close_per_elem(o2, 0.25 * a - 1.5 * b, 1e-6, what="lincomb")
+    assert_close_per_elem(o2, 0.25 * a - 1.5 * b, 1e-5, what="lincomb")
     K.lincomb(a.to(DEV), None, o2, 2.0, 0.0, accumulate=True)
-    assert_close_per_elem(o2, 2.25 * a - 1.5 * b, 1e-6, what="lincomb accumulate")
+    assert_close_per_elem(o2, 2.25 * a - 1.5 * b, 1e-5, what="lincomb accumulate")
     K.affine(a.to(DEV), o2, 0.5, 0.5)
     assert torch.equal(o2.cpu(), a * 0.5 + 0.5), "deprocess (x+1)/2 == x*0.5+0.5 bit for bit"
     # ping-pong order + [B,T] -> [T,B] (lib/Teco.py:80-85): bit-exact gather
@@ -812,8 +813,8 @@ WS_CASES = [
     # N, H, W, Cin, Cout, flip(bwd_data form), res, aux(mask), act
     (1, 270, 250, 64, 64, False, False, False, ACT_RELU),     # ragged right/bottom edges, persistent tile loop
     (2, 128, 128, 64, 64, False, True, False, ACT_NONE),      # residual epilogue (res-block conv_2)
-    (1, 135, 240, 56, 64, False, False, False, ACT_RELU),     # Cin = 56 (generator input conv): zero-filled chunk
-    (3, 64, 96, 64, 128, False, False, False, ACT_LRELU),     # two channel tiles (grid.y = 2)
+    (1, 270, 480, 56, 64, False, False, False, ACT_RELU),     # Cin = 56 (generator input conv): zero-filled chunk
+    (3, 128, 128, 64, 128, False, False, False, ACT_LRELU),   # two channel tiles (grid.y = 2)
     (2, 128, 128, 64, 64, True, True, True, ACT_NONE),        # input-gradient form: mirrored taps + residual + ReLU mask
     (1, 200, 170, 32, 64, True, False, True, ACT_NONE),       # Cin = 32, LeakyReLU mask
     (1, 1080, 1920, 16, 64, False, False, False, ACT_RELU),   # > 2^16 tiles per image row block; Cin = 16
@@ -860,3 +861,41 @@ def test_conv3x3_weights_in_registers_kernel(case, coexist):
     close(out, ref, 8e-3, "conv3x3_ws %s" % (case,))
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 2e-2).all(), "per-element: max %g" % err.max().item()
+
+
+# ---- vectorised HBM-bound kernels of the inference step ---------------------------------------------------------------
+@pytest.mark.parametrize("B,h,w", [(1, 5, 9), (2, 33, 47), (1, 270, 480)])
+def test_warp_s2d_forward_bf16_vectorised_rows(B, h, w):
+    """The LDS-assembled 16-byte-row form (bf16, Cpad 56) incl. pixel counts that are not multiples of 4 / of the grid and
+    the optional warped-frame output; against the oracle, and bit-exact against the scalar fallback (Cpad 59 = odd row size)."""
+    pre = rnd(B, 4 * h, 4 * w, 3, seed=1)
+    flow = rnd(B, h, w, 2, seed=2, scale=3.0)
+    lr = (rnd(B, h, w, 3, seed=3) + 1) * 0.5
+    ref = oracle_gen_input(pre, flow, lr, 0.5, 0.5, 56)
+    out = torch.full((B, h, w, 56), 9.0, device=DEV, dtype=torch.bfloat16)
+    warped = torch.empty(B, 4 * h, 4 * w, 3, device=DEV)
+    K.warp_s2d_forward(pre.to(DEV), flow.to(DEV), lr.to(DEV), out, 0.5, 0.5, warped=warped)
+    close(out, ref, 4e-3, "warp_s2d bf16 rows")
+    close(warped, O.dense_image_warp(pre, O.upscale_four(flow * 4.0)), 2e-5, "warped frame")
+    out59 = torch.empty(B, h, w, 59, device=DEV, dtype=torch.bfloat16)                   # 118-byte rows: scalar kernel
+    K.warp_s2d_forward(pre.to(DEV), flow.to(DEV), lr.to(DEV), out59, 0.5, 0.5)
+    assert torch.equal(out59[..., :51].cpu(), out[..., :51].cpu()), "vector and scalar kernels disagree"
+    assert torch.equal(out[..., 51:].float().cpu(), torch.zeros(B, h, w, 5))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bicubic_quad_kernel_state_output(dtype):
+    """Row-quad bicubic epilogue: frame in [-1,1] and, in the same pass, the deprocessed recurrent state (main.py:207);
+    `out` may be omitted.  Odd sizes, replicate padding at all four borders."""
+    B, h, w = 2, 7, 9
+    gen_in = rnd(B, h, w, 56, seed=1).to(dtype)
+    conv_out = rnd(B, 4 * h, 4 * w, 3, seed=2)
+    ref = O.preprocess(conv_out + O.bicubic_four(gen_in[..., :3].float()))
+    out = torch.empty(B, 4 * h, 4 * w, 3, device=DEV)
+    state = torch.empty_like(out)
+    K.bicubic_add_preprocess(conv_out.to(DEV), gen_in.to(DEV), out, state)
+    close(out, ref, 2e-6, "bicubic quad out")
+    assert torch.equal(state.cpu(), out.cpu() * 0.5 + 0.5), "state must be deprocess(out) bit for bit"
+    state2 = torch.empty_like(out)
+    K.bicubic_add_preprocess(conv_out.to(DEV), gen_in.to(DEV), None, state2)
+    assert torch.equal(state2.cpu(), state.cpu())
