@@ -794,7 +794,7 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
     else TG_CHECK_ARG(false, "bad dtype");
     TG_CHECK_LAUNCH();
   }
-  TG_CHECK_ARG(out != nullptr, "the per-pixel fallback needs `out`");
+  TG_CHECK_ARG(out != nullptr && state == nullptr, "the per-pixel fallback writes `out` only");
   if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add<f32>", 0, by, (bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
   else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add<bf16>", 0, by, (bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
   else TG_CHECK_ARG(false, "bad dtype");

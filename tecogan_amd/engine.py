@@ -8,6 +8,7 @@ and each flow slab is a contiguous `[B, ...]` block.  Semantics that differ from
 purpose: all gradients are taken from the pre-update weights, then D (gate permitting), G and FNet
 are applied (the TF1 graph has an ordering race there).
 """
+import contextlib
 import os
 from collections import OrderedDict
 
@@ -83,7 +84,9 @@ class TrainEngine:
         self.in_lr = torch.zeros(self.B, self.T0, h, h, 3, device=self.dev)
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
-        self.graph = None
+        self._segs = None
+        self._pools = {}
+        self._done, self._mode, self._main, self._d_vgg = {}, "flat", None, None
         # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
         self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
         self.host_step = 0
@@ -96,6 +99,10 @@ class TrainEngine:
         self.ov_parts = int(os.environ.get("TG_OVERLAP_PARTS", "15")) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.streams = {"S": self.side_stream, "C": self.comm_stream}
+        # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
+        uses_side = ((self.use_vgg and self.ov_parts & 5) or (gan and self.ov_parts & 10) or (self.ov_parts & 16 and self.T > 1))
+        self.segmented = bool(uses_side) or self.world > 1
 
     # ------------------------------------------------------------------------------------------
     def set_batch(self, r_inputs, r_targets):
@@ -108,23 +115,91 @@ class TrainEngine:
             self.set_batch(r_inputs, r_targets)
         self.host_step += 1
         if not self.use_graph:
-            self._program()
+            self._run_program("eager")
             return
-        if self.graph is None:
+        if self._segs is None:
             self._capture()
-        self.graph.replay()
-        if self.exchange_mode == "eager-split":      # collectives between the two captured halves (same stream)
-            self._allreduce()
-            self.graph_update.replay()
+        self._replay()
+
+    # ------------------------------------------------------------------------------------------
+    # Execution model: a step is a DAG of SEGMENTS.  A segment is a run of launches on one of three streams -- "M" the
+    # caller's stream (the recurrent chain and everything ordered with it), "S" the side stream (throughput work that
+    # may run beside the chain), "C" the communication stream (RCCL) -- with explicit dependencies on earlier segments.
+    # Captured, every segment is its OWN single-stream hipGraph, replayed on its stream with event waits in between.
+    # Why not one multi-stream graph: on this stack a graph with ANY forked branch pays +0.9 us on every node (3.63 ->
+    # 4.53 us per chain node with one tiny forked kernel, tools/mb_forktax.py), +1.8 ms on the 3000-node TecoGAN step,
+    # more than the overlap returns; single-stream graphs on two streams overlap as well as a forked graph does and
+    # keep the 3.6 us node.  Memory: one graph pool per stream (segments of a stream replay in capture order, so reuse
+    # inside a pool is safe; tensors that cross streams stay referenced in self._hold).
+    @contextlib.contextmanager
+    def _seg(self, name, skey="M", after=()):
+        deps = [d for d in after if d in self._done and self._done[d][1] != skey]
+        if self._mode == "flat":                       # one stream, one graph (or plain eager): nothing to do
+            self._done[name] = (None, "M")
+            yield
+            return
+        if self._mode == "eager":
+            st = self._main if skey == "M" else self.streams[skey]
+            for d in deps:
+                st.wait_event(self._done[d][0])
+            with torch.cuda.stream(st):
+                yield
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._done[name] = (ev, skey)
+            return
+        g = torch.cuda.CUDAGraph()                     # capture
+        with torch.cuda.graph(g, pool=self._pool(skey)):
+            yield
+        seg = dict(name=name, skey=skey, deps=deps, graph=g, fn=None, event=torch.cuda.Event())
+        self._segs.append(seg)
+        self._done[name] = (seg["event"], skey)
+
+    def _seg_call(self, name, skey, after, fn):
+        """A segment that cannot be captured (a gloo all-reduce): `fn` runs eagerly on the segment's stream every step."""
+        if self._mode != "capture":
+            with self._seg(name, skey, after):
+                fn()
+            return
+        deps = [d for d in after if d in self._done and self._done[d][1] != skey]
+        seg = dict(name=name, skey=skey, deps=deps, graph=None, fn=fn, event=torch.cuda.Event())
+        self._segs.append(seg)
+        self._done[name] = (seg["event"], skey)
+
+    def _pool(self, skey):
+        if skey not in self._pools:
+            self._pools[skey] = torch.cuda.graph_pool_handle()
+        return self._pools[skey]
+
+    def _run_program(self, mode):
+        self._mode = mode if self.segmented else "flat"
+        self._main = torch.cuda.current_stream()
+        self._done = {}
+        self._program()
+
+    def _replay(self):
+        main = torch.cuda.current_stream()
+        evs = {}
+        for seg in self._segs:
+            st = main if seg["skey"] == "M" else self.streams[seg["skey"]]
+            for d in seg["deps"]:
+                st.wait_event(evs[d])
+            if st is main:
+                seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
+            else:
+                with torch.cuda.stream(st):
+                    seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
+            seg["event"].record(st)
+            evs[seg["name"]] = seg["event"]
 
     def _capture(self):
-        # warm-up run on a side stream (allocator pools, lazy module loads), with state restored afterwards
+        # warm-up run (allocator pools, lazy module loads, the real two-stream schedule), state restored afterwards
         snap = [t.clone() for t in (self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper)]
         moving = [m.clone() for m in self.D.moving] if self.gan else []
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._program()
+            self._run_program("eager")
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for t, c in zip((self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper), snap):
@@ -135,47 +210,43 @@ class TrainEngine:
         torch.cuda.synchronize()
         if self.exchange_mode == "captured":
             try:
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._program()
+                self._segs = []
+                self._run_program("capture")
                 return
-            except Exception as e:           # a collective backend that cannot be stream-captured: split the step instead
+            except Exception as e:           # a collective backend that cannot be stream-captured: run it eagerly instead
                 import warnings
                 warnings.warn("captured RCCL exchange failed (%s): falling back to the eager-split exchange" % (e,))
                 self.exchange_mode = "eager-split"
+                self._pools = {}
                 torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        if self.world == 1:
-            with torch.cuda.graph(self.graph):
-                self._program()
-        else:
-            with torch.cuda.graph(self.graph):
-                self._program_compute()
-            self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update):
-                self._program_update()
+        self._segs = []
+        if self.segmented:
+            self._run_program("capture")
+        else:                                # one stream, no exchange: the whole step is ONE graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_program("flat")
+            self._segs.append(dict(name="step", skey="M", deps=[], graph=g, fn=None, event=torch.cuda.Event()))
 
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
+        after = ["wgrad", "fnet_bwd"]
         if self.exchange_mode == "eager-split":
-            self._allreduce()
+            self._seg_call("exchange", "M", after, self._allreduce)
+            after = ["exchange"]
         elif self.exchange_mode == "captured":
-            torch.cuda.current_stream().wait_stream(self.comm_stream)      # join: all scopes reduced
-        self._program_update()
+            after = ["ar_d", "ar_g", "ar_f"]
+        with self._seg("update", "M", after):
+            self._program_update()
 
-    def _exchange_async(self, scopes, with_balance=False, after=None):
-        """captured mode: all-reduce `scopes` of the flat gradient buffer on the communication stream, ordered after
-        the event `after` (default: everything enqueued so far on the compute stream); the compute stream runs on
-        (fork), `_program` joins."""
+    def _exchange_seg(self, name, scopes, after, with_balance=False):
+        """captured mode: all-reduce `scopes` of the flat gradient buffer as a segment of the communication stream,
+        ordered after the segments `after`; it overlaps whatever the compute streams do next, `update` joins."""
         if self.exchange_mode != "captured":
             return
         import torch.distributed as dist
-        if after is not None:
-            self.comm_stream.wait_event(after[0])
-        else:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
+        with self._seg(name, "C", after):
             if with_balance and self.gan:            # every rank must take the same D-gate branch (lib/Teco.py:493-494)
                 tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
                 dist.all_reduce(tb, group=self.pg)
@@ -190,142 +261,146 @@ class TrainEngine:
         return 4 * n + (4 if self.gan else 0)
 
     def _program_compute(self):
-        """Forward + backward of one step as a two-stream program (both streams are branches of one hipGraph).
+        """Forward + backward of one step as segments on two streams.
 
         The recurrent generator chain (T frames x ~38 dependent launches forward, as many backward) is latency bound:
-        each launch keeps one wave per SIMD busy for ~3.5 us, a third of the step during which >90 % of the chip's issue
+        each launch keeps one wave per SIMD busy for ~3.6 us, a third of the step during which >90 % of the chip's issue
         slots idle.  Everything that does not depend on the chain's current position runs on the SIDE stream meanwhile,
         with tile shapes whose LDS / register footprint lets a chain workgroup co-reside on the same CU
-        (TG_CONV_COEXIST; profiles/r02a_overlap.txt: 87 % of the chain hides under VGG-sized convolutions):
+        (TG_CONV_COEXIST; profiles/r02a_overlap.txt, r02d_forktax.txt):
             forward chain   ||  VGG target features, D real pass, VGG gen pass (fwd + dX) of the early frames
-            backward chain  ||  D's own-gradient passes, generator weight gradients of the late frames
+            backward chain  ||  D's own-gradient passes [, generator weight gradients of the late frames: measured a loss]
         TG_OVERLAP=0 runs the identical program on one stream (A/B switch; the results are the same either way)."""
         F, ps, B, T, h = self.F, self.ps, self.B, self.T, self.cs
         H = 4 * h
-        main = torch.cuda.current_stream()
-        ov = self.overlap
-        hold = self._hold = []                  # tensors that cross streams stay referenced until the next step
-        forked = [False]
+        hold = self._hold = []                  # tensors that cross segments / streams stay referenced until the next step
+        seg = self._seg
 
         def part(bit):
-            """(stream, conv footprint flag) for schedule piece `bit`: the side stream, forked after everything enqueued
-            on main so far, or main itself when the piece is not overlapped."""
-            if not (self.ov_parts & bit):
-                return main, 0
-            self.side_stream.wait_stream(main)
-            forked[0] = True
-            return self.side_stream, K.CONV_COEXIST
+            """(stream key, conv footprint flag) of schedule piece `bit`."""
+            return ("S", K.CONV_COEXIST) if (self.ov_parts & bit) else ("M", 0)
 
-        def event(stream):
-            e = torch.cuda.Event()
-            e.record(stream)
-            return (e, stream)
-
-        def wait(stream, ev):
-            """stream waits for ev -- unless ev was recorded on that very stream (stream order already holds, and a
-            forked stream waiting on its own event crashes hipStreamEndCapture on this stack: tools/mb_capture.py P5)."""
-            if ev is not None and ev[1] is not stream:
-                stream.wait_event(ev[0])
-
-        self._wait = wait
-
-        ps.grad.zero_()
-        self.zbuf.zero_()
-        if self.gan:
-            self.D.set_scratch(self.bn_pool)
-        # ping-pong extension (lib/Teco.py:80-85) + [B,T] -> frame-major [T,B] in one gather each
-        lr_seq = K.seq_gather(self.in_lr, torch.empty(T, B, h, h, 3, device=self.dev), self.seq_idx)
-        hr_seq = K.seq_gather(self.in_hr, torch.empty(T, B, H, H, 3, device=self.dev), self.seq_idx)
+        with seg("seq"):
+            ps.grad.zero_()
+            self.zbuf.zero_()
+            if self.gan:
+                self.D.set_scratch(self.bn_pool)
+            # ping-pong extension (lib/Teco.py:80-85) + [B,T] -> frame-major [T,B] in one gather each
+            lr_seq = K.seq_gather(self.in_lr, torch.empty(T, B, h, h, 3, device=self.dev), self.seq_idx)
+            hr_seq = K.seq_gather(self.in_hr, torch.empty(T, B, H, H, 3, device=self.dev), self.seq_idx)
         hold += [lr_seq, hr_seq]
         npair = (T - 1) * B
         # ---- side: VGG-19 features of the targets (lib/Teco.py:177-178; needs hr_seq only) ---------------------
-        taps_t = ev_vggt = None
+        taps_t = None
         if self.use_vgg:
-            side, cx = part(1)
-            with torch.cuda.stream(side):
+            sk, cx = part(1)
+            with seg("vggt", sk, ["seq"]):
                 xt = K.vgg_preprocess_forward(hr_seq.view(T * B, H, H, 3),
                                               torch.empty(T * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
                 taps_t, _ = self.V.forward(xt, keep=False, flags=cx)
-                ev_vggt = event(side)
             hold += [xt, taps_t]
-        # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
-        pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
-        cur_lr = lr_seq[1:].reshape(npair, h, h, 3)
-        fnet_in = K.concat2_pad(pre_lr, cur_lr, torch.empty(npair, h, h, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
-        flow, fsaved = self.Fn.forward(fnet_in)                                              # [npair,h,h,2] fp32
-        flow_t = flow.view(T - 1, B, h, h, 2)
-        hold += [flow, fsaved]
+        with seg("fnet"):
+            # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
+            pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
+            cur_lr = lr_seq[1:].reshape(npair, h, h, 3)
+            fnet_in = K.concat2_pad(pre_lr, cur_lr,
+                                    torch.empty(npair, h, h, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
+            flow, fsaved = self.Fn.forward(fnet_in)                                              # [npair,h,h,2] fp32
+            flow_t = flow.view(T - 1, B, h, h, 2)
+            gd = self._gan_setup(lr_seq, flow_t) if self.gan else None
+            # ---- LR warp loss (lib/Teco.py:120-122,329-333) and its gradient to the flow ----------------
+            warped_lr = K.warp_forward(pre_lr, flow, torch.empty_like(pre_lr))
+            npx = float(npair * h * h)
+            K.sum_sq_diff(cur_lr, warped_lr, 1.0 / npx, self.loss[LI["l2_warp_loss"]:LI["l2_warp_loss"] + 1])
+            c = 2.0 * F.warp_scaling / npx
+            d_wl = K.lincomb(warped_lr, cur_lr, torch.empty_like(warped_lr), c, -c)
+            d_flow = torch.empty_like(flow)
+            K.warp_backward(d_wl, pre_lr, flow, None, d_flow)
+        hold += [fnet_in, flow, fsaved, gd, warped_lr, d_wl, d_flow]
         # ---- side: discriminator on the real triplets (needs the flows, not the generator) -----------------
-        gd = None
         if self.gan:
-            gd = self._gan_setup(lr_seq, flow_t)
-            side, cx = part(2)
-            with torch.cuda.stream(side):
+            sk, cx = part(2)
+            with seg("dreal", sk, ["fnet"]):
                 gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
                                                     gd["merge"])
                 gd["p_real"], gd["l_real"], gd["sv_real"] = self.D.forward(gd["real"], flags=cx)
-                gd["ev_real"] = event(side)
-            hold.append(gd)
-        # ---- LR warp loss (lib/Teco.py:120-122,329-333) and its gradient to the flow ----------------
-        warped_lr = K.warp_forward(pre_lr, flow, torch.empty_like(pre_lr))
-        npx = float(npair * h * h)
-        K.sum_sq_diff(cur_lr, warped_lr, 1.0 / npx, self.loss[LI["l2_warp_loss"]:LI["l2_warp_loss"] + 1])
-        c = 2.0 * F.warp_scaling / npx
-        d_wl = K.lincomb(warped_lr, cur_lr, torch.empty_like(warped_lr), c, -c)
-        d_flow = torch.empty_like(flow)
-        K.warp_backward(d_wl, pre_lr, flow, None, d_flow)
         # ---- recurrent generator (lib/Teco.py:125-155); side: VGG pass of the early frames ----------------------
-        gen = torch.empty(T, B, H, H, 3, device=self.dev)
-        self.G.begin_sequence(T, B, h, h, self.dev)
-        seq = self.G.seq
-        tc = (T + 1) // 2 if T > 1 else T                # frames [0, tc): early chunk (side), [tc, T): late chunk (main)
-        d_vgg = ev_vgg_early = None
-        if self.use_vgg:
-            d_vgg = torch.empty(tc, B, H, H, 3, device=self.dev)        # VGG gradient w.r.t. the early frames (added to d_gen below)
-            hold.append(d_vgg)
-        for t in range(T):
-            K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], seq["x_in"][t], 0.5, 0.5)
-            self.G.forward_t(t, gen[t])
-            if self.use_vgg and t == tc - 1:
-                side, cx = part(4)
-                with torch.cuda.stream(side):
-                    wait(side, ev_vggt)
-                    self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx, zero=True)
-                    ev_vgg_early = event(side)
+        gen = torch.empty(T, B, H, H, 3, device=self.dev) if self.gen is None else self.gen
         self.gen = gen
-        # ---- generator losses seeded into d_gen -------------------------------------------------------
-        nhr = float(T * B * H * H)
-        K.sum_sq_diff(gen, hr_seq, 1.0 / nhr, self.loss[LI["l2_content_loss"]:LI["l2_content_loss"] + 1])
-        d_gen = K.lincomb(gen, hr_seq, torch.empty_like(gen), 2.0 / nhr, -2.0 / nhr)         # lib/Teco.py:320-322
-        hold.append(d_gen)
-        if F.pingpang:
-            self._pingpong(gen, d_gen)
-        if self.gan:
-            ev_dgrad = self._gan_fake_and_losses(gd, gen, lr_seq, d_gen, part)
-            # D's gradients and t_balance are final after its own-gradient passes: their all-reduce overlaps the BPTT
-            self._exchange_async(["tdiscriminator"], with_balance=True, after=ev_dgrad)
+        tc = (T + 1) // 2 if T > 1 else T                # frames [0, tc): early chunk (side), [tc, T): late chunk (main)
+        d_vgg = None
         if self.use_vgg:
-            if tc < T:                                               # late frames: straight into d_gen
-                wait(main, ev_vggt)
+            d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
+
+        def forward_frames(t0, t1):
+            for t in range(t0, t1):
+                K.warp_s2d_forward(gen[t - 1] if t else None, flow_t[t - 1] if t else None, lr_seq[t], self.G.seq["x_in"][t],
+                                   0.5, 0.5)
+                self.G.forward_t(t, gen[t])
+
+        with seg("fwd_a"):
+            if self.G.seq is None or self._mode != "capture":
+                self.G.begin_sequence(T, B, h, h, self.dev)
+            forward_frames(0, tc)
+        if self.use_vgg:
+            sk, cx = part(4)
+            with seg("vgg_early", sk, ["fwd_a", "vggt"]):
+                self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx, zero=True)
+        with seg("fwd_b"):
+            forward_frames(tc, T)
+            # ---- generator losses seeded into d_gen -------------------------------------------------------
+            nhr = float(T * B * H * H)
+            K.sum_sq_diff(gen, hr_seq, 1.0 / nhr, self.loss[LI["l2_content_loss"]:LI["l2_content_loss"] + 1])
+            d_gen = K.lincomb(gen, hr_seq, torch.empty_like(gen), 2.0 / nhr, -2.0 / nhr)         # lib/Teco.py:320-322
+            if F.pingpang:
+                self._pingpong(gen, d_gen)
+            if self.gan:
+                gd["fake"] = K.pack_d_input_forward(gen, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
+                                                    gd["merge"])
+                gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
+        hold.append(d_gen)
+        if self.gan:
+            with seg("dloss", "M", ["dreal"]):
+                self._gan_losses(gd)
+            sk, cx = part(8)
+            with seg("down", sk, ["dloss"]):     # D's own gradients (t_discrim_loss) from both passes
+                self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
+                self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
+            # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
+            self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
+        with seg("dG", "M", ["vggt"]):
+            if self.gan:     # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
+                dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
+                K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
+                                        gd["off"], gd["merge"])
+                hold.append(dx)
+            if self.use_vgg and tc < T:                              # late frames: straight into d_gen
                 self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
-            wait(main, ev_vgg_early)                                 # early frames: computed beside the forward chain
-            K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)
-        # ---- backward through the recurrence; side: weight gradients of the late frames ---------------------------
+        # ---- backward through the recurrence ------------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
-        for t in range(T - 1, -1, -1):
-            dx = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
-            if t > 0:
-                K.warp_s2d_backward(dx, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
-            if (self.ov_parts & 16) and t == tc and 0 < tc < T:
-                side, cx = part(16)
-                with torch.cuda.stream(side):
-                    self.G.wgrad_sequence(tc, T, flags=cx)
-        if forked[0]:
-            main.wait_stream(self.side_stream)                       # join: everything the side stream did is visible
-        self.G.wgrad_sequence(0, tc if ((self.ov_parts & 16) and 0 < tc < T) else T)
-        self._exchange_async(["generator"])             # overlaps the FNet backward pass below
-        self.Fn.backward(fsaved, d_flow)
-        self._exchange_async(["fnet"])
+
+        def backward_frames(t1, t0):
+            for t in range(t1 - 1, t0 - 1, -1):
+                dx_in = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
+                if t > 0:
+                    K.warp_s2d_backward(dx_in, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
+
+        split = bool(self.ov_parts & 16) and 0 < tc < T
+        with seg("bptt_a", "M", ["vgg_early"]):
+            if self.use_vgg:                                         # early frames: computed beside the forward chain
+                K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)
+            backward_frames(T, tc if split else 0)
+        if split:
+            with seg("wgrad_late", "S", ["bptt_a"]):
+                self.G.wgrad_sequence(tc, T, flags=K.CONV_COEXIST)
+            with seg("bptt_b"):
+                backward_frames(tc, 0)
+        with seg("wgrad", "M", ["wgrad_late", "down"]):
+            self.G.wgrad_sequence(0, tc if split else T)
+        self._exchange_seg("ar_g", ["generator"], ["wgrad"])            # overlaps the FNet backward pass
+        with seg("fnet_bwd"):
+            self.Fn.backward(fsaved, d_flow)
+        self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""
@@ -406,46 +481,28 @@ class TrainEngine:
     def _d_input_buf(self, gd):
         return torch.empty(gd["tb"], gd["Ho"], gd["Ho"], pad8(self.d_cin), device=self.dev, dtype=self.act_dtype)
 
-    def _gan_fake_and_losses(self, gd, gen, lr_seq, d_gen, part):
-        """lib/Teco.py:252-313,374-417: fake pass, losses, the generator-side gradient through D into d_gen (main stream);
-        D's own-gradient passes go to the side stream (they feed no gradient of the recurrence).  Returns the event after
-        which D's weight gradients are final."""
-        F, B, h = self.F, self.B, self.cs
-        main = torch.cuda.current_stream()
-        fake = K.pack_d_input_forward(gen, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"], gd["merge"])
-        p_fake, l_fake, sv_fake = self.D.forward(fake)
-        self._wait(main, gd["ev_real"])
-        p_real, l_real, sv_real = gd["p_real"], gd["l_real"], gd["sv_real"]
+    def _gan_losses(self, gd):
+        """lib/Teco.py:275-313,374-417: adversarial / discriminator / balance scalars and the layer losses, with the gradient
+        seeds of the three D backward passes."""
+        F = self.F
+        p_real, l_real, p_fake, l_fake = gd["p_real"], gd["l_real"], gd["p_fake"], gd["l_fake"]
         dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * (self.host_step - 1))   # Teco.py:379-380
-        d_real_D, d_fake_D, d_fake_G = (torch.empty_like(p_real) for _ in range(3))
+        gd["d_real_D"], gd["d_fake_D"], gd["d_fake_G"] = (torch.empty_like(p_real) for _ in range(3))
         # the five scalars land straight in their (contiguous) loss slots
         i0 = LI["t_adversarial_loss"]
         assert LOSS_NAMES[i0:i0 + 5] == ["t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output",
                                          "t_discrim_fake_output"]
-        K.gan_losses(p_real, p_fake, F.EPS, F.ratio * dt_ratio, self.loss[i0:i0 + 5], d_real_D, d_fake_D, d_fake_G)
-        d_layers = None
+        K.gan_losses(p_real, p_fake, F.EPS, F.ratio * dt_ratio, self.loss[i0:i0 + 5], gd["d_real_D"], gd["d_fake_D"],
+                     gd["d_fake_G"])
+        gd["d_layers"] = None
         if F.D_LAYERLOSS:                                             # Teco.py:275-313,389-390
-            d_layers = []
+            gd["d_layers"] = []
             for i, norm in enumerate((12.0, 14.0, 24.0, 100.0)):
                 r, f = l_real[i], l_fake[i]
                 npix = float(r.numel() // r.shape[-1])
                 d = torch.empty_like(f)
                 K.l1_loss(r, f, 1.0 / npix, 0.02 / norm * dt_ratio / npix, self._slot("D_layer_%d_loss" % i), d)
-                d_layers.append(d)
-        # discriminator's own gradients (t_discrim_loss) from both passes: side stream
-        side, cx = part(8)
-        with torch.cuda.stream(side):
-            self.D.backward(sv_real, d_real_D, None, wgrad=True, need_dx=False, flags=cx)
-            self.D.backward(sv_fake, d_fake_D, None, wgrad=True, need_dx=False, flags=cx)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            ev = (ev, side)
-        # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
-        dx = self.D.backward(sv_fake, d_fake_G, d_layers, wgrad=False, need_dx=True)
-        K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
-                                gd["off"], gd["merge"])
-        self._hold += [fake, p_fake, l_fake, sv_fake, d_real_D, d_fake_D, d_fake_G, d_layers, dx]
-        return ev
+                gd["d_layers"].append(d)
 
     # ------------------------------------------------------------------------------------------
     def losses(self):

@@ -876,7 +876,8 @@ def test_warp_s2d_forward_bf16_vectorised_rows(B, h, w):
     warped = torch.empty(B, 4 * h, 4 * w, 3, device=DEV)
     K.warp_s2d_forward(pre.to(DEV), flow.to(DEV), lr.to(DEV), out, 0.5, 0.5, warped=warped)
     close(out, ref, 4e-3, "warp_s2d bf16 rows")
-    close(warped, O.dense_image_warp(pre, O.upscale_four(flow * 4.0)), 2e-5, "warped frame")
+    # query coordinates reach 4w: fp32 carries them to ~4w * 6e-8 px, and random frames change by O(1) per pixel
+    close(warped, O.dense_image_warp(pre, O.upscale_four(flow * 4.0)), max(2e-5, 4 * w * 3e-7), "warped frame")
     out59 = torch.empty(B, h, w, 59, device=DEV, dtype=torch.bfloat16)                   # 118-byte rows: scalar kernel
     K.warp_s2d_forward(pre.to(DEV), flow.to(DEV), lr.to(DEV), out59, 0.5, 0.5)
     assert torch.equal(out59[..., :51].cpu(), out[..., :51].cpu()), "vector and scalar kernels disagree"
