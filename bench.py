@@ -78,6 +78,9 @@ def new_engine(config, dtype, device, pg=None, use_graph=True):
     return TrainEngine(F, device, gan=config != "frvsr", act_dtype=tdt, seed=42, process_group=pg, use_graph=use_graph)
 
 
+HOST_ENQUEUE_MS = [None]          # host time to enqueue one step (no device wait), from the last time_steps() call
+
+
 def time_steps(eng, steps, warmup, fence):
     for _ in range(warmup):
         eng.step()
@@ -85,7 +88,9 @@ def time_steps(eng, steps, warmup, fence):
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.step()
+    t1 = time.perf_counter()
     fence()
+    HOST_ENQUEUE_MS[0] = (t1 - t0) / steps * 1e3
     return time.perf_counter() - t0
 
 
@@ -329,7 +334,8 @@ def main():
         assert all(v == v for v in L.values()), "NaN in losses: %s" % L
         cfg = {"workload": workload_name(a.config, F), "global_batch": world * F.batch_size,
                "frames_per_step": world * F.batch_size * frame_len, "parallelism": "dp%d" % world,
-               "hipgraph": not a.no_graph}
+               "hipgraph": not a.no_graph, "graph_segments": len(eng._segs or []),
+               "host_enqueue_ms_per_step": round(HOST_ENQUEUE_MS[0], 3)}
         if world > 1:
             cfg["collective_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
             cfg["ranks"] = torch.distributed.get_world_size()

@@ -57,6 +57,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   constexpr int TM = TH / WAVES_M, TN = (BN / 16) / WAVES_N;
   constexpr bool F32 = sizeof(TIn) == 4;
   static_assert(TM >= 1 && TN >= 1, "tile too small for 4 waves");
+  // Small (latency-regime) bf16 tiles: MFMA operands swapped (A = weights, B = pixels), so a lane's four accumulator
+  // rows are four CONSECUTIVE OUTPUT CHANNELS of one pixel and the epilogue is register-only with one 8-byte store per
+  // accumulator -- no LDS staging, no epilogue barriers on the recurrent chain's critical path (conv3x3_ws.hip does
+  // the same in the throughput regime).
+  constexpr bool SWAP = !F32 && sizeof(TOut) == 2 && TH <= 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                          // [HALO_PIX][144]
@@ -155,6 +160,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bv[j] = (p.bias && col0 + j * 16 < p.Cout) ? p.bias[col0 + j * 16] : 0.f;
+  float bvs[SWAP ? TN : 1][4];                       // swapped layout: bias of channels chan0 + 16 j + 4 fg + r
+  if constexpr (SWAP) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = n0 + wn * TN * 16 + j * 16 + fg * 4 + r;
+        bvs[j][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+      }
+  }
 
   f32x4 acc[TM][TN];
 
@@ -205,6 +220,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[i][j], 0, 0, 0);
+            } else if constexpr (SWAP) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&bfr[j]),
+                                                                  *reinterpret_cast<bf16x8*>(&af[i]), acc[i][j],
+                                                                  0, 0, 0);
             } else {
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[i]),
                                                                   *reinterpret_cast<bf16x8*>(&bfr[j]), acc[i][j],
@@ -219,7 +238,58 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
       const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
       const bool has_res = gres != nullptr, has_aux = gaux != nullptr;
       constexpr bool LDS_EPI = sizeof(TOut) == 2;      // bf16 outputs: stage through LDS, 16-byte global rows
-      if (LDS_EPI && (p.Cout & 7) == 0 && !p.direct_epi) {
+      if constexpr (SWAP) {
+        // accumulator r of lane (frow, fg) = pixel column frow, output channel chan0 + 16 j + 4 fg + r
+        const int x = tx * 16 + frow;
+        const bool vec4 = (p.Cout & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int y = ty * TH + wm * TM + i;
+          if (y >= p.H || x >= p.W) continue;
+          const int pix = ((n * p.H + y) * p.W + x) * p.Cout;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn * TN * 16 + j * 16 + fg * 4;
+            if (co >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[i][j][r] + bvs[j][r];
+              if (p.act >= TG_ACT_TANH) v[r] = act_fwd(v[r], p.act, p.act_alpha);
+              else v[r] = fmaxf(v[r], v[r] * p.nslope);
+            }
+            if (vec4) {
+              if (has_res) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(gres + pix + co);
+                v[0] += __uint_as_float(rr.x << 16);
+                v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                v[2] += __uint_as_float(rr.y << 16);
+                v[3] += __uint_as_float(rr.y & 0xffff0000u);
+              }
+              if (has_aux) {
+                const uint2 aa = *reinterpret_cast<const uint2*>(gaux + pix + co);
+                v[0] *= __uint_as_float(aa.x << 16) > 0.f ? 1.f : p.mslope;
+                v[1] *= __uint_as_float(aa.x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+                v[2] *= __uint_as_float(aa.y << 16) > 0.f ? 1.f : p.mslope;
+                v[3] *= __uint_as_float(aa.y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+              }
+              uint2 o;
+              o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+              o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+              if (ABL & 1) { asm volatile("" ::"v"(o.x), "v"(o.y)); } else *reinterpret_cast<uint2*>(gout + pix + co) = o;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (co + r >= p.Cout) continue;
+                float w = v[r];
+                if (has_res) w += Elem<TOut>::ld(gres + pix + co + r);
+                if (has_aux) w *= Elem<TOut>::ld(gaux + pix + co + r) > 0.f ? 1.f : p.mslope;
+                Elem<TOut>::st(gout + pix + co + r, w);
+              }
+            }
+          }
+        }
+      } else if (LDS_EPI && (p.Cout & 7) == 0 && !p.direct_epi) {
         // Phase 1: bias + activation in fp32 registers, bf16 tile into the (now idle) halo region of LDS.
         // Phase 2: every thread moves 16-byte rows: residual / mask operands arrive as vector loads and the
         // result leaves as one dwordx4 store per 8 channels (the per-lane 2-byte stores of the direct epilogue

@@ -120,21 +120,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   issue_dma(tile, 0);
   WS_STAMP(1);
 
-  // ---- weights -> registers: lane (frow, fg) of fragment (tap, kk, j) holds w[tap][cbase + 16 j + frow][32 kk + 8 fg .. +7]
+  // ---- weights -> registers: lane (frow, fg) of fragment (tap, kk, j) holds w[tap][cbase + 16 j + frow][32 kk + 8 fg .. +7].
+  //      Issued in the order the MFMA loop consumes them (kw, kk, kh, j): the loop below starts on the first fragments
+  //      while the rest are still streaming in (the compiler places the counted vmcnt waits), instead of draining all 36
+  //      loads first -- at kernel start every wave of the chip pulls its 36 KB through the texture path at once and the
+  //      full drain cost 13k of the 23k prologue cycles (tools/trace_ws.py).
   u32x4w wf[9][2][2];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int wt = p.flip ? 8 - tap : tap;
+  for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
-        const bool ok = co < p.Cout && ci < p.Cin;
-        wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
-            rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
+      for (int kh = 0; kh < 3; ++kh) {
+        const int tap = kh * 3 + kw;
+        const int wt = p.flip ? 8 - tap : tap;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
+          const bool ok = co < p.Cout && ci < p.Cin;
+          wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
+              rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
+        }
       }
-  }
   float bv[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -150,12 +157,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   // (vmcnt retires in issue order on gfx9-family parts) -- draining the stores too (vmcnt(0), or the vmcnt(0) that
   // __syncthreads() adds while a DMA is in flight) exposed a full store round trip per tile.  Hence also the raw s_barrier.
   WS_STAMP(2);                                              // weight loads issued
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first tile: this wave's DMA slots and its weight fragments
+  asm volatile("s_waitcnt vmcnt(36)" ::: "memory");         // first tile: this wave's DMA slots (all but the 36 weight loads)
   WS_STAMP(3);
   int buf = 0;
   [[maybe_unused]] int it = 0;
-  while (true) {
-    const int ntile = tile + gridDim.x;
+  // one tile: barrier, next tile's DMA, MFMA block, epilogue.  A lambda so that the FIRST tile is a peeled copy: there the
+  // compiler can wait for the weight fragments one by one (counted vmcnt) as the MFMA loop reaches them; inside the loop
+  // it would have to drain them all at the loop header.
+  auto process = [&](const int tile, const int ntile) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                           // every wave's slots landed; nobody still reads the other buffer
     WS_STAMP(4 + 5 * it);
@@ -229,12 +238,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
       }
     }
     WS_STAMP(7 + 5 * it);                                   // epilogue stores issued
-    tile = ntile;
-    if (tile >= p.ntiles) break;
+  };
+  process(tile, tile + gridDim.x);
+  tile += gridDim.x;
+  while (tile < p.ntiles) {
     buf ^= 1;
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // the DMA of the tile we turn to has landed (stores may still fly)
     WS_STAMP(8 + 5 * it);
     ++it;
+    process(tile, tile + gridDim.x);
+    tile += gridDim.x;
   }
 #ifdef TG_WS_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -252,8 +265,10 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   });
   // TG_CONV_COEXIST: ONE workgroup per CU (32 KB of unused LDS push the request past half the CU) -- two of them would
   // take 480 of the SIMD's 512 registers and lock the latency-bound chain kernel out of the CU
-  static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 2;      // A/B switch
-  const int per_cu = (coexist || per_cu_env < 2) ? 1 : 2;
+  // two workgroups per CU pay the weight prologue twice per CU: worth it from ~4 tiles per workgroup on
+  // (measured at 1020 tiles: 16.4 us with one, 17.8 us with two; at 9728 tiles: 97 vs 95 us); TG_C3WS_PERCU forces it
+  static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 0;      // A/B switch
+  const int per_cu = coexist ? 1 : (per_cu_env ? (per_cu_env < 2 ? 1 : 2) : (p.ntiles >= 2048 ? 2 : 1));
   const int LDS = per_cu == 1 ? LDS_MAX : 2 * WS_BUF;
   const int nt = p.Cout / 64;
   int gx = p.ntiles;

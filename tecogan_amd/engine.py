@@ -95,14 +95,15 @@ class TrainEngine:
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
-        # frames, 8 D's own-gradient passes, 16 generator weight gradients of the late frames
-        self.ov_parts = int(os.environ.get("TG_OVERLAP_PARTS", "15")) if self.overlap else 0
+        # frames, 8 D's own-gradient passes.  (Generator weight gradients of finished frames beside the BPTT were measured
+        # a loss twice -- 6.16 vs 6.00 ms in round 1, 4.35 vs 3.73 ms FRVSR with capped residency -- and are gone.)
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "15")) & 15) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
-        uses_side = ((self.use_vgg and self.ov_parts & 5) or (gan and self.ov_parts & 10) or (self.ov_parts & 16 and self.T > 1))
-        self.segmented = bool(uses_side) or self.world > 1
+        uses_side = (self.use_vgg and self.ov_parts & 5) or (gan and self.ov_parts & 10)
+        self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
 
     # ------------------------------------------------------------------------------------------
     def set_batch(self, r_inputs, r_targets):
@@ -231,12 +232,12 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
-        after = ["wgrad", "fnet_bwd"]
+        after = ["down"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["ar_d", "ar_g", "ar_f"]
+            after = ["down", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
 
@@ -280,7 +281,7 @@ class TrainEngine:
             """(stream key, conv footprint flag) of schedule piece `bit`."""
             return ("S", K.CONV_COEXIST) if (self.ov_parts & bit) else ("M", 0)
 
-        with seg("seq"):
+        with seg("head"):
             ps.grad.zero_()
             self.zbuf.zero_()
             if self.gan:
@@ -288,18 +289,7 @@ class TrainEngine:
             # ping-pong extension (lib/Teco.py:80-85) + [B,T] -> frame-major [T,B] in one gather each
             lr_seq = K.seq_gather(self.in_lr, torch.empty(T, B, h, h, 3, device=self.dev), self.seq_idx)
             hr_seq = K.seq_gather(self.in_hr, torch.empty(T, B, H, H, 3, device=self.dev), self.seq_idx)
-        hold += [lr_seq, hr_seq]
-        npair = (T - 1) * B
-        # ---- side: VGG-19 features of the targets (lib/Teco.py:177-178; needs hr_seq only) ---------------------
-        taps_t = None
-        if self.use_vgg:
-            sk, cx = part(1)
-            with seg("vggt", sk, ["seq"]):
-                xt = K.vgg_preprocess_forward(hr_seq.view(T * B, H, H, 3),
-                                              torch.empty(T * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
-                taps_t, _ = self.V.forward(xt, keep=False, flags=cx)
-            hold += [xt, taps_t]
-        with seg("fnet"):
+            npair = (T - 1) * B
             # ---- FNet on all consecutive pairs (lib/Teco.py:102-117) ------------------------------------
             pre_lr = lr_seq[:-1].reshape(npair, h, h, 3)
             cur_lr = lr_seq[1:].reshape(npair, h, h, 3)
@@ -316,11 +306,20 @@ class TrainEngine:
             d_wl = K.lincomb(warped_lr, cur_lr, torch.empty_like(warped_lr), c, -c)
             d_flow = torch.empty_like(flow)
             K.warp_backward(d_wl, pre_lr, flow, None, d_flow)
-        hold += [fnet_in, flow, fsaved, gd, warped_lr, d_wl, d_flow]
-        # ---- side: discriminator on the real triplets (needs the flows, not the generator) -----------------
+        hold += [lr_seq, hr_seq, fnet_in, flow, fsaved, gd, warped_lr, d_wl, d_flow]
+        # ---- side: VGG-19 features of the targets (lib/Teco.py:177-178; needs hr_seq only) and the discriminator on the
+        #      real triplets (needs the flows, not the generator) -- beside the first half of the forward chain
+        taps_t = None
+        if self.use_vgg:
+            sk, cx = part(1)
+            with seg("vggt", sk, ["head"]):
+                xt = K.vgg_preprocess_forward(hr_seq.view(T * B, H, H, 3),
+                                              torch.empty(T * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+                taps_t, _ = self.V.forward(xt, keep=False, flags=cx)
+            hold += [xt, taps_t]
         if self.gan:
             sk, cx = part(2)
-            with seg("dreal", sk, ["fnet"]):
+            with seg("dreal", sk, ["head"]):
                 gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
                                                     gd["merge"])
                 gd["p_real"], gd["l_real"], gd["sv_real"] = self.D.forward(gd["real"], flags=cx)
@@ -338,16 +337,18 @@ class TrainEngine:
                                    0.5, 0.5)
                 self.G.forward_t(t, gen[t])
 
+        early_on_side = self.use_vgg and bool(self.ov_parts & 4) and self._mode != "flat"
         with seg("fwd_a"):
             if self.G.seq is None or self._mode != "capture":
                 self.G.begin_sequence(T, B, h, h, self.dev)
-            forward_frames(0, tc)
+            forward_frames(0, tc if early_on_side else T)
         if self.use_vgg:
             sk, cx = part(4)
             with seg("vgg_early", sk, ["fwd_a", "vggt"]):
-                self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx, zero=True)
-        with seg("fwd_b"):
-            forward_frames(tc, T)
+                self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx if early_on_side else 0, zero=True)
+        with seg("fwd_b", "M", ["dreal", "vggt"]):
+            if early_on_side:
+                forward_frames(tc, T)
             # ---- generator losses seeded into d_gen -------------------------------------------------------
             nhr = float(T * B * H * H)
             K.sum_sq_diff(gen, hr_seq, 1.0 / nhr, self.loss[LI["l2_content_loss"]:LI["l2_content_loss"] + 1])
@@ -358,49 +359,42 @@ class TrainEngine:
                 gd["fake"] = K.pack_d_input_forward(gen, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
                                                     gd["merge"])
                 gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
+                self._gan_losses(gd)
         hold.append(d_gen)
         if self.gan:
-            with seg("dloss", "M", ["dreal"]):
-                self._gan_losses(gd)
             sk, cx = part(8)
-            with seg("down", sk, ["dloss"]):     # D's own gradients (t_discrim_loss) from both passes
+            with seg("down", sk, ["fwd_b"]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
                 self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
                 self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
             self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
-        with seg("dG", "M", ["vggt"]):
+        # ---- backward through the recurrence ------------------------------------------------------------------
+        d_flow_t = d_flow.view(T - 1, B, h, h, 2)
+        tail_split = self.exchange_mode == "captured"    # the RCCL segments hook in after wgrad and after FNet's backward
+        with seg("bwd", "M", ["vgg_early"]):
             if self.gan:     # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
                 dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
                 K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
                                         gd["off"], gd["merge"])
                 hold.append(dx)
-            if self.use_vgg and tc < T:                              # late frames: straight into d_gen
-                self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
-        # ---- backward through the recurrence ------------------------------------------------------------------
-        d_flow_t = d_flow.view(T - 1, B, h, h, 2)
-
-        def backward_frames(t1, t0):
-            for t in range(t1 - 1, t0 - 1, -1):
+            if self.use_vgg:
+                if tc < T:                                           # late frames: straight into d_gen
+                    self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
+                K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)      # early frames (computed beside the chain)
+            for t in range(T - 1, -1, -1):
                 dx_in = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
                 if t > 0:
                     K.warp_s2d_backward(dx_in, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
-
-        split = bool(self.ov_parts & 16) and 0 < tc < T
-        with seg("bptt_a", "M", ["vgg_early"]):
-            if self.use_vgg:                                         # early frames: computed beside the forward chain
-                K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)
-            backward_frames(T, tc if split else 0)
-        if split:
-            with seg("wgrad_late", "S", ["bptt_a"]):
-                self.G.wgrad_sequence(tc, T, flags=K.CONV_COEXIST)
-            with seg("bptt_b"):
-                backward_frames(tc, 0)
-        with seg("wgrad", "M", ["wgrad_late", "down"]):
-            self.G.wgrad_sequence(0, tc if split else T)
-        self._exchange_seg("ar_g", ["generator"], ["wgrad"])            # overlaps the FNet backward pass
-        with seg("fnet_bwd"):
-            self.Fn.backward(fsaved, d_flow)
-        self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
+            if not tail_split:
+                self.G.wgrad_sequence(0, T)
+                self.Fn.backward(fsaved, d_flow)
+        if tail_split:
+            with seg("wgrad"):
+                self.G.wgrad_sequence(0, T)
+            self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
+            with seg("fnet_bwd"):
+                self.Fn.backward(fsaved, d_flow)
+            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""

@@ -1,0 +1,37 @@
+"""rocprofv3 kernel names -> the names the library's launch profiler (csrc/runtime.hip, TG_LAUNCH) books them under."""
+import re
+
+_T = {"unsigned short": "bf16", "float": "f32"}
+
+
+def tg_name(k):
+    m = re.search(r"conv3x3_tile_kernel<([a-z ]+), ([a-z ]+), (\d+), (\d+), \d+>", k)
+    if m:
+        return "conv3x3_tile<%s,%s,%s,%s>" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4))
+    m = re.search(r"conv3x3_ws_kernel<(true|false), (true|false)>", k)
+    if m:
+        tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
+        return "conv3x3_ws<%s>" % ",".join(tags)
+    m = re.search(r"conv3x3_c8_kernel<(\d+)>", k)
+    if m:
+        return "conv3x3_c8<%s>" % m.group(1)
+    m = re.search(r"conv_igemm_kernel<([a-z ]+), ([a-z ]+), (\d+), (\d+), (\d+), (\d+), (true|false)>", k)
+    if m:
+        return "conv_igemm<%s,%s,%s,%s,%s,%s>" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4), m.group(5), m.group(6))
+    if "conv_wgrad_row3_bf16_kernel" in k:
+        return "conv_wgrad_row3_bf16"
+    m = re.search(r"conv_wgrad_bf16_kernel<(\d+)>", k)
+    if m:
+        return "conv_wgrad_bf16<%s>" % m.group(1)
+    m = re.search(r"conv_wgrad_kernel<([a-z ]+), ([a-z ]+)>", k)
+    if m:
+        return "conv_wgrad<%s,%s>" % (_T[m.group(1)], _T[m.group(2)])
+    for base, tg in (("warp_s2d_fwd_scalar_kernel", "warp_s2d_fwd_scalar"), ("warp_s2d_fwd_kernel", "warp_s2d_fwd"),
+                     ("warp_s2d_bwd_kernel", "warp_s2d_bwd"), ("bicubic_add_quad_kernel", "bicubic_add_quad"),
+                     ("bicubic_add_kernel", "bicubic_add"), ("upsample2_fwd_kernel", "upsample2_fwd")):
+        m = re.search(base + r"<([a-z ]+)>", k)
+        if m:
+            return "%s<%s>" % (tg, _T[m.group(1)])
+    if "upsample2_fwd_x8_kernel" in k:
+        return "upsample2_fwd_x8"
+    return None

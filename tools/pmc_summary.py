@@ -1,17 +1,26 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc counter_collection CSVs: mean counter value per kernel name, and (with --json OUT) the
-HBM-side traffic of the roofline kernel of bench.py in bytes per launch.
-    python tools/pmc_summary.py <fetch-dir> <write-dir> [--json profiles/pmc_traffic.json]
+"""Summarise rocprofv3 --pmc passes of the bench workload into profiles/<tag>_pmc.json, keyed by the launch profiler's
+kernel names (tools/knames.py), per launch:
+    fetch_bytes  = FETCH_SIZE [KiB] * 1024 * 2      (gfx950: FETCH_SIZE tallies the 128-B requests of wide reads at 64 B,
+                                                     MI355X_MICROARCH.md section HBM; calibrated in the same pass on a
+                                                     64 MiB-in streaming kernel when the run contains tg lincomb launches)
+    write_bytes  = WRITE_SIZE [KiB] * 1024
+    hbm_bytes_per_launch = fetch_bytes + write_bytes
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 * 256)    (cycles some SIMD's matrix pipe was busy,
+                                                     summed over the chip's 1024 SIMDs, over the cycles the GPU was active)
+Counters come from SEPARATE passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with trace domains).
 
-Units / corrections (MI355X_MICROARCH.md, HBM section; calibrated in the same passes on tools/pmc_conv.py's 64 MiB
-lincomb copy): FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of a wide
-(16 B / lane) read at 64 B, i.e. half the bytes -- doubled here; WRITE_SIZE matched the known byte count 1:1."""
+    python tools/pmc_summary.py --json profiles/r02_pmc.json <dir-or-csv> [...]
+"""
 import csv
 import glob
 import json
 import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from knames import tg_name  # noqa: E402
 
 
 def collect(path):
@@ -30,30 +39,36 @@ def main(argv):
         i = argv.index("--json")
         out_json = argv[i + 1]
         argv = argv[:i] + argv[i + 2:]
-    means = {}
+    per = defaultdict(lambda: defaultdict(list))
     for p in argv:
-        for (kern, ctr), vals in sorted(collect(p).items()):
-            k = kern if len(kern) < 110 else kern[:107] + "..."
-            means[(kern, ctr)] = sum(vals) / len(vals)
-            print("%-14s mean %14.1f  min %14.1f  max %14.1f  n=%4d  %s" % (ctr, sum(vals) / len(vals), min(vals), max(vals), len(vals), k))
+        for (kern, ctr), vals in collect(p).items():
+            name = tg_name(kern) or kern.split("(")[0][:80]
+            per[name][ctr].extend(vals)
+    res = {}
+    for name, ctrs in sorted(per.items()):
+        e = {"launches_counted": max(len(v) for v in ctrs.values())}
+        mean = {c: sum(v) / len(v) for c, v in ctrs.items()}
+        if "FETCH_SIZE" in mean:
+            e["raw_FETCH_SIZE_KiB"] = round(mean["FETCH_SIZE"], 2)
+            e["fetch_bytes"] = int(mean["FETCH_SIZE"] * 1024 * 2)
+        if "WRITE_SIZE" in mean:
+            e["raw_WRITE_SIZE_KiB"] = round(mean["WRITE_SIZE"], 2)
+            e["write_bytes"] = int(mean["WRITE_SIZE"] * 1024)
+        if "fetch_bytes" in e and "write_bytes" in e:
+            e["hbm_bytes_per_launch"] = e["fetch_bytes"] + e["write_bytes"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACTIVE"] > 0:
+            e["raw_SQ_VALU_MFMA_BUSY_CYCLES"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"], 1)
+            e["raw_GRBM_GUI_ACTIVE"] = round(mean["GRBM_GUI_ACTIVE"], 1)
+            e["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] * 4 * 256), 5)
+        for c in ("SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+            if c in mean:
+                e["raw_" + c] = round(mean[c], 1)
+        res[name] = e
+        print("%-44s %s" % (name, {k: v for k, v in e.items() if not k.startswith("raw_")}))
     if out_json:
-        def pick(sub, ctr):
-            for (kern, c), v in means.items():
-                if c == ctr and sub in kern:
-                    return v
-            return None
-        f, w = pick("conv3x3_tile_kernel", "FETCH_SIZE"), pick("conv3x3_tile_kernel", "WRITE_SIZE")
-        cf, cw = pick("lincomb_kernel", "FETCH_SIZE"), pick("lincomb_kernel", "WRITE_SIZE")
-        res = {}
-        if f is not None and w is not None:
-            res["conv3x3_tile_kernel@[4,32,32,64->64]_bf16"] = {
-                "fetch_bytes": int(f * 1024 * 2), "write_bytes": int(w * 1024),
-                "raw_FETCH_SIZE_KiB": f, "raw_WRITE_SIZE_KiB": w, "fetch_correction": 2.0,
-                "calibration": {"kernel": "lincomb 2 x 64 MiB in, 64 MiB out", "FETCH_SIZE_KiB": cf, "WRITE_SIZE_KiB": cw,
-                                "expected_read_KiB": 131072, "expected_write_KiB": 65536}}
         os.makedirs(os.path.dirname(os.path.abspath(out_json)), exist_ok=True)
         with open(out_json, "w") as fh:
-            json.dump(res, fh, indent=1)
+            json.dump(res, fh, indent=1, sort_keys=True)
         print("wrote", out_json)
 
 
