@@ -323,6 +323,15 @@ def main():
     x, y = synthetic_batch(F, 1234 + rank, device)
     eng.set_batch(x, y)
     dt = time_steps(eng, a.steps, a.warmup, fence)
+    host_ms = HOST_ENQUEUE_MS[0]
+    # host cost of enqueueing ONE step on an idle device (no queue back-pressure): the floor under which the step is host-bound
+    idle = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step()
+        idle.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -335,7 +344,7 @@ def main():
         cfg = {"workload": workload_name(a.config, F), "global_batch": world * F.batch_size,
                "frames_per_step": world * F.batch_size * frame_len, "parallelism": "dp%d" % world,
                "hipgraph": not a.no_graph, "graph_segments": len(eng._segs or []),
-               "host_enqueue_ms_per_step": round(HOST_ENQUEUE_MS[0], 3)}
+               "host_enqueue_ms_per_step": round(host_ms, 3), "host_enqueue_ms_idle_device": round(min(idle), 3)}
         if world > 1:
             cfg["collective_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
             cfg["ranks"] = torch.distributed.get_world_size()

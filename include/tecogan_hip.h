@@ -279,6 +279,19 @@ int tg_pack_d_input_backward(const void* d_out, int dtype, const float* frames, 
                              const float* flow_nxt, const int* idx_pre, const int* idx_nxt, float* d_frames, int B,
                              int h, int w, int nt, int off, int merge, int Cpad, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Data step before the path / output step after it.
+ * ------------------------------------------------------------------------ */
+/* tf_data_gaussDownby4 (lib/ops.py:347-367): depthwise k x k Gaussian (HOST array `weights`, k*k, row-major, k <= 11),
+ * stride 4, VALID: hr [N,H,W,3] fp32 -> lr [N,(H-k)/4+1,(W-k)/4+1,3]; target (nullable) additionally receives
+ * preprocess(hr[:, border:border+4h, border:border+4w]) = 2x-1 (lib/dataloader.py:306-332) in the same pass. */
+int tg_gauss_down4_preprocess(const float* hr, float* lr, float* target /*nullable*/, int N, int H, int W, int k,
+                              const float* weights /*host*/, int border, void* stream);
+
+/* save_img (lib/ops.py:521-523): out = uint8(clip(frame * 255, 0, 255)) (truncation), RGB or BGR byte order. */
+int tg_frame_to_u8(const float* frame /*[npix][3] in [0,1]*/, unsigned char* out /*[npix][3]*/, int64_t npix, int bgr,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

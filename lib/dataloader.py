@@ -64,14 +64,18 @@ class SyntheticSequences:
 
 
 class SceneSequences:
-    """Directory loader: shared random crop (+ Gaussian margin), random flip, GPU down-sampling
-    (reference lib/dataloader.py:53-167,276-348; the moving-first-frame augmentation is not reproduced)."""
+    """Directory loader (reference lib/dataloader.py:53-167,276-348): shared random crop with a Gaussian margin, random
+    flip, the moving-first-frame augmentation, GPU down-sampling + target crop + preprocess in one HIP launch.  PNG
+    decoding and augmentation run in a background thread that keeps `prefetch` batches ahead (the reference uses
+    FLAGS.queue_thread TF queue runners), so a training step of a few milliseconds is not input-bound."""
 
-    def __init__(self, FLAGS, device, first_dir, last_dir, seed=1):
+    def __init__(self, FLAGS, device, first_dir, last_dir, seed=1, prefetch=2):
         if FLAGS.input_video_dir == '':
             raise ValueError('Video input directory input_video_dir is not provided')
         if not os.path.exists(FLAGS.input_video_dir):
             raise ValueError('Video input directory not found')
+        if not FLAGS.random_crop:
+            raise Exception('Not implemented')          # as the reference (lib/dataloader.py:107): crops are required
         self.F, self.dev, self.rng = FLAGS, device, np.random.RandomState(seed)
         self.scenes = []
         for d in range(first_dir, last_dir + 1):
@@ -82,8 +86,10 @@ class SceneSequences:
             raise ValueError('No scene with %d frames under %s' % (FLAGS.max_frm + 1, FLAGS.input_video_dir))
         self.image_count = len(self.scenes) * (FLAGS.max_frm - FLAGS.RNN_N + 1)
         self.steps_per_epoch = self.image_count // FLAGS.batch_size
+        self._q, self._thread, self._prefetch = None, None, prefetch
 
-    def next_batch(self):
+    def _host_batch(self):
+        """One batch of HR crops [B,T,tar,tar,3] in [0,1] on the host (decode + augmentation)."""
         F = self.F
         border = int(1.5 * 3.0)
         tar = F.crop_size * 4 + 2 * border
@@ -91,18 +97,55 @@ class SceneSequences:
         for _ in range(F.batch_size):
             sd = self.scenes[self.rng.randint(len(self.scenes))]
             t0 = self.rng.randint(F.max_frm - F.RNN_N + 2)
-            frames = [_read_png(os.path.join(sd, 'col_high_%04d.png' % (t0 + i))) / 255.0 for i in range(F.RNN_N)]
-            H, W = frames[0].shape[:2]
+            moving = bool(F.movingFirstFrame) and self.rng.rand() >= 0.7        # lib/dataloader.py:146 (30 % of the sequences)
+            first = _read_png(os.path.join(sd, 'col_high_%04d.png' % t0)) / 255.0
+            H, W = first.shape[:2]
             oy, ox = self.rng.randint(H - tar + 1), self.rng.randint(W - tar + 1)
-            clip = np.stack([f[oy:oy + tar, ox:ox + tar] for f in frames])
-            if F.flip and self.rng.rand() < 0.5:
-                clip = clip[:, :, ::-1]
-            seqs.append(np.ascontiguousarray(clip))
-        hr = torch.from_numpy(np.stack(seqs)).to(self.dev)                     # [B,T,tar,tar,3] in [0,1]
-        B, T = hr.shape[:2]
-        lr = _ops.tf_data_gaussDownby4(hr.reshape(B * T, tar, tar, 3), 1.5).reshape(B, T, F.crop_size, F.crop_size, 3)
-        tgt = _ops.preprocess(hr[:, :, border:border + 4 * F.crop_size, border:border + 4 * F.crop_size]).contiguous()
-        return _ops.preprocessLR(lr), tgt
+            flip = bool(F.flip) and self.rng.rand() < 0.5
+            if moving:
+                # camera-motion augmentation (lib/dataloader.py:112-125,138-146): every frame is the FIRST frame, cropped at
+                # a random walk of integer offsets in [-4, 4] per step; the walk is shifted so that all crops stay inside
+                off = np.floor(self.rng.uniform(-3.5, 4.5, size=(F.RNN_N, 2))).astype(np.int64)
+                pos = np.concatenate((np.zeros((1, 2), np.int64), np.cumsum(off, 0)[:-1]))       # exclusive cumsum, (x, y)
+                mn = pos.min(0)
+                rng_xy = pos.max(0) - mn
+                lt = pos - mn
+                fy = int(np.clip(oy, 0, H - tar - rng_xy[1]))
+                fx = int(np.clip(ox, 0, W - tar - rng_xy[0]))
+                src = first[:, ::-1] if flip else first
+                clip = np.stack([src[fy + lt[i, 1]:fy + lt[i, 1] + tar, fx + lt[i, 0]:fx + lt[i, 0] + tar]
+                                 for i in range(F.RNN_N)])
+            else:
+                frames = [first] + [_read_png(os.path.join(sd, 'col_high_%04d.png' % (t0 + i))) / 255.0
+                                    for i in range(1, F.RNN_N)]
+                if flip:
+                    frames = [f[:, ::-1] for f in frames]
+                clip = np.stack([f[oy:oy + tar, ox:ox + tar] for f in frames])
+            seqs.append(np.ascontiguousarray(clip, dtype=np.float32))
+        return np.stack(seqs)
+
+    def _worker(self):
+        while True:
+            self._q.put(torch.from_numpy(self._host_batch()).pin_memory() if torch.cuda.is_available()
+                        else torch.from_numpy(self._host_batch()))
+
+    def next_batch(self):
+        F = self.F
+        if self._prefetch > 0:
+            if self._thread is None:
+                import queue
+                import threading
+                self._q = queue.Queue(maxsize=self._prefetch)
+                self._thread = threading.Thread(target=self._worker, daemon=True)
+                self._thread.start()
+            host = self._q.get()
+        else:
+            host = torch.from_numpy(self._host_batch())
+        hr = host.to(self.dev, non_blocking=True)                               # [B,T,tar,tar,3] in [0,1]
+        B, T, tar = hr.shape[0], hr.shape[1], hr.shape[2]
+        lr, tgt = _ops.gauss_down_crop_preprocess(hr.reshape(B * T, tar, tar, 3), 1.5)
+        cs = F.crop_size
+        return _ops.preprocessLR(lr).reshape(B, T, cs, cs, 3), tgt.reshape(B, T, 4 * cs, 4 * cs, 3)
 
 
 def frvsr_gpu_data_loader(FLAGS, useValData_ph=None, device="cuda", synthetic=False, rank=0):

@@ -326,12 +326,26 @@ def tf_data_gaussDownby4(HRdata, sigma=1.5):
     if Cn != 3:
         raise ValueError("tf_data_gaussDownby4 only works for RGB images")
     k_w = 1 + 2 * int(sigma * 3.0)
-    gk = torch.tensor(gaussian_2dkernel(k_w, sigma), dtype=torch.float32, device=x.device)
-    wt = torch.zeros(k_w * k_w, 3, 8, device=x.device)
-    for c in range(3):
-        wt[:, c, c] = gk.reshape(-1)
+    gk = np.float32(gaussian_2dkernel(k_w, sigma)).reshape(-1)
     Ho, Wo = (H - k_w) // 4 + 1, (W - k_w) // 4 + 1
-    return _conv_forward(_pad_channels(x, 8), wt, None, (N, H, W, 8, Ho, Wo, k_w, 4, 0, 0, 0), 3)
+    # one depthwise HIP kernel (3 channels: memory-bound, no MFMA); the loader's fused form also crops + preprocesses the
+    # target in the same launch (gauss_down_crop_preprocess below)
+    return K.gauss_down4_preprocess(x.float().contiguous(), gk, torch.empty(N, Ho, Wo, 3, device=x.device))
+
+
+def gauss_down_crop_preprocess(HRdata, sigma=1.5):
+    """The training loader's GPU data step in ONE launch (reference lib/dataloader.py:306-332): HR crop [N,H,W,3] in [0,1]
+    with a `border = int(1.5*3)` blur margin -> (preprocessLR(gauss_down4(HR)), preprocess(HR[border:-border]))."""
+    x = _need_cuda(HRdata).float().contiguous()
+    N, H, W, _ = x.shape
+    k_w = 1 + 2 * int(sigma * 3.0)
+    border = int(sigma * 3.0)
+    gk = np.float32(gaussian_2dkernel(k_w, sigma)).reshape(-1)
+    Ho, Wo = (H - k_w) // 4 + 1, (W - k_w) // 4 + 1
+    lr = torch.empty(N, Ho, Wo, 3, device=x.device)
+    tgt = torch.empty(N, 4 * Ho, 4 * Wo, 3, device=x.device)
+    K.gauss_down4_preprocess(x, gk, lr, tgt, border)
+    return lr, tgt
 
 
 # ------------------------------------------------------------------------------------------------
@@ -364,11 +378,17 @@ def get_existing_from_ckpt(ckpt, var_list=None, rest_zero=False, print_level=1):
 
 
 def save_img(out_path, img):
-    """clip(img*255, 0, 255).astype(uint8) -- truncation, like the reference -- written as RGB by PIL."""
+    """clip(img*255, 0, 255).astype(uint8) -- truncation, like the reference -- written as RGB by PIL.  Device tensors are
+    converted on the GPU (tg_frame_to_u8) so only a quarter of the bytes crosses PCIe; the streaming inference loop uses
+    the asynchronous tecogan_amd.output.FrameWriter instead."""
     from PIL import Image
-    if isinstance(img, torch.Tensor):
-        img = img.detach().float().cpu().numpy()
-    arr = np.clip(img * 255.0, 0, 255).astype(np.uint8)
+    if isinstance(img, torch.Tensor) and img.is_cuda:
+        u8 = K.frame_to_u8(img.detach().float().contiguous(), torch.empty(img.shape, dtype=torch.uint8, device=img.device))
+        arr = u8.cpu().numpy()
+    else:
+        if isinstance(img, torch.Tensor):
+            img = img.detach().float().cpu().numpy()
+        arr = np.clip(img * 255.0, 0, 255).astype(np.uint8)
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     Image.fromarray(arr).save(out_path)
 

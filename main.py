@@ -112,6 +112,8 @@ def run_inference(FLAGS):
     image_dir = FLAGS.output_dir if FLAGS.output_pre == "" else os.path.join(FLAGS.output_dir, FLAGS.output_pre)
     os.makedirs(image_dir, exist_ok=True)
     max_iter, srtime = len(data.inputs), 0.0
+    from tecogan_amd.output import FrameWriter
+    writer = FrameWriter((4 * h, 4 * w, 3))                  # uint8 conversion on the GPU, async D2H, background encoding
     print('Frame evaluation starts!!')
     for i in range(max_iter):
         frame = torch.from_numpy(data.inputs[i].copy()).float()[None].cuda()
@@ -124,9 +126,10 @@ def run_inference(FLAGS):
             name = os.path.splitext(os.path.basename(str(data.paths_LR[i])))[0]
             filename = FLAGS.output_name + '_' + name
             print('saving image %s' % filename)
-            save_img(os.path.join(image_dir, "%s.%s" % (filename, FLAGS.output_ext)), out[0])
+            writer.submit(os.path.join(image_dir, "%s.%s" % (filename, FLAGS.output_ext)), out[0])
         else:   # first 5 frames: mirrored warm-up, timed but not saved (reference main.py:268-269)
             print("Warming up %d" % (5 - i))
+    writer.close()
     print("total time " + str(srtime) + ", frame number " + str(max_iter))
 
 

@@ -653,7 +653,9 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   p.act = d->act; p.act_alpha = d->act_alpha;
   static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
   p.direct_epi = direct;
-  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 0;
+  // default ON: with throughput kernels of the side stream on the same CU, the chain's waves at s_setprio 3 hide 75 % instead
+  // of 48 % of a co-running VGG layer (tools/mb_forktax.py D: 5.14 vs 6.06 ms) and the TecoGAN step gains 2 %
+  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
   p.prio = prio;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);

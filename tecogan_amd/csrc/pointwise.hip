@@ -1002,3 +1002,82 @@ void tg_set_error(const char* fmt, ...) {
 }
 extern "C" const char* tg_last_error_string(void) { return g_err; }
 extern "C" int tg_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// Data step BEFORE the path: tf_data_gaussDownby4 (lib/ops.py:347-367) -- depthwise k x k Gaussian, stride 4,
+// VALID -- fused with the training loader's 4-pixel... `border`-pixel crop + preprocess of the HR target
+// (lib/dataloader.py:306-332: target = preprocess(HR[border:-border]), input = preprocessLR(gauss_down(HR))).
+// One thread per LR pixel: its k x k window (81 taps x 3 channels, fp32, L1/L2 resident) and the 4x4 HR block it maps to.
+// No MFMA: 3 channels, memory-bound (HR read once: 12 B / HR pixel).
+struct GaussP {
+  float w[121];          // up to 11 x 11 taps (sigma 1.5 -> 9 x 9), row-major
+};
+
+__global__ __launch_bounds__(256) void gauss_down4_kernel(const float* __restrict__ hr, float* __restrict__ lr,
+                                                          float* __restrict__ target, int N, int H, int W, int k, int border,
+                                                          GaussP g) {
+  const int ho = (H - k) / 4 + 1, wo = (W - k) / 4 + 1;
+  const int n = N * ho * wo;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int j = e % wo, i = (e / wo) % ho, b = e / (wo * ho);
+    const float* __restrict__ src = hr + ((int64_t)(b * H + 4 * i) * W + 4 * j) * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        const float wv = g.w[ky * k + kx];
+        const float* __restrict__ p = src + ((int64_t)ky * W + kx) * 3;
+        acc[0] += wv * p[0];
+        acc[1] += wv * p[1];
+        acc[2] += wv * p[2];
+      }
+    lr[(int64_t)e * 3] = acc[0];
+    lr[(int64_t)e * 3 + 1] = acc[1];
+    lr[(int64_t)e * 3 + 2] = acc[2];
+    if (target) {                                            // preprocess(x) = 2x - 1 of the cropped HR block (lib/ops.py:13-16)
+      const int Ht = 4 * ho, Wt = 4 * wo;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy) {
+        const float* __restrict__ s = hr + ((int64_t)(b * H + border + 4 * i + dy) * W + border + 4 * j) * 3;
+        float* __restrict__ d = target + ((int64_t)(b * Ht + 4 * i + dy) * Wt + 4 * j) * 3;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) d[q] = s[q] * 2.f - 1.f;
+      }
+    }
+  }
+}
+
+extern "C" int tg_gauss_down4_preprocess(const float* hr, float* lr, float* target, int N, int H, int W, int k,
+                                         const float* weights, int border, void* stream) {
+  TG_CHECK_ARG(hr && lr && weights && N > 0 && k >= 1 && k <= 11 && H >= k && W >= k, "bad argument");
+  const int ho = (H - k) / 4 + 1, wo = (W - k) / 4 + 1;
+  TG_CHECK_ARG(!target || (border >= 0 && border + 4 * ho <= H && border + 4 * wo <= W), "target crop leaves the image");
+  TG_CHECK_ARG((int64_t)N * H * W * 3 < ((int64_t)1 << 31), "tensor too large");
+  GaussP g;
+  for (int t = 0; t < k * k; ++t) g.w[t] = weights[t];
+  hipLaunchKernelGGL(gauss_down4_kernel, dim3(grid_1d((int64_t)N * ho * wo, 256, 1 << 16)), dim3(256), 0, ST(stream), hr, lr,
+                     target, N, H, W, k, border, g);
+  TG_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output step AFTER the path: save_img's clip(img * 255, 0, 255).astype(uint8) -- truncation -- and the
+// RGB -> BGR flip cv.imwrite wants (lib/ops.py:521-523, main.py:262-267), on the device: the host copy shrinks 4x
+// (1 byte instead of 4 per value) and can run asynchronously into pinned memory (tecogan_amd/output.py).
+__global__ __launch_bounds__(256) void frame_to_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
+                                                          int64_t npix, int bgr) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const float r = x[p * 3], g = x[p * 3 + 1], b = x[p * 3 + 2];
+    const unsigned char cr = (unsigned char)fminf(fmaxf(r * 255.f, 0.f), 255.f);
+    const unsigned char cg = (unsigned char)fminf(fmaxf(g * 255.f, 0.f), 255.f);
+    const unsigned char cb = (unsigned char)fminf(fmaxf(b * 255.f, 0.f), 255.f);
+    out[p * 3] = bgr ? cb : cr;
+    out[p * 3 + 1] = cg;
+    out[p * 3 + 2] = bgr ? cr : cb;
+  }
+}
+
+extern "C" int tg_frame_to_u8(const float* frame, unsigned char* out, int64_t npix, int bgr, void* stream) {
+  TG_CHECK_ARG(frame && out && npix > 0, "bad argument");
+  hipLaunchKernelGGL(frame_to_u8_kernel, dim3(grid_1d(npix, 256, 1 << 16)), dim3(256), 0, ST(stream), frame, out, npix, bgr);
+  TG_CHECK_LAUNCH();
+}

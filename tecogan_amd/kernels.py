@@ -272,6 +272,23 @@ def resblock_fused(x, w1, b1, m1, mid, w2, b2, m2, out, flip, relu1):
     return out
 
 
+# ---- data step before / output step after the path -----------------------------------
+def gauss_down4_preprocess(hr, weights2d, lr, target=None, border=0):
+    """hr [N,H,W,3] fp32 -> lr (Gaussian k x k, stride 4, VALID); target (optional) = 2*hr[crop]-1 in the same launch."""
+    N, H, W, _ = hr.shape
+    k = int(round(len(weights2d) ** 0.5))
+    wts = (C.c_float * (k * k))(*[float(v) for v in weights2d])
+    check(lib().tg_gauss_down4_preprocess(_p(hr), _p(lr), _p(target), N, H, W, k, wts, border, _stream()),
+          "tg_gauss_down4_preprocess")
+    return lr
+
+
+def frame_to_u8(frame, out, bgr=False):
+    """frame [...,3] fp32 in [0,1] -> out uint8, truncating like save_img (lib/ops.py:521-523)."""
+    check(lib().tg_frame_to_u8(_p(frame), _p(out), frame.numel() // 3, int(bgr), _stream()), "tg_frame_to_u8")
+    return out
+
+
 # ---- built-in launch profiler (csrc/runtime.hip) -----------------------------------------------------
 def prof_enable(on=True):
     check(lib().tg_prof_enable(int(bool(on))), "tg_prof_enable")

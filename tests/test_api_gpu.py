@@ -179,3 +179,39 @@ def test_main_inference_and_training_cli(tmp_path):
     r = subprocess.run(base + ["--max_iter", "2", "--checkpoint", str(tr / "model-4"), "--nopre_trained_model"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0 and "global_step 6" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_fused_data_step_and_output_step(tmp_path):
+    """Gaussian down-sampling + target crop + preprocess in one launch (reference lib/ops.py:347-367,
+    lib/dataloader.py:306-332) and the uint8 output conversion with the asynchronous frame writer (lib/ops.py:521-523)."""
+    import numpy as np
+    from PIL import Image
+    import lib.ops as ops
+    from tecogan_amd.output import FrameWriter
+    g = torch.Generator().manual_seed(4)
+    hr = torch.rand(3, 40, 48, 3, generator=g)
+    lr, tgt = ops.gauss_down_crop_preprocess(hr.cuda(), 1.5)
+    k = torch.tensor(ops.gaussian_2dkernel(9, 1.5), dtype=torch.float32)
+    w = torch.zeros(3, 1, 9, 9)
+    w[:] = k
+    ref = torch.nn.functional.conv2d(hr.permute(0, 3, 1, 2), w, stride=4, groups=3).permute(0, 2, 3, 1)
+    assert tuple(lr.shape) == (3, 8, 10, 3) and tuple(tgt.shape) == (3, 32, 40, 3)
+    assert (lr.cpu() - ref).abs().max().item() < 2e-6
+    assert torch.equal(tgt.cpu(), hr[:, 4:36, 4:44] * 2 - 1)                     # preprocess: bit-exact
+    assert (ops.tf_data_gaussDownby4(hr.cuda(), 1.5).cpu() - ref).abs().max().item() < 2e-6
+    # output step: truncating uint8 conversion, RGB and BGR, incl. out-of-range values
+    fr = (torch.rand(1, 36, 52, 3, generator=g) * 1.4 - 0.2)
+    u8 = torch.empty(36, 52, 3, dtype=torch.uint8, device="cuda")
+    from tecogan_amd import kernels as K
+    K.frame_to_u8(fr[0].cuda(), u8)
+    want = np.clip(fr[0].numpy() * 255.0, 0, 255).astype(np.uint8)
+    assert np.array_equal(u8.cpu().numpy(), want)
+    K.frame_to_u8(fr[0].cuda(), u8, bgr=True)
+    assert np.array_equal(u8.cpu().numpy(), want[:, :, ::-1])
+    wr = FrameWriter((36, 52, 3), slots=2)
+    for i in range(5):
+        wr.submit(str(tmp_path / ("f%d.png" % i)), (fr[0] * (0.5 + 0.1 * i)).cuda())
+    wr.close()
+    for i in range(5):
+        got = np.asarray(Image.open(tmp_path / ("f%d.png" % i)))
+        assert np.array_equal(got, np.clip((fr[0] * (0.5 + 0.1 * i)).numpy() * 255.0, 0, 255).astype(np.uint8)), i

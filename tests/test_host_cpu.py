@@ -209,3 +209,40 @@ def test_engine_program_dry_run_with_mocked_kernels(monkeypatch):
         # the overlap schedule only splits the generator weight-gradient pass in two: same launches otherwise
         strip = [c for c in counts["1"] if not c.startswith("conv_wgrad") and c != "colsum"]
         assert strip == [c for c in counts["0"] if not c.startswith("conv_wgrad") and c != "colsum"]
+
+
+def test_scene_loader_moving_first_frame_augmentation(tmp_path):
+    """lib/dataloader.py:112-146 of the reference: 30 % of the sequences show the FIRST frame under a random walk of
+    integer crop offsets in [-4, 4] per step (camera-motion augmentation); the others are ordinary frame sequences."""
+    import numpy as np
+    from PIL import Image
+    from lib.dataloader import SceneSequences
+    from tecogan_amd.flags import frvsr_flags
+    F = frvsr_flags(batch_size=8, RNN_N=4, crop_size=8, input_video_dir=str(tmp_path), str_dir=1000, end_dir=1000, max_frm=7,
+                    flip=False)
+    sd = tmp_path / "scene_1000"
+    sd.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(8):     # every frame has its own constant red level, plus a fixed spatial pattern in green / blue
+        img = np.zeros((64, 72, 3), np.uint8)
+        img[..., 0] = 10 * i + 5
+        img[..., 1] = np.arange(64)[:, None] * 3
+        img[..., 2] = np.arange(72)[None, :] * 3
+        Image.fromarray(img).save(sd / ("col_high_%04d.png" % i))
+    ld = SceneSequences(F, "cpu", 1000, 1000, seed=3, prefetch=0)
+    moved = plain = 0
+    for _ in range(6):
+        clips = ld._host_batch()                                         # [B,T,tar,tar,3]
+        assert clips.shape == (8, 4, 8 * 4 + 8, 8 * 4 + 8, 3)
+        for c in clips:
+            reds = [round(float(c[t, 0, 0, 0]) * 255) for t in range(4)]
+            if len(set(reds)) == 1:                                      # all four crops come from ONE frame
+                moved += 1
+                dy = [round((float(c[t + 1, 0, 0, 1]) - float(c[t, 0, 0, 1])) * 255 / 3) for t in range(3)]
+                dx = [round((float(c[t + 1, 0, 0, 2]) - float(c[t, 0, 0, 2])) * 255 / 3) for t in range(3)]
+                assert all(-4 <= d <= 4 for d in dy + dx), (dy, dx)
+            else:
+                plain += 1
+                assert reds == [reds[0] + 10 * t for t in range(4)], reds      # consecutive frames, one shared crop
+                assert all(c[t, 0, 0, 1] == c[0, 0, 0, 1] and c[t, 0, 0, 2] == c[0, 0, 0, 2] for t in range(4))
+    assert moved > 0 and plain > moved, (moved, plain)

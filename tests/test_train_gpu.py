@@ -30,8 +30,8 @@ def frame_major(gen_outputs):          # oracle [B,T,...] -> engine [T,B,...]
     return gen_outputs.transpose(0, 1)
 
 
-def run_pair(F, gan, steps=1, act_dtype=torch.float32, use_graph=False, damp=False):
-    S = OT.State(F, seed=42, gan=gan)
+def run_pair(F, gan, steps=1, act_dtype=torch.float32, use_graph=False, damp=False, oracle_dtype=torch.float32):
+    S = OT.State(F, seed=42, gan=gan, dtype=oracle_dtype)
     if damp:        # a well-conditioned recurrence (tecogan_amd.params.damp_values): see check_full_config
         from tecogan_amd.params import damp_values
         S.P = damp_values(S.P)
@@ -42,7 +42,7 @@ def run_pair(F, gan, steps=1, act_dtype=torch.float32, use_graph=False, damp=Fal
     x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
     out = []
     for _ in range(steps):
-        R = OT.train_step(S, x, y)
+        R = OT.train_step(S, x.to(oracle_dtype), y.to(oracle_dtype))
         eng.step(x.to(DEV), y.to(DEV))
         torch.cuda.synchronize()
         out.append(R)
@@ -162,7 +162,9 @@ def check_full_config(F, gan, tag):
     Weights: seeded xavier, damped (params.damp_values) so that the 10/19-frame recurrence is well conditioned -- with the
     raw xavier init the frame maximum doubles per frame and the fp32 ORACLE itself is 1.6e-2 away from its own fp64 run
     at frame 18 (tests/oracle_conditioning.py), so no fp32 implementation can be held to 1e-3 there."""
-    S, eng, Rs = run_pair(F, gan=gan, damp=True)
+    # The oracle runs in float64 here: at these sizes the fp32 oracle's own rounding (batch-norm backward subtracts
+    # sums over 1e5 pixels) is of the order of the tolerance, so the fp64 run is the truth both fp32 paths are held to.
+    S, eng, Rs = run_pair(F, gan=gan, damp=True, oracle_dtype=torch.float64)
     R = Rs[-1]
     worst = assert_close_per_elem(eng.gen, frame_major(R["gen_outputs"]), 1e-3, 1e-3, what=tag + " gen_outputs")
     L = eng.losses()

@@ -9,9 +9,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--h", type=int, default=270); ap.add_argument("--w", type=int, default=480)
 ap.add_argument("--frames", type=int, default=60); ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--nres", type=int, default=16)
+ap.add_argument("--no-graph", action="store_true")
 a = ap.parse_args()
 tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-eng = InferenceEngine(a.nres, a.h, a.w, "cuda", tdt)
+eng = InferenceEngine(a.nres, a.h, a.w, "cuda", tdt, use_graph=not a.no_graph)
 frames = torch.rand(8, 1, a.h, a.w, 3, device="cuda")
 for i in range(a.warmup):
     eng.step(frames[i % 8])
