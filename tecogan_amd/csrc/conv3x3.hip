@@ -45,12 +45,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ABL: profiling-only ablation bits (1 = skip epilogue stores, 2 = skip the MFMA block, 4 = skip reloads of later
 // stages, 8 = skip LDS staging writes of later stages); the product always launches ABL = 0.
-template <typename TIn, typename TOut, int TH, int BN, int ABL = 0>
+// PACK > 1 (images no wider than 16/PACK pixels: VGG conv5 at 8x8, FNet's 8x8 / 4x4 levels): the 16 tile columns hold
+// PACK images side by side -- LDS columns [0 | image 0 | 0 | image 1 | 0 ...], the zero columns are each image's left /
+// right padding -- instead of one image and 8 (12) idle columns; the fragment address only gains a per-lane column
+// offset (frow / WP).  conv5 ran at 135 TFLOP/s with half of every MFMA multiplying padding.
+template <typename TIn, typename TOut, int TH, int BN, int ABL = 0, int PACK = 1>
 __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   constexpr int EPV = 16 / (int)sizeof(TIn);
   constexpr int BK = 8 * EPV;                       // channels per 128-byte chunk
   constexpr int ROWB = 144;
-  constexpr int HALO_PIX = (TH + 2) * 18;
+  constexpr int WP = 16 / PACK;                      // columns per packed image
+  constexpr int HW = PACK > 1 ? 16 + PACK + 1 : 18;  // LDS halo columns
+  constexpr int HALO_PIX = (TH + 2) * HW;
   constexpr int A_ITEMS = HALO_PIX * 8, A_LOADS = (A_ITEMS + 255) / 256;
   constexpr int B_ITEMS = 9 * BN * 8, B_LOADS = (B_ITEMS + 255) / 256;
   constexpr int WAVES_M = TH >= 4 ? 4 : TH, WAVES_N = 4 / WAVES_M;
@@ -92,9 +98,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   for (int k = 0; k < A_LOADS; ++k) {
     const int item = min(tid + k * 256, A_ITEMS - 1);
     const int pix = item >> 3, ch = item & 7;
-    const int dy = pix / 18, dx = pix % 18;
-    relA[k] = ((dy * p.W + dx) * p.Cin + ch * EPV) * (int)sizeof(TIn);      // bytes
-    dydx[k] = dy | (dx << 8) | ((ch * EPV) << 16);
+    const int dy = pix / HW, dx = pix % HW;
+    if constexpr (PACK == 1) {
+      relA[k] = ((dy * p.W + dx) * p.Cin + ch * EPV) * (int)sizeof(TIn);      // bytes
+      dydx[k] = dy | (dx << 8) | ((ch * EPV) << 16);
+    } else {                  // dx field: local column + 1 (0 = separator / padding column); bits 28..: image within the group
+      const int g = dx / (WP + 1), lc1 = dx % (WP + 1);
+      relA[k] = (((g * p.H + dy) * p.W + lc1 - 1) * p.Cin + ch * EPV) * (int)sizeof(TIn);
+      dydx[k] = dy | (lc1 << 8) | ((ch * EPV) << 16) | (g << 28);
+    }
   }
   int relB[B_LOADS];          // < 0: row beyond Cout (stays zero)
 #pragma unroll
@@ -116,14 +128,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   auto load_stage = [&](int tile, int chunk, bool with_b) {
     const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
     const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-    const int y0 = ty * TH - 1, x0 = tx * 16 - 1;
+    const int y0 = ty * TH - 1, x0 = PACK > 1 ? 0 : tx * 16 - 1;
     const int c0 = chunk * BK;
-    const int base = (((n * p.H + y0) * p.W + x0) * p.Cin + c0) * (int)sizeof(TIn);   // wave-uniform, bytes
+    const int base = (((n * PACK * p.H + y0) * p.W + x0) * p.Cin + c0) * (int)sizeof(TIn);   // wave-uniform, bytes
 #pragma unroll
     for (int k = 0; k < A_LOADS; ++k) {
       // Loads are UNCONDITIONAL (a branch around each load makes hipcc wait vmcnt(0) per load).
-      const int y = y0 + (dydx[k] & 255), x = x0 + ((dydx[k] >> 8) & 255), c = c0 + (dydx[k] >> 16);
-      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && c < p.Cin;
+      const int y = y0 + (dydx[k] & 255), c = c0 + ((dydx[k] >> 16) & 0xfff);
+      bool ok = (unsigned)y < (unsigned)p.H && c < p.Cin;
+      if constexpr (PACK == 1) {
+        const int x = x0 + ((dydx[k] >> 8) & 255);
+        ok = ok && (unsigned)x < (unsigned)p.W;
+      } else {
+        const int lc1 = (dydx[k] >> 8) & 255;
+        ok = ok && lc1 != 0 && lc1 <= p.W && n * PACK + (dydx[k] >> 28) < p.N;
+      }
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)(ok ? (unsigned)(base + relA[k]) : OOB), 0, 0);
       ra[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   };
 
   // fragment bases: lane part + wave part once; every (tap, kk, tile) offset below is a compile-time constant
-  const unsigned char* Afrag = As + (wm * TM * 18 + frow) * ROWB + fg * 16;
+  const unsigned char* Afrag = As + (wm * TM * HW + frow + (PACK > 1 ? frow / WP : 0)) * ROWB + fg * 16;
   const unsigned char* Bfrag = Bs + (wn * TN * 16 + frow) * ROWB + fg * 16;
   const int col0 = n0 + wn * TN * 16 + frow;
   float bv[TN];
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
         uint4 af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[i] = *reinterpret_cast<const uint4*>(Afrag + ((i + kh) * 18 + kw) * ROWB + kk * 64);
+          af[i] = *reinterpret_cast<const uint4*>(Afrag + ((i + kh) * HW + kw) * ROWB + kk * 64);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           bfr[j] = *reinterpret_cast<const uint4*>(Bfrag + (tap * BN + j * 16) * ROWB + kk * 64);
@@ -240,13 +259,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
       constexpr bool LDS_EPI = sizeof(TOut) == 2;      // bf16 outputs: stage through LDS, 16-byte global rows
       if constexpr (SWAP) {
         // accumulator r of lane (frow, fg) = pixel column frow, output channel chan0 + 16 j + 4 fg + r
-        const int x = tx * 16 + frow;
+        const int x = PACK > 1 ? frow % WP : tx * 16 + frow;
+        const int nimg = PACK > 1 ? n * PACK + frow / WP : n;
         const bool vec4 = (p.Cout & 3) == 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int y = ty * TH + wm * TM + i;
-          if (y >= p.H || x >= p.W) continue;
-          const int pix = ((n * p.H + y) * p.W + x) * p.Cout;
+          if (y >= p.H || x >= p.W || nimg >= p.N) continue;
+          const int pix = ((nimg * p.H + y) * p.W + x) * p.Cout;
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn * TN * 16 + j * 16 + fg * 4;
@@ -323,11 +343,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
         const int y0 = ty * TH, x0 = tx * 16;
         for (int it = tid; it < NV; it += 256) {
           const int pl = it / VPP, cv = it % VPP;
-          const int y = y0 + pl / 16, x = x0 + pl % 16, c = n0 + cv * 8;
+          const int col = pl % 16;
+          const int y = y0 + pl / 16, x = PACK > 1 ? col % WP : x0 + col, c = n0 + cv * 8;
+          const int nimg = PACK > 1 ? n * PACK + col / WP : n;
           if (ABL & 1) continue;
-          if (y >= p.H || x >= p.W || c >= p.Cout) continue;
+          if (y >= p.H || x >= p.W || c >= p.Cout || nimg >= p.N) continue;
           uint4 o = *reinterpret_cast<const uint4*>(stage + pl * SP + cv * 8);
-          const int idx = ((n * p.H + y) * p.W + x) * p.Cout + c;
+          const int idx = ((nimg * p.H + y) * p.W + x) * p.Cout + c;
           if (has_res || has_aux) {
             uint4 rr = make_uint4(0, 0, 0, 0), aa = rr;
             if (has_res) rr = *reinterpret_cast<const uint4*>(gres + idx);
@@ -384,25 +406,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
   }
 }
 
-template <typename TIn, typename TOut, int TH, int BN, int ABL = 0>
+template <typename TIn, typename TOut, int TH, int BN, int ABL = 0, int PACK = 1>
 static void launch3(Conv3P p, hipStream_t st) {
-  constexpr int LDS = ((TH + 2) * 18 + 9 * BN) * 144;
-  auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN, ABL>;
+  constexpr int LDS = ((TH + 2) * (PACK > 1 ? 16 + PACK + 1 : 18) + 9 * BN) * 144;
+  auto kern = conv3x3_tile_kernel<TIn, TOut, TH, BN, ABL, PACK>;
   static std::once_flag attr_once;               // one-time, thread-safe: raise the dynamic-LDS limit of this instantiation
   std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   p.tiles_y = (p.H + TH - 1) / TH;
-  p.tiles_x = (p.W + 15) / 16;
-  p.ntiles = p.N * p.tiles_y * p.tiles_x;
+  p.tiles_x = PACK > 1 ? 1 : (p.W + 15) / 16;
+  p.ntiles = ((p.N + PACK - 1) / PACK) * p.tiles_y * p.tiles_x;
   const int nt = (p.Cout + BN - 1) / BN;
   int gx = p.ntiles;
   const int per = 256 / nt > 0 ? 256 / nt : 1;        // one workgroup per CU (LDS-bound residency)
   if (gx > per) gx = per;
   static const char* const pname = [] {
     static char b[96];
-    snprintf(b, sizeof(b), "conv3x3_tile<%s,%s,%d,%d>", sizeof(TIn) == 2 ? "bf16" : "f32", sizeof(TOut) == 2 ? "bf16" : "f32",
-             TH, BN);
+    snprintf(b, sizeof(b), PACK > 1 ? "conv3x3_tile<%s,%s,%d,%d,pack%d>" : "conv3x3_tile<%s,%s,%d,%d>",
+             sizeof(TIn) == 2 ? "bf16" : "f32", sizeof(TOut) == 2 ? "bf16" : "f32", TH, BN, PACK);
     return (const char*)b;
   }();
   const double px = (double)p.N * p.H * p.W;
@@ -447,12 +469,21 @@ static void launch3_typed(const Conv3P& p, hipStream_t st, bool coexist) {
       if (th == 16 && bn == 32) return launch3<TIn, TOut, 16, 32>(p, st);
     }
   }
+  if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
+    // narrow images: several per tile row (A/B switch TG_NO_C3_PACK=1)
+    static const bool no_pack = getenv("TG_NO_C3_PACK") != nullptr;
+    if (!no_pack && !p.direct_epi && p.W <= 8 && p.N >= 2 && (p.Cout & 7) == 0 && p.Cout >= 64 && !(force && p.Cout > 32)) {
+      if (p.W <= 4 && p.N >= 4) return launch3<TIn, TOut, 4, 64, 0, 4>(p, st);
+      if (p.H <= 4) return launch3<TIn, TOut, 4, 64, 0, 2>(p, st);
+      return launch3<TIn, TOut, 8, 64, 0, 2>(p, st);
+    }
+  }
   if (p.Cout <= 16) {
-    if (pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 16>(p, st);
+    if (!coexist && pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 16>(p, st);
     else if (pix >= 8 * 16 * 256) launch3<TIn, TOut, 8, 16>(p, st);
     else launch3<TIn, TOut, 4, 16>(p, st);
   } else if (p.Cout <= 32) {
-    if (pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 32>(p, st);
+    if (!coexist && pix >= 16 * 16 * 256) launch3<TIn, TOut, 16, 32>(p, st);
     else if (pix >= 8 * 16 * 256) launch3<TIn, TOut, 8, 32>(p, st);
     else launch3<TIn, TOut, 4, 32>(p, st);
   } else if (p.Cin * (int)sizeof(TIn) > 128) {

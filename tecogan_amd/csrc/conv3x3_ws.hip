@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
       const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
       const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
       const int x = tx * 16 + frow;
+      unsigned offs[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = ty * WS_TH + wm * 4 + i;
@@ -209,7 +210,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int co = cbase + j * 16 + fg * 4;
-          const unsigned off = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : WS_OOB;
+          offs[i][j] = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : WS_OOB;
+        }
+      }
+      // all residual / mask vectors of the tile in flight at once (8 + 8 loads), then the arithmetic: one exposed round
+      // trip per tile instead of one per accumulator (the residual form ran 23.3 us against 17.6 us without)
+      u32x2w rr[HAS_RES ? 4 : 1][2], aa[HAS_AUX ? 4 : 1][2];
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
+      }
+      if constexpr (HAS_AUX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -217,23 +239,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
             v[r] = fmaxf(v[r], v[r] * p.nslope);
           }
           if constexpr (HAS_RES) {
-            const u32x2w rr = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)off, 0, 0);
-            v[0] += __uint_as_float(rr.x << 16);
-            v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16);
-            v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            v[0] += __uint_as_float(rr[i][j].x << 16);
+            v[1] += __uint_as_float(rr[i][j].x & 0xffff0000u);
+            v[2] += __uint_as_float(rr[i][j].y << 16);
+            v[3] += __uint_as_float(rr[i][j].y & 0xffff0000u);
           }
           if constexpr (HAS_AUX) {
-            const u32x2w aa = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)off, 0, 0);
-            v[0] *= __uint_as_float(aa.x << 16) > 0.f ? 1.f : p.mslope;
-            v[1] *= __uint_as_float(aa.x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
-            v[2] *= __uint_as_float(aa.y << 16) > 0.f ? 1.f : p.mslope;
-            v[3] *= __uint_as_float(aa.y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+            v[0] *= __uint_as_float(aa[i][j].x << 16) > 0.f ? 1.f : p.mslope;
+            v[1] *= __uint_as_float(aa[i][j].x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+            v[2] *= __uint_as_float(aa[i][j].y << 16) > 0.f ? 1.f : p.mslope;
+            v[3] *= __uint_as_float(aa[i][j].y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
           }
           u32x2w o;
           o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
           o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)offs[i][j], 0, 0);
         }
       }
     }

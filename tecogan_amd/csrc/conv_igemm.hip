@@ -347,7 +347,7 @@ static void launch_cfg(const ConvP& p, int nphase, int mq_max, hipStream_t st) {
 }
 
 template <typename TIn, typename TOut>
-static void launch_typed(const ConvP& p, int nphase, int mq_max, hipStream_t st) {
+static void launch_typed(const ConvP& p, int nphase, int mq_max, hipStream_t st, bool coexist) {
   const int64_t M = mq_max;
   if (p.Cout <= 16) {
     if (M * nphase >= 128 * 512) launch_cfg<TIn, TOut, 4, 1, 2, 1>(p, nphase, mq_max, st);
@@ -357,7 +357,9 @@ static void launch_typed(const ConvP& p, int nphase, int mq_max, hipStream_t st)
     else launch_cfg<TIn, TOut, 4, 1, 1, 2>(p, nphase, mq_max, st);
   } else {
     const int64_t ntile = (p.Cout + 63) / 64;
-    if (M * nphase * ntile >= (int64_t)128 * 512) launch_cfg<TIn, TOut, 2, 2, 4, 2>(p, nphase, mq_max, st);
+    // TG_CONV_COEXIST: the 128-row tile (56 KB LDS, 132 registers) does not fit beside a resident <8,64> 3x3 workgroup
+    // (109 KB); the 64-row tile (37 KB) does
+    if (!coexist && M * nphase * ntile >= (int64_t)128 * 512) launch_cfg<TIn, TOut, 2, 2, 4, 2>(p, nphase, mq_max, st);
     else if (M * nphase * ntile >= (int64_t)64 * 512) launch_cfg<TIn, TOut, 2, 2, 2, 2>(p, nphase, mq_max, st);
     else launch_cfg<TIn, TOut, 2, 2, 1, 2>(p, nphase, mq_max, st);
   }
@@ -408,8 +410,9 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
     mq_max = d->N * ((d->Hout + d->stride - 1) / d->stride) * ((d->Wout + d->stride - 1) / d->stride);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (d->in_dtype == TG_F32) launch_typed<float, float>(p, nphase, mq_max, st);
-  else if (d->out_dtype == TG_BF16) launch_typed<u16, u16>(p, nphase, mq_max, st);
-  else launch_typed<u16, float>(p, nphase, mq_max, st);
+  const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;
+  if (d->in_dtype == TG_F32) launch_typed<float, float>(p, nphase, mq_max, st, coexist);
+  else if (d->out_dtype == TG_BF16) launch_typed<u16, u16>(p, nphase, mq_max, st, coexist);
+  else launch_typed<u16, float>(p, nphase, mq_max, st, coexist);
   TG_CHECK_LAUNCH();
 }

@@ -289,6 +289,27 @@ __global__ __launch_bounds__(256) void bicubic_add_kernel(const float* __restric
 // depend on Y & 3 only); conv_out arrives and the frame leaves as 3 x 16-byte vectors.  Optionally also writes the
 // deprocessed frame (x + 1) / 2 -- the recurrent state of the inference loop (main.py:207) -- so that pass disappears.
 // Same operation order as the per-pixel kernel: rows first, then columns (lib/ops.py:190-210).
+// the three colour channels of one LR pixel with ONE load (the row stride is Cpad elements: a scalar load per channel made
+// every lane touch its own cache line three times -- the kernel was bound by line requests, 62 us at 1080p)
+__device__ __forceinline__ void ld_rgb(const u16* __restrict__ p, bool vec, float (&v)[3]) {
+  if (vec) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(q.x << 16);
+    v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16);
+  } else {
+    v[0] = bf2f(p[0]); v[1] = bf2f(p[1]); v[2] = bf2f(p[2]);
+  }
+}
+__device__ __forceinline__ void ld_rgb(const float* __restrict__ p, bool vec, float (&v)[3]) {
+  if (vec) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z;
+  } else {
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+  }
+}
+
 template <typename TI>
 __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __restrict__ conv_out,
                                                                const TI* __restrict__ gen_in, int Cpad,
@@ -307,14 +328,13 @@ __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __re
       rx[k] = min(max(j + k - 1, 0), w - 1);
     }
     const TI* __restrict__ base = gen_in + (int64_t)b * h * w * Cpad;
+    const bool vec = Cpad >= 4 && (Cpad * (int)sizeof(TI)) % (4 * (int)sizeof(TI)) == 0 && (((uintptr_t)gen_in) & 15) == 0;
     float col[4][3];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float p[4][3];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) p[m][c] = Elem<TI>::ld(base + ((int64_t)ry[m] * w + rx[k]) * Cpad + c);
+      for (int m = 0; m < 4; ++m) ld_rgb(base + ((int64_t)ry[m] * w + rx[k]) * Cpad, vec, p[m]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[k][c] = wy[0] * p[0][c] + wy[1] * p[1][c] + wy[2] * p[2][c] + wy[3] * p[3][c];
     }

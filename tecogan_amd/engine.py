@@ -104,6 +104,11 @@ class TrainEngine:
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
         uses_side = (self.use_vgg and self.ov_parts & 5) or (gan and self.ov_parts & 10)
         self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
+        # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
+        # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
+        # and each such node would wait for a CU to drain (~50 us, 27 + 19 nodes per step)
+        if uses_side and os.environ.get("TG_CHAIN_COEXIST", "1") != "0":
+            self.G.chain_flags = K.CONV_COEXIST
 
     # ------------------------------------------------------------------------------------------
     def set_batch(self, r_inputs, r_targets):

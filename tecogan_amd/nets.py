@@ -71,25 +71,25 @@ def conv_wgrad(ps, wname, bname, x, dy, stride=1, flags=0):
     K.conv_wgrad(d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, ldx=Cp, ldy=Co)
 
 
-def deconv_fwd(ps, wname, bname, x, act=ACT_NONE, alpha=0.0, out=None):
+def deconv_fwd(ps, wname, bname, x, act=ACT_NONE, alpha=0.0, out=None, flags=0):
     """slim.conv2d_transpose k3 s2 SAME (reference lib/ops.py:35-44, [TF1] A.2): transposed mode, pad 0."""
     e = ps.entries[wname]                      # TF layout [kh,kw,Cout,Cin] -> A = Cout, B = Cin
     N, H, W, Ci = x.shape
     k = e["k"]
     if out is None:
         out = _empty((N, 2 * H, 2 * W, e["A"]), ps.act_dtype, x)
-    d = K.conv_desc(N, H, W, Ci, 2 * H, 2 * W, e["A"], k, k, 2, 0, 0, 1, K.dt(x), K.dt(out), act, alpha)
+    d = K.conv_desc(N, H, W, Ci, 2 * H, 2 * W, e["A"], k, k, 2, 0, 0, 1, K.dt(x), K.dt(out), act, alpha, flags=flags)
     K.conv_forward(d, x, ps.packed(wname, False), ps.view(bname), None, None, out)
     return out
 
 
-def deconv_bwd_data(ps, wname, dy, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, out=None):
+def deconv_bwd_data(ps, wname, dy, aux=None, mask_act=ACT_NONE, mask_alpha=0.0, out=None, flags=0):
     e = ps.entries[wname]
     N, H2, W2, Co = dy.shape
     k = e["k"]
     dx = _empty((N, H2 // 2, W2 // 2, e["B"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, H2, W2, Co, H2 // 2, W2 // 2, e["B"], k, k, 2, 0, 0, 0, K.dt(dy), K.dt(dx), 0, 0.0,
-                    mask_act, mask_alpha)
+                    mask_act, mask_alpha, flags=flags)
     K.conv_forward(d, dy, ps.packed(wname, True), None, None, aux, dx)
     return dx
 
@@ -131,6 +131,10 @@ class Generator:
         # one grouped weight-gradient launch for all res-block convs; TG_WGRAD_GROUPED=0 is the A/B switch
         # (FRVSR step 4.25 -> 3.91 ms in the same session, profiles/r01o_grouped_wgrad_ab.txt)
         self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "1") == "1"
+        # scheduling hint for the recurrence's own launches (forward_t / backward_t): K.CONV_COEXIST when throughput work
+        # of another stream shares the chip, so that the chain's bigger launches (HR deconv, output conv) also pick tile
+        # shapes that fit NEXT to a resident VGG workgroup instead of waiting for a CU to drain
+        self.chain_flags = 0
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -183,8 +187,9 @@ class Generator:
         """Frame t: reads seq['x_in'][t] (filled by the warp kernel), writes the HR frame into `out`."""
         ps, p, q = self.ps, self.P, self.seq
         x_in = q["x_in"][t]
+        cf = self.chain_flags
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
-                     out=q["a"][0][t])
+                     out=q["a"][0][t], flags=cf)
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
             if self.fused:          # one launch per residual block (csrc/resblock.hip)
@@ -192,13 +197,14 @@ class Generator:
                                      None, q["r"][i][t], ps.packed(s + "conv_2/Conv/weights", True),
                                      ps.view(s + "conv_2/Conv/biases"), None, q["a"][i][t], flip=False, relu1=True)
                 continue
-            r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t])
+            r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t], flags=cf)
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
-                         out=q["a"][i][t])
+                         out=q["a"][i][t], flags=cf)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
-        t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU, out=q["t1"][t])
-        t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU, out=q["t2"][t])
-        c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1, out=q["c"])
+        t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU, out=q["t1"][t], flags=cf)
+        t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU, out=q["t2"][t], flags=cf)
+        c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1, out=q["c"],
+                     flags=cf)
         return K.bicubic_add_preprocess(c, x_in, out)
 
     def backward_t(self, t, d_out, need_dx=True):
@@ -206,11 +212,12 @@ class Generator:
         ps, p, q, n = self.ps, self.P, self.seq, self.nres
         h, w = q["h"], q["w"]
         dc = K.concat2_pad(d_out, None, q["g_out"][t], scale=2.0)                              # d/dc of (.)*2-1
+        cf = self.chain_flags
         g = conv_bwd_data(ps, p + "output_stage/conv/Conv/weights", dc, (4 * h, 4 * w), 1, aux=q["t2"][t],
-                          mask_act=ACT_RELU, out=q["g_t2"][t])
+                          mask_act=ACT_RELU, out=q["g_t2"][t], flags=cf)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
-        g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=q["t1"][t], mask_act=ACT_RELU, out=q["g_t1"][t])
-        g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t])
+        g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=q["t1"][t], mask_act=ACT_RELU, out=q["g_t1"][t], flags=cf)
+        g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t], flags=cf)
         if n == 0:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
         for i in range(n, 0, -1):
@@ -222,14 +229,14 @@ class Generator:
                                      q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], flip=True, relu1=False)
                 continue
             dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
-                               out=q["g_c1"][i][t])
+                               out=q["g_c1"][i][t], flags=cf)
             # d a_{i-1} = bwd(conv_1)(dr) + skip gradient; block 1's input is itself a ReLU output (masked here)
             g = conv_bwd_data(ps, sc + "conv_1/Conv/weights", dr, (h, w), 1, res=g,
                               aux=q["a"][0][t] if i == 1 else None, mask_act=ACT_RELU if i == 1 else ACT_NONE,
-                              out=q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t])
+                              out=q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], flags=cf)
         if not need_dx:
             return None
-        return conv_bwd_data(ps, p + "input_stage/conv/Conv/weights", g, (h, w), 1, out=q["dx_in"])
+        return conv_bwd_data(ps, p + "input_stage/conv/Conv/weights", g, (h, w), 1, out=q["dx_in"], flags=cf)
 
     def wgrad_sequence(self, t0=0, t1=None, flags=0):
         """Weight / bias gradients of frames [t0, t1): one launch per layer over the (t1-t0)*B frames.

@@ -152,3 +152,78 @@ def test_network_shapes_and_inference_padding():
     assert out.shape == (1, 72, 80, 3)
     flow = ON.fnet(P, torch.rand(1, 18, 20, 6))
     assert flow.shape == (1, 16, 16, 2) and flow.abs().max() <= 24.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Value tables of TensorFlow's OWN unit tests for the ops whose semantics live inside TF ("parity unpinned").
+# There is no network in this environment, so the tables below are TRANSCRIBED FROM MEMORY of the TF 1.x sources named in
+# each docstring (no commit hash can be given); each one is also re-derived from the TF1 rule it exercises in the comment
+# next to it, so a mis-remembered number would show up as an inconsistency here, not as a silently wrong oracle.
+# They pin the oracle to TensorFlow's documented behaviour harder than closed forms alone; they do not replace a run of
+# real TensorFlow.
+# ---------------------------------------------------------------------------------------------------------
+def test_tf_resize_bilinear_legacy_table():
+    """tensorflow/python/ops/image_ops_test.py, ResizeImagesTest.testResizeUp (align_corners=False, BILINEAR): a 3x2 image
+    [[64,32],[32,64],[50,100]] resized to 6x4.  Legacy rule: src = dst * in/out (no half-pixel), hi = min(lo+1, in-1)."""
+    x = torch.tensor([64., 32., 32., 64., 50., 100.]).reshape(1, 3, 2, 1)
+    want = torch.tensor([64.0, 48.0, 32.0, 32.0,
+                         48.0, 48.0, 48.0, 48.0,
+                         32.0, 48.0, 64.0, 64.0,
+                         41.0, 61.5, 82.0, 82.0,
+                         50.0, 75.0, 100.0, 100.0,
+                         50.0, 75.0, 100.0, 100.0]).reshape(1, 6, 4, 1)
+    assert torch.equal(O.resize_bilinear_legacy(x, 6, 4), want)
+    # the x2 special case the FNet decoder uses (lib/frvsr.py:21-22) is the same function
+    assert torch.equal(O.upsample2_legacy(x), O.resize_bilinear_legacy(x, 6, 4))
+
+
+def test_tf_conv2d_transpose_same_stride2_table():
+    """tensorflow/python/kernel_tests/conv2d_transpose_test.py, testConv2DTransposeSame: ones input [1,6,4,3], ones filter
+    [3,3,2,3] ([kh,kw,Cout,Cin]), strides 2, SAME, output [1,12,8,2].  Expected: 3.0 everywhere, +3.0 where exactly one of
+    (h, w) is an even index > 0, +9.0 where both are -- i.e. 3 * c(h) * c(w) with c = 2 on even positions > 0, else 1:
+    output position 2i+k receives input i through tap k in {0,1,2}, so even positions > 0 collect two taps, position 0 and
+    odd positions one.  (torch's padding=1/output_padding=1 alignment would give the two-tap count to ODD positions.)"""
+    x = torch.ones(1, 6, 4, 3)
+    w = torch.ones(3, 3, 2, 3)
+    y = O.conv2_tran(x, w, None, 2)
+    assert tuple(y.shape) == (1, 12, 8, 2)
+    want = torch.empty(12, 8)
+    for h in range(12):
+        for v in range(8):
+            h_in = h % 2 == 0 and h > 0
+            w_in = v % 2 == 0 and v > 0
+            want[h, v] = 3.0 + (9.0 if (h_in and w_in) else (3.0 if (h_in or w_in) else 0.0))
+    assert torch.equal(y[0, :, :, 0], want) and torch.equal(y[0, :, :, 1], want)
+
+
+def test_tf_interpolate_bilinear_small_grid_table():
+    """tensorflow/contrib/image/python/kernel_tests/dense_image_warp_test.py, test_interpolate_small_grid_ij: grid
+    [[0,1,2],[3,4,5],[6,7,8]], query points (0,0), (1,0), (2,0.5), (1.5,1.5) -> 0, 3, 6.5, 6.  dense_image_warp queries
+    (y - flow_y, x - flow_x), floors clamped to [0, size-2], alphas clamped to [0,1]."""
+    img = torch.arange(9.).reshape(1, 3, 3, 1)
+    flow = torch.zeros(1, 3, 3, 2)
+    flow[0, 2, 1] = torch.tensor([0.0, 0.5])          # pixel (2,1) queries (2, 0.5)
+    flow[0, 1, 1] = torch.tensor([-0.5, -0.5])        # pixel (1,1) queries (1.5, 1.5)
+    out = O.dense_image_warp(img, flow)
+    assert out[0, 0, 0, 0].item() == 0.0 and out[0, 1, 0, 0].item() == 3.0
+    assert out[0, 2, 1, 0].item() == 6.5 and out[0, 1, 1, 0].item() == 6.0
+
+
+def test_tf_adam_numpy_reference_three_steps():
+    """tensorflow/python/training/adam_test.py (adam_update_numpy): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m, v exponential
+    averages; param -= lr_t * m / (sqrt(v) + eps); var0 = [1,2], grads0 = [0.1,0.1], var1 = [3,4], grads1 = [0.01,0.01],
+    lr 0.001, 3 steps."""
+    import math
+    for var, grad in (([1.0, 2.0], [0.1, 0.1]), ([3.0, 4.0], [0.01, 0.01])):
+        p = torch.tensor(var, dtype=torch.float64)
+        g = torch.tensor(grad, dtype=torch.float64)
+        m, v = torch.zeros(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)
+        pn, mn, vn = list(var), [0.0, 0.0], [0.0, 0.0]
+        for t in (1, 2, 3):
+            O.adam_tf_step(p, g, m, v, t, 0.001, 0.9, 0.999, 1e-8)
+            lr_t = 0.001 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            for i in range(2):
+                mn[i] = 0.9 * mn[i] + 0.1 * grad[i]
+                vn[i] = 0.999 * vn[i] + 0.001 * grad[i] * grad[i]
+                pn[i] -= lr_t * mn[i] / (math.sqrt(vn[i]) + 1e-8)
+        assert torch.allclose(p, torch.tensor(pn, dtype=torch.float64), rtol=1e-12, atol=0)

@@ -6,8 +6,12 @@ kernel names (tools/knames.py), per launch:
                                                      64 MiB-in streaming kernel when the run contains tg lincomb launches)
     write_bytes  = WRITE_SIZE [KiB] * 1024
     hbm_bytes_per_launch = fetch_bytes + write_bytes
-    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 * 256)    (cycles some SIMD's matrix pipe was busy,
-                                                     summed over the chip's 1024 SIMDs, over the cycles the GPU was active)
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)
+        SQ_VALU_MFMA_BUSY_CYCLES is the sum over all MFMA instructions of their pipe cycles (calibrated: the chain kernel
+        <4,16> at [4,32,32,64->64] issues 256 WG x 4 waves x 18 v_mfma_f32_16x16x32_bf16 = 18432 instructions x 16 cycles
+        = 294912, exactly the counter's value); GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 = SIMDs of the chip.
+        For kernels of a few microseconds GUI_ACTIVE also holds the profiler's serialisation gaps (the fraction is a lower
+        bound there).
 Counters come from SEPARATE passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with trace domains).
 
     python tools/pmc_summary.py --json profiles/r02_pmc.json <dir-or-csv> [...]
@@ -59,7 +63,7 @@ def main(argv):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACTIVE"] > 0:
             e["raw_SQ_VALU_MFMA_BUSY_CYCLES"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"], 1)
             e["raw_GRBM_GUI_ACTIVE"] = round(mean["GRBM_GUI_ACTIVE"], 1)
-            e["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] * 4 * 256), 5)
+            e["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 5)
         for c in ("SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU_MFMA_MOPS_BF16"):
             if c in mean:
                 e["raw_" + c] = round(mean[c], 1)
