@@ -275,6 +275,188 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Transposed 3x3 stride-2 SAME convolution (slim.conv2d_transpose, reference lib/ops.py:35-44 as used by the generator's
+// conv_tran2highres stage, lib/frvsr.py:73-78) in the same weights-in-registers / LDS-DMA scheme, for the throughput
+// regime (the 1080p inference step: [1,270,480,64] -> [1,540,960,64] -> [1,1080,1920,64], 0.26 ms of a 1.44 ms frame on
+// the generic engine).  TF alignment ([TF1] SURVEY A.2): y[2i+ky, 2j+kx] += x[i,j] . w[ky,kx], so the four output phases
+// of input pixel (i,j) are small stride-1 convolutions over x with NO zero MACs:
+//     out(2i  ,2j  ) = x[i,j] w00 + x[i,j-1] w02 + x[i-1,j] w20 + x[i-1,j-1] w22        (4 taps)
+//     out(2i  ,2j+1) = x[i,j] w01 + x[i-1,j] w21                                         (2 taps)
+//     out(2i+1,2j  ) = x[i,j] w10 + x[i,j-1] w12                                         (2 taps)
+//     out(2i+1,2j+1) = x[i,j] w11                                                        (1 tap)
+// A tile is 8 x 16 INPUT pixels (+ one halo row / column up-left; the conv's (8+2) x 18 halo tile is reused) and
+// 16 x 32 output pixels; per wave 144 MFMAs per tile as in the conv, four register epilogues (bias + ReLU, 8-byte stores).
+__global__ __launch_bounds__(256, 2) void deconv3x3s2_ws_kernel(ConvWsP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int cbase = blockIdx.y * 64 + wn * 32;
+  const int row_bytes = p.Cin * 2;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  const auto rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+
+  int code[WS_KPW];
+#pragma unroll
+  for (int k = 0; k < WS_KPW; ++k) {
+    const int S = (wave + 4 * k) * 64 + lane;
+    const int pix = S / 9, c = S - 9 * pix;
+    const int dy = pix / 18, dx = pix - 18 * dy;
+    const bool valid = S < WS_SLOTS && c * 8 < p.Cin;
+    code[k] = dy | (dx << 8) | (c << 16) | (valid ? (1 << 24) : 0);
+  }
+  auto issue_dma = [&](int tile, int buf) {
+    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+    const int y0 = ty * WS_TH - 1, x0 = tx * 16 - 1;
+    const int base = ((n * p.H + y0) * p.W + x0) * row_bytes;
+#pragma unroll
+    for (int k = 0; k < WS_KPW; ++k) {
+      const int inst = wave + 4 * k;
+      if (4 * k + 3 < WS_NDMA || inst < WS_NDMA) {
+        const int dy = code[k] & 255, dx = (code[k] >> 8) & 255, c = (code[k] >> 16) & 255;
+        const bool ok = (code[k] >> 24) && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)(base + (dy * p.W + dx) * row_bytes + c * 16) : WS_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(smem + buf * WS_BUF + inst * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.ntiles) return;
+  issue_dma(tile, 0);
+  u32x4w wf[9][2][2];                                        // [ky*3+kx][K-step][channel group], TF layout [kh,kw,Cout,Cin]
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
+        const bool ok = co < p.Cout && ci < p.Cin;
+        wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcW, (int)(ok ? (unsigned)(((tap * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
+      }
+  float bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cbase + j * 16 + fg * 4 + r;
+      bv[j][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int buf = 0;
+  const int Ho = 2 * p.H, Wo = 2 * p.W;
+  while (true) {
+    const int ntile = tile + gridDim.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ntile < p.ntiles) issue_dma(ntile, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // halo pixel of input (row i, column frow) of this wave: row wm*4 + i + 1, column frow + 1; "up" / "left" = -1
+    const unsigned char* Afrag = smem + buf * WS_BUF + ((wm * 4) * 18 + frow) * WS_ROWB + fg * 16;
+    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+    const int xin = tx * 16 + frow;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int dyi = 0; dyi < (py ? 1 : 2); ++dyi)          // phase row 0 also sees the input row above (ky = 2)
+#pragma unroll
+            for (int dxi = 0; dxi < (px ? 1 : 2); ++dxi) {      // phase column 0 also sees the input column to the left (kx = 2)
+              const int ky = py ? 1 : 2 * dyi, kx = px ? 1 : 2 * dxi;
+              u32x4w af[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                af[i] = *reinterpret_cast<const u32x4w*>(Afrag + ((i + 1 - dyi) * 18 + 1 - dxi) * WS_ROWB + kk * 64);
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ky * 3 + kx][kk][j]),
+                                                                      __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+            }
+        const int xo = 2 * xin + px;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int yin = ty * WS_TH + wm * 4 + i;
+          const int yo = 2 * yin + py;
+          const bool pok = yin < p.H && xin < p.W;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int co = cbase + j * 16 + fg * 4;
+            const unsigned off = (pok && co < p.Cout) ? (unsigned)((((n * Ho + yo) * Wo + xo) * p.Cout + co) * 2) : WS_OOB;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[i][j][r] + bv[j][r];
+              v[r] = fmaxf(v[r], v[r] * p.nslope);
+            }
+            u32x2w o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)off, 0, 0);
+          }
+        }
+      }
+    tile = ntile;
+    if (tile >= p.ntiles) break;
+    buf ^= 1;
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");       // the next tile's DMA has landed; the 32 stores may still fly
+  }
+}
+
+// Returns 1 if handled (bf16, Cin <= 64, Cout % 64 == 0, k3 s2 pad 0 transposed, >= 256 input tiles), else 0.
+int tg_deconv3x3s2_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                          const void* aux, void* out, hipStream_t st) {
+  static const bool enabled = getenv("TG_NO_DECONV_WS") == nullptr;         // A/B switch
+  if (!enabled || d->mode != 1 || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad_t != 0 || d->pad_l != 0) return 0;
+  if (d->Hout != 2 * d->Hin || d->Wout != 2 * d->Win || res || aux) return 0;
+  if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16 || d->act >= TG_ACT_TANH) return 0;
+  if (d->Cin % 8 != 0 || d->Cin > 64 || d->Cin < 16 || d->Cout % 64 != 0) return 0;
+  if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out) & 15)) return 0;
+  const int64_t px = (int64_t)d->N * d->Hin * d->Win;
+  const int64_t in_bytes = px * d->Cin * 2, out_bytes = 4 * px * d->Cout * 2, w_bytes = (int64_t)9 * d->Cout * d->Cin * 2;
+  if (in_bytes >= ((int64_t)1 << 31) || out_bytes >= ((int64_t)1 << 31)) return 0;
+  ConvWsP p;
+  p.in = in; p.w = weight; p.bias = bias; p.res = nullptr; p.aux = nullptr; p.out = out;
+  p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
+  p.flip = 0;
+  p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
+  p.mslope = 1.f;
+  p.tiles_y = (p.H + WS_TH - 1) / WS_TH;
+  p.tiles_x = (p.W + 15) / 16;
+  const int64_t ntiles = (int64_t)p.N * p.tiles_y * p.tiles_x;
+  if (ntiles < 256 || ntiles >= ((int64_t)1 << 30)) return 0;
+  p.ntiles = (int)ntiles;
+  p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
+  constexpr int LDS = 2 * WS_BUF;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3x3s2_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  const int nt = p.Cout / 64;
+  int gx = p.ntiles;
+  const int cap = 512 / nt > 0 ? 512 / nt : 1;
+  if (gx > cap) gx = cap;
+  TG_LAUNCH("deconv3x3s2_ws", 2.0 * (double)px * 9.0 * p.Cin * p.Cout, (double)px * (p.Cin * 2.0 + 4.0 * p.Cout * 2.0) + 18.0 * p.Cin * p.Cout,
+            deconv3x3s2_ws_kernel, dim3(gx, nt), dim3(256), LDS, st, p);
+  return 1;
+}
+
 template <bool HAS_RES, bool HAS_AUX>
 static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   auto kern = conv3x3_ws_kernel<HAS_RES, HAS_AUX>;

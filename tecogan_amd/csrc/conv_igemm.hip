@@ -325,6 +325,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   else epilogue(std::true_type{}, std::false_type{});
 }
 
+int tg_deconv3x3s2_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                          const void* aux, void* out, hipStream_t st);      // conv3x3_ws.hip
+
 template <typename TIn, typename TOut, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvP& p, int nphase, int mq_max, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -383,6 +386,7 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   hipStream_t st0 = static_cast<hipStream_t>(stream);
   static const bool use_tile3 = getenv("TG_NO_CONV3X3") == nullptr;      // A/B switch for profiling
   if (use_tile3 && tg_conv3x3_try(d, in, weight, bias, res, aux, out, st0)) TG_CHECK_LAUNCH();
+  if (tg_deconv3x3s2_ws_try(d, in, weight, bias, res, aux, out, st0)) TG_CHECK_LAUNCH();
   ConvP p;
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin;

@@ -945,3 +945,24 @@ def test_conv3x3_packed_narrow_images(case):
     assert ents and "pack" in ents[0]["name"], "the packed-tile instantiation was not selected: %s" % ents
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 3e-2).all(), "%s: max err %g" % (case, err.max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 270, 480, 64, 64), (2, 128, 128, 32, 64), (1, 133, 245, 64, 128)])
+def test_deconv3x3s2_weights_in_registers_kernel(case):
+    """slim.conv2d_transpose k3 s2 SAME (lib/ops.py:35-44) + bias + ReLU in the throughput regime: the four output phases as
+    stride-1 sub-convolutions with the weights in registers (conv3x3_ws.hip), against the oracle's TF-aligned conv2_tran."""
+    N, H, W, Cin, Cout = case
+    x = rnd(N, H, W, Cin, seed=1).bfloat16()
+    w = rnd(3, 3, Cout, Cin, seed=2, scale=0.1).bfloat16()               # TF layout [kh,kw,Cout,Cin]
+    b = rnd(Cout, seed=3)
+    ref = torch.relu(O.conv2_tran(x.float(), w.float(), b, 2))
+    out = torch.full((N, 2 * H, 2 * W, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
+    d = K.conv_desc(N, H, W, Cin, 2 * H, 2 * W, Cout, 3, 3, 2, 0, 0, 1, TG_BF16, TG_BF16, ACT_RELU)
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_forward(d, x.to(DEV), w.reshape(9, Cout, Cin).contiguous().to(DEV), b.to(DEV), None, None, out)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"] == "deconv3x3s2_ws", ents
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 8e-3 * ref.abs() + 2e-2).all(), "%s: max err %g" % (case, err.max().item())
