@@ -472,7 +472,11 @@ static void launch3_typed(const Conv3P& p, hipStream_t st, bool coexist) {
   if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
     // narrow images: several per tile row (A/B switch TG_NO_C3_PACK=1)
     static const bool no_pack = getenv("TG_NO_C3_PACK") != nullptr;
-    if (!no_pack && !p.direct_epi && p.W <= 8 && p.N >= 2 && (p.Cout & 7) == 0 && p.Cout >= 64 && !(force && p.Cout > 32)) {
+    // ... once the layer is big enough to fill the chip anyway (pixels x channel tiles >= 16k: VGG conv5, the 72-pair
+    // FNet of the TecoGAN step); below that the packed tiling only cuts the workgroup count of a latency-bound launch
+    // (FRVSR step 3.96 -> 4.06 ms with packing everywhere)
+    if (!no_pack && !p.direct_epi && p.W <= 8 && p.N >= 2 && (p.Cout & 7) == 0 && p.Cout >= 64 && !(force && p.Cout > 32) &&
+        pix * nt64 >= 16384) {
       if (p.W <= 4 && p.N >= 4) return launch3<TIn, TOut, 4, 64, 0, 4>(p, st);
       if (p.H <= 4) return launch3<TIn, TOut, 4, 64, 0, 2>(p, st);
       return launch3<TIn, TOut, 8, 64, 0, 2>(p, st);

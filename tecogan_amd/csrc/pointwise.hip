@@ -291,8 +291,9 @@ __global__ __launch_bounds__(256) void bicubic_add_kernel(const float* __restric
 // Same operation order as the per-pixel kernel: rows first, then columns (lib/ops.py:190-210).
 // the three colour channels of one LR pixel with ONE load (the row stride is Cpad elements: a scalar load per channel made
 // every lane touch its own cache line three times -- the kernel was bound by line requests, 62 us at 1080p)
-__device__ __forceinline__ void ld_rgb(const u16* __restrict__ p, bool vec, float (&v)[3]) {
-  if (vec) {
+template <bool VEC>
+__device__ __forceinline__ void ld_rgb(const u16* __restrict__ p, float (&v)[3]) {
+  if constexpr (VEC) {
     const uint2 q = *reinterpret_cast<const uint2*>(p);
     v[0] = __uint_as_float(q.x << 16);
     v[1] = __uint_as_float(q.x & 0xffff0000u);
@@ -301,8 +302,9 @@ __device__ __forceinline__ void ld_rgb(const u16* __restrict__ p, bool vec, floa
     v[0] = bf2f(p[0]); v[1] = bf2f(p[1]); v[2] = bf2f(p[2]);
   }
 }
-__device__ __forceinline__ void ld_rgb(const float* __restrict__ p, bool vec, float (&v)[3]) {
-  if (vec) {
+template <bool VEC>
+__device__ __forceinline__ void ld_rgb(const float* __restrict__ p, float (&v)[3]) {
+  if constexpr (VEC) {
     const float4 q = *reinterpret_cast<const float4*>(p);
     v[0] = q.x; v[1] = q.y; v[2] = q.z;
   } else {
@@ -310,7 +312,9 @@ __device__ __forceinline__ void ld_rgb(const float* __restrict__ p, bool vec, fl
   }
 }
 
-template <typename TI>
+// VEC is a TEMPLATE parameter on purpose: as a run-time flag it put a branch around each of the 16 loads and hipcc waited
+// vmcnt(0) per load -- 16 dependent round trips, 95 us instead of 62 (the trap of cdna_hip_programming.md section 5, item 4c).
+template <typename TI, bool VEC>
 __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __restrict__ conv_out,
                                                                const TI* __restrict__ gen_in, int Cpad,
                                                                float* __restrict__ out, float* __restrict__ state, int B,
@@ -328,13 +332,12 @@ __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __re
       rx[k] = min(max(j + k - 1, 0), w - 1);
     }
     const TI* __restrict__ base = gen_in + (int64_t)b * h * w * Cpad;
-    const bool vec = Cpad >= 4 && (Cpad * (int)sizeof(TI)) % (4 * (int)sizeof(TI)) == 0 && (((uintptr_t)gen_in) & 15) == 0;
     float col[4][3];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float p[4][3];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) ld_rgb(base + ((int64_t)ry[m] * w + rx[k]) * Cpad, vec, p[m]);
+      for (int m = 0; m < 4; ++m) ld_rgb<VEC>(base + ((int64_t)ry[m] * w + rx[k]) * Cpad, p[m]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[k][c] = wy[0] * p[0][c] + wy[1] * p[1][c] + wy[2] * p[2][c] + wy[3] * p[3][c];
     }
@@ -809,12 +812,15 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
   if (!no_quad && ((((uintptr_t)conv_out | (uintptr_t)out | (uintptr_t)state)) & 15) == 0 &&
       (int64_t)B * h * w * 4 < ((int64_t)1 << 31)) {
     dim3 gq(grid_1d((int64_t)B * h * w * 4, 256, 1 << 20));
-    if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add_quad<f32>", 0, by, (bicubic_add_quad_kernel<float>), gq, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, state, B, h, w);
-    else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add_quad<bf16>", 0, by, (bicubic_add_quad_kernel<u16>), gq, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, state, B, h, w);
+    const bool vec = Cpad >= 4 && Cpad % 4 == 0 && (((uintptr_t)gen_in) & 15) == 0;      // one 8 / 16-byte load per LR pixel
+    if (in_dtype == TG_F32 && vec) TG_LAUNCH("bicubic_add_quad<f32>", 0, by, (bicubic_add_quad_kernel<float, true>), gq, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, state, B, h, w);
+    else if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add_quad<f32>", 0, by, (bicubic_add_quad_kernel<float, false>), gq, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, state, B, h, w);
+    else if (in_dtype == TG_BF16 && vec) TG_LAUNCH("bicubic_add_quad<bf16>", 0, by, (bicubic_add_quad_kernel<u16, true>), gq, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, state, B, h, w);
+    else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add_quad<bf16>", 0, by, (bicubic_add_quad_kernel<u16, false>), gq, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, state, B, h, w);
     else TG_CHECK_ARG(false, "bad dtype");
     TG_CHECK_LAUNCH();
   }
-  TG_CHECK_ARG(out != nullptr && state == nullptr, "the per-pixel fallback writes `out` only");
+  TG_CHECK_ARG(out != nullptr && state == nullptr, "the per-pixel fallback (TG_NO_BICUBIC_QUAD) writes `out` only");
   if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add<f32>", 0, by, (bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
   else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add<bf16>", 0, by, (bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
   else TG_CHECK_ARG(false, "bad dtype");

@@ -25,6 +25,16 @@ LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_
 LI = {n: i for i, n in enumerate(LOSS_NAMES)}
 
 
+class _Shifted:
+    """`x[t0:t1]` of a tensor whose first frame is frame `base` of the sequence (scratch buffers of a frame range)."""
+
+    def __init__(self, t, base):
+        self.t, self.base = t, base
+
+    def __getitem__(self, sl):
+        return self.t[sl.start - self.base:sl.stop - self.base]
+
+
 class TrainEngine:
     def __init__(self, flags, device="cuda", gan=True, act_dtype=torch.float32, seed=42, process_group=None,
                  use_graph=True):
@@ -86,7 +96,7 @@ class TrainEngine:
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
         self._pools = {}
-        self._done, self._mode, self._main, self._d_vgg = {}, "flat", None, None
+        self._done, self._mode, self._main, self._d_vgg, self._d_vgg_mid = {}, "flat", None, None, None
         # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
         self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
         self.host_step = 0
@@ -95,14 +105,15 @@ class TrainEngine:
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
-        # frames, 8 D's own-gradient passes.  (Generator weight gradients of finished frames beside the BPTT were measured
-        # a loss twice -- 6.16 vs 6.00 ms in round 1, 4.35 vs 3.73 ms FRVSR with capped residency -- and are gone.)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "15")) & 15) if self.overlap else 0
+        # frames, 8 D's own-gradient passes, 16 VGG pass of the middle frames beside the first part of the BPTT.  (Generator
+        # weight gradients of finished frames beside the BPTT were measured a loss twice -- 6.16 vs 6.00 ms in round 1,
+        # 4.35 vs 3.73 ms FRVSR with capped residency -- and are gone.)
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "15")) & 31) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
-        uses_side = (self.use_vgg and self.ov_parts & 5) or (gan and self.ov_parts & 10)
+        uses_side = (self.use_vgg and self.ov_parts & 21) or (gan and self.ov_parts & 10)
         self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
         # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
         # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
@@ -366,6 +377,15 @@ class TrainEngine:
                 gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
                 self._gan_losses(gd)
         hold.append(d_gen)
+        # ---- side: VGG pass of the MIDDLE frames [tc, tm) beside the first part of the BPTT (which only needs the last ones)
+        tm = tc + (T - tc + 1) // 2 if (self.use_vgg and (self.ov_parts & 16) and self._mode != "flat" and T - tc >= 2) else tc
+        d_vgg_mid = None
+        if tm > tc:
+            d_vgg_mid = self._d_vgg_mid = (torch.empty(tm - tc, B, H, H, 3, device=self.dev) if self._d_vgg_mid is None
+                                           else self._d_vgg_mid)
+            with seg("vgg_mid", "S", ["fwd_b"]):
+                # _vgg_chunk writes dst[t0:t1]: hand it a view whose index tc is the scratch tensor's first frame
+                self._vgg_chunk(gen, taps_t, tc, tm, _Shifted(d_vgg_mid, tc), K.CONV_COEXIST, zero=True)
         if self.gan:
             sk, cx = part(8)
             with seg("down", sk, ["fwd_b"]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
@@ -376,20 +396,29 @@ class TrainEngine:
         # ---- backward through the recurrence ------------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
         tail_split = self.exchange_mode == "captured"    # the RCCL segments hook in after wgrad and after FNet's backward
-        with seg("bwd", "M", ["vgg_early"]):
+
+        def backward_frames(t1, t0):
+            for t in range(t1 - 1, t0 - 1, -1):
+                dx_in = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
+                if t > 0:
+                    K.warp_s2d_backward(dx_in, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
+
+        with (seg("bwd", "M", []) if (self.gan or self.use_vgg) else contextlib.nullcontext()):   # (no empty segments)
             if self.gan:     # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
                 dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
                 K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
                                         gd["off"], gd["merge"])
                 hold.append(dx)
+            if self.use_vgg and tm < T:                              # the last frames: straight into d_gen
+                self._vgg_chunk(gen, taps_t, tm, T, d_gen, 0, zero=False)
+            if tm > tc:
+                backward_frames(T, tm)                               # ... and their BPTT, while the side stream does [tc, tm)
+        with seg("bwd_b", "M", ["vgg_mid", "vgg_early"]):
+            if tm > tc:
+                K.lincomb(d_vgg_mid, None, d_gen[tc:tm], 1.0, 0.0, accumulate=True)
             if self.use_vgg:
-                if tc < T:                                           # late frames: straight into d_gen
-                    self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
                 K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)      # early frames (computed beside the chain)
-            for t in range(T - 1, -1, -1):
-                dx_in = self.G.backward_t(t, d_gen[t], need_dx=t > 0)
-                if t > 0:
-                    K.warp_s2d_backward(dx_in, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
+            backward_frames(tm if tm > tc else T, 0)
             if not tail_split:
                 self.G.wgrad_sequence(0, T)
                 self.Fn.backward(fsaved, d_flow)

@@ -5,9 +5,10 @@ _T = {"unsigned short": "bf16", "float": "f32"}
 
 
 def tg_name(k):
-    m = re.search(r"conv3x3_tile_kernel<([a-z ]+), ([a-z ]+), (\d+), (\d+), \d+>", k)
+    m = re.search(r"conv3x3_tile_kernel<([a-z ]+), ([a-z ]+), (\d+), (\d+), \d+(?:, (\d+))?>", k)
     if m:
-        return "conv3x3_tile<%s,%s,%s,%s>" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4))
+        base = "conv3x3_tile<%s,%s,%s,%s" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4))
+        return base + (",pack%s>" % m.group(5) if m.group(5) and m.group(5) != "1" else ">")
     m = re.search(r"conv3x3_ws_kernel<(true|false), (true|false)>", k)
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
@@ -18,6 +19,8 @@ def tg_name(k):
     m = re.search(r"conv_igemm_kernel<([a-z ]+), ([a-z ]+), (\d+), (\d+), (\d+), (\d+), (true|false)>", k)
     if m:
         return "conv_igemm<%s,%s,%s,%s,%s,%s>" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4), m.group(5), m.group(6))
+    if "deconv3x3s2_ws_kernel" in k:
+        return "deconv3x3s2_ws"
     if "conv_wgrad_row3_bf16_kernel" in k:
         return "conv_wgrad_row3_bf16"
     m = re.search(r"conv_wgrad_bf16_kernel<(\d+)>", k)
@@ -27,11 +30,14 @@ def tg_name(k):
     if m:
         return "conv_wgrad<%s,%s>" % (_T[m.group(1)], _T[m.group(2)])
     for base, tg in (("warp_s2d_fwd_scalar_kernel", "warp_s2d_fwd_scalar"), ("warp_s2d_fwd_kernel", "warp_s2d_fwd"),
-                     ("warp_s2d_bwd_kernel", "warp_s2d_bwd"), ("bicubic_add_quad_kernel", "bicubic_add_quad"),
+                     ("warp_s2d_bwd_kernel", "warp_s2d_bwd"), 
                      ("bicubic_add_kernel", "bicubic_add"), ("upsample2_fwd_kernel", "upsample2_fwd")):
         m = re.search(base + r"<([a-z ]+)>", k)
         if m:
             return "%s<%s>" % (tg, _T[m.group(1)])
+    m = re.search(r"bicubic_add_quad_kernel<([a-z ]+), (?:true|false)>", k)
+    if m:
+        return "bicubic_add_quad<%s>" % _T[m.group(1)]
     if "upsample2_fwd_x8_kernel" in k:
         return "upsample2_fwd_x8"
     return None
