@@ -22,6 +22,8 @@
 
 int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                       const void* aux, void* out, hipStream_t st);        // conv3x3_ws.hip
+int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                       const void* aux, void* out, hipStream_t st);       // conv3x3_dma.hip
 
 struct Conv3P {
   const void* in;
@@ -680,6 +682,7 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   if (aux && d->mask_act != TG_ACT_RELU && d->mask_act != TG_ACT_LRELU) return 0;   // generic engine handles others
   if (conv3x3_c8_try(d, in, weight, bias, res, aux, out, st)) return 1;
   if (tg_conv3x3_ws_try(d, in, weight, bias, res, aux, out, st)) return 1;       // one-chunk layers in the throughput regime
+  if (tg_conv3x3_dma_try(d, in, weight, bias, res, aux, out, st)) return 1;      // wide layers (Cin > 64) in the throughput regime
   Conv3P p;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;

@@ -1,0 +1,317 @@
+// 3x3 stride-1 SAME convolution for the wide layers (Cin a multiple of 32, > 64; bf16) -- gfx950.
+//
+// Covers where most of the training step's MACs are: VGG-19 conv2_2 ... conv4_4 (reference lib/ops.py:319-327 through
+// lib/Teco.py:5-24: 85 % of the perceptual-loss MACs, which are 86 % of the TecoGAN step's),
+// FNet's 128 / 256-channel levels (lib/frvsr.py:13-27) and -- taps mirrored -- their input gradients.
+//
+// Why a third kernel.  conv3x3_tile_kernel<8|16,64> (conv3x3.hip) stages every 64-channel chunk of the input halo AND of
+// the 9 x 64 weight panel global -> registers -> ds_write_b128 -> barrier into a SINGLE LDS buffer (130 KB at TH = 16), so
+// per chunk the load round trip, 1250 cycles of ds_write traffic, two barriers and the 2300-cycle MFMA block run one
+// after the other: 500 TFLOP/s, 20 % of the MFMA peak (profiles/r02g_bench.json).  conv3x3_ws.hip fixed this for
+// Cin <= 64 by keeping the weights in registers; with Cin up to 512 they do not fit.  Here:
+//   * a pipeline STAGE is one 32-channel chunk (= one K step of v_mfma_f32_16x16x32_bf16) of one 16 x 16 pixel tile:
+//     the 18 x 18 halo pixels (20.3 KB) and the 9 x 64 x 32 weight panel (36 KB) of the stage arrive by LDS-DMA
+//     (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write pass; out-of-image lanes get an out-of-range
+//     offset and the hardware writes zeros) into a DOUBLE buffer (2 x 57 KB): the DMA of stage s+1 is issued right
+//     after the one barrier of stage s and flies during its 72 MFMAs per wave;
+//   * rows are 64 bytes (32 channels) with NO padding; the four 16-byte slots of a row are XOR-swizzled by
+//     2 * (row bit 2), which makes every ds_read_b128 fragment read of 16 consecutive rows conflict-free under the
+//     gfx950 lane grouping (MI355X_MICROARCH.md LDS table) -- the swizzle is applied on the GLOBAL side of the DMA (each
+//     lane picks which chunk it fetches), since the LDS side is fixed at base + 16 * lane;
+//   * 8 waves (4 x 2): a wave owns 4 pixel rows x 32 output channels; per (kw) it reads 6 halo-row fragments once and
+//     reuses them for the three vertical taps: 12 ds_read_b128 per 24 MFMAs (the tile kernel: 6 per 8), two waves per
+//     SIMD so one wave's LDS latency and address work hide under the other's MFMAs;
+//   * MFMA operands swapped (A = weights, B = pixels) as in conv3x3_ws.hip: register-only epilogue, 8-byte stores.
+#include "common.h"
+#include <mutex>
+#include <stdlib.h>
+
+struct ConvDmaP {
+  const void* in;
+  const void* w;      // [9][Cout][Cin]
+  const float* bias;
+  const void* res;
+  const void* aux;
+  void* out;
+  int N, H, W, Cin, Cout;
+  int flip;           // 1: taps mirrored (input-gradient form)
+  float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
+  float mslope;       // act-grad mask: aux > 0 ? 1 : mslope
+  int tiles_y, tiles_x, ntiles;
+  unsigned in_bytes, w_bytes, out_bytes;
+};
+
+typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_d;
+
+namespace {
+constexpr int DM_TH = 16, DM_HW = 18, DM_HALO = (DM_TH + 2) * DM_HW;      // 324 halo pixels
+constexpr int DM_HALO_INST = (DM_HALO * 4 + 63) / 64;                     // 21 wave-wide DMA instructions (1 KB each)
+constexpr int DM_HALO_ROUNDS = (DM_HALO_INST + 7) / 8;                    // 3 rounds of 8 waves (the last: waves 0..4)
+constexpr int DM_W_INST = 9 * 64 * 4 / 64;                                // 36
+constexpr int DM_WBASE_INST = DM_HALO_ROUNDS * 8;                         // the weight panel starts on a round boundary,
+constexpr int DM_INST = DM_WBASE_INST + DM_W_INST;                        // so a round's kind is a compile-time fact (60)
+constexpr int DM_WOFF = DM_WBASE_INST * 1024;                             // weight panel offset in a buffer (24576)
+constexpr int DM_BUF = DM_INST * 1024;                                    // 61440 bytes per stage buffer
+constexpr int DM_KPW = (DM_INST + 7) / 8;                                 // DMA rounds per wave (8; the last one: waves 0..3)
+constexpr unsigned DM_OOB = 0x80000000u;
+static_assert(DM_WOFF % 512 == 0, "the weight panel must start on a multiple of 8 rows (swizzle period)");
+}  // namespace
+
+template <bool HAS_RES, bool HAS_AUX>
+__global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x DM_BUF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                  // 4 x 2 waves: 4 pixel rows x 32 channels each
+  const int frow = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.y * 64;
+  const int cbase = n0 + wn * 32;
+  const int row_bytes = p.Cin * 2;
+  const int nchunk = p.Cin >> 5;
+
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  const auto rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+  const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_RES ? p.res : p.out), 0, (int)p.out_bytes, 0x00020000);
+  const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.out), 0, (int)p.out_bytes, 0x00020000);
+
+  // ---- LDS-DMA slot descriptors of this lane (stage-independent).  Instruction `inst` = wave + 8k fills the 64
+  //      16-byte slots S = 64 inst + lane of the stage buffer: row q = S / 4, position S % 4, which holds channel group
+  //      (S % 4) ^ 2*((q >> 2) & 1) of that row.  Rounds 0..2: halo pixel q (instructions 21..23 would be all padding and
+  //      are not issued); rounds 3..7: weight row q - 384 = tap * 64 + channel.
+  int rel[DM_KPW], code[DM_KPW];
+#pragma unroll
+  for (int k = 0; k < DM_KPW; ++k) {
+    const int inst = wave + 8 * k;
+    const int S = inst * 64 + lane;
+    const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
+    if (k < DM_HALO_ROUNDS) {
+      const int dy = q / DM_HW, dx = q - DM_HW * dy;
+      rel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
+      code[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
+    } else {
+      const int r = q - DM_WOFF / 64, tap = r >> 6, co = n0 + (r & 63);
+      const int wt = p.flip ? 8 - tap : tap;
+      rel[k] = (inst < DM_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
+      code[k] = 0;
+    }
+  }
+
+  auto issue_dma = [&](int tile, int chunk, int buf) {
+    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+    const int y0 = ty * DM_TH - 1, x0 = tx * 16 - 1;
+    const int base = ((n * p.H + y0) * p.W + x0) * row_bytes + chunk * 64;   // wave-uniform
+    unsigned char* dst = smem + buf * DM_BUF;
+#pragma unroll
+    for (int k = 0; k < DM_KPW; ++k) {
+      const int inst = wave + 8 * k;                                          // wave-uniform
+      if (k < DM_HALO_ROUNDS) {
+        if (k + 1 < DM_HALO_ROUNDS || inst < DM_HALO_INST) {
+        const int dy = code[k] & 255, dx = (code[k] >> 8) & 255;
+        const bool ok = (code[k] >> 24) && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)(base + rel[k]) : DM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
+        }
+      } else if (k + 1 < DM_KPW || inst < DM_INST) {
+        const unsigned off = rel[k] >= 0 ? (unsigned)(rel[k] + chunk * 64) : DM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= p.ntiles) return;
+  issue_dma(tile, 0, 0);
+
+  float bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cbase + j * 16 + fg * 4 + r;
+      bv[j][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+
+  // ---- fragment addresses.  Halo fragment (row r, tap column kw): pixel q = Q0 + K with Q0 = 72 wm + frow (lane part)
+  //      and K = 18 r + kw (compile time).  The swizzle bit (q >> 2) & 1 depends only on (Q0 + K) mod 8, so eight lane
+  //      bases cover every K: the read is base[K & 7] + 64 K as an immediate offset -- no address arithmetic per read.
+  const int Q0 = wm * 4 * DM_HW + frow;
+  int abase[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) abase[d] = Q0 * 64 + ((fg ^ ((((Q0 & 7) + d) >> 2 & 1) << 1)) << 4);
+  // weight fragment (tap, j): row tap*64 + 32 wn + 16 j + frow -- the swizzle bit is (frow >> 2) & 1
+  const int bbase = DM_WOFF + (wn * 32 + frow) * 64 + ((fg ^ (((frow >> 2) & 1) << 1)) << 4);
+
+  f32x4 acc[4][2];
+  int chunk = 0, buf = 0;
+  bool prev_epi = false;
+  while (true) {
+    int ntile = tile, nch = chunk + 1;
+    if (nch == nchunk) {
+      nch = 0;
+      ntile = tile + gridDim.x;
+    }
+    // This wave's DMA slots of the stage have landed.  The VMEM queue holds (oldest first) the stage's DMA and, after an
+    // epilogue, that tile's 8 stores: vmcnt retires in order, so vmcnt(8) waits for the DMA without draining the stores.
+    if (prev_epi) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // every wave's slots landed; nobody still reads the other buffer
+    if (ntile < p.ntiles) issue_dma(ntile, nch, buf ^ 1);   // flies during the MFMA block below
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (chunk == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned char* sb = smem + buf * DM_BUF;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      u32x4d af[6];                                         // halo rows 0..5 of this wave at column offset kw
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int K = r * DM_HW + kw;
+        af[r] = *reinterpret_cast<const u32x4d*>(sb + abase[K & 7] + K * 64);
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        u32x4d bfr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bfr[j] = *reinterpret_cast<const u32x4d*>(sb + bbase + ((kh * 3 + kw) * 64 + j * 16) * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
+                                                                __builtin_bit_cast(bf16x8, af[i + kh]), acc[i][j], 0, 0, 0);
+      }
+    }
+
+    prev_epi = chunk == nchunk - 1;
+    if (prev_epi) {
+      // ---- epilogue in registers: accumulator r of lane (frow, fg) = pixel column frow, output channel cbase+16j+4fg+r
+      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+      const int x = tx * 16 + frow;
+      unsigned offs[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int y = ty * DM_TH + wm * 4 + i;
+        const bool pok = y < p.H && x < p.W;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int co = cbase + j * 16 + fg * 4;
+          offs[i][j] = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : DM_OOB;
+        }
+      }
+      u32x2d rr[HAS_RES ? 4 : 1][2], aa[HAS_AUX ? 4 : 1][2];
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
+      }
+      if constexpr (HAS_AUX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r] + bv[j][r];
+            v[r] = fmaxf(v[r], v[r] * p.nslope);
+          }
+          if constexpr (HAS_RES) {
+            v[0] += __uint_as_float(rr[i][j].x << 16);
+            v[1] += __uint_as_float(rr[i][j].x & 0xffff0000u);
+            v[2] += __uint_as_float(rr[i][j].y << 16);
+            v[3] += __uint_as_float(rr[i][j].y & 0xffff0000u);
+          }
+          if constexpr (HAS_AUX) {
+            v[0] *= __uint_as_float(aa[i][j].x << 16) > 0.f ? 1.f : p.mslope;
+            v[1] *= __uint_as_float(aa[i][j].x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+            v[2] *= __uint_as_float(aa[i][j].y << 16) > 0.f ? 1.f : p.mslope;
+            v[3] *= __uint_as_float(aa[i][j].y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+          }
+          u32x2d o;
+          o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)offs[i][j], 0, 0);
+        }
+      }
+    }
+    if (ntile >= p.ntiles) break;
+    tile = ntile;
+    chunk = nch;
+    buf ^= 1;
+  }
+}
+
+template <bool HAS_RES, bool HAS_AUX>
+static void launch_dma(const ConvDmaP& p, hipStream_t st) {
+  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX>;
+  constexpr int LDS = 2 * DM_BUF;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  const int nt = p.Cout / 64;
+  // persistent over tiles: one workgroup per CU; grid.x a multiple of 8 so that the channel blocks of one pixel tile
+  // (workgroup ids x, x + grid.x, ...) land on the SAME XCD and share its L2 copy of the halo
+  int gx = 256 / nt;
+  if (gx < 8) gx = 8;
+  gx &= ~7;
+  if (gx > p.ntiles) gx = p.ntiles;
+  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>")
+                                           : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>");
+  const double px = (double)p.N * p.H * p.W;
+  TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
+            px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(512),
+            LDS, st, p);
+}
+
+// Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
+int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
+                       const void* aux, void* out, hipStream_t st) {
+  static const bool enabled = getenv("TG_NO_C3DMA") == nullptr;            // A/B switch
+  static const int min_wg = getenv("TG_C3DMA_MIN_WG") ? atoi(getenv("TG_C3DMA_MIN_WG")) : 96;
+  if (!enabled) return 0;
+  if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
+  if (d->Cin % 32 != 0 || d->Cin < 64 || d->Cout % 64 != 0) return 0;
+  if (d->act >= TG_ACT_TANH) return 0;
+  if (d->Hin <= 8 || d->Win <= 8) return 0;               // 8 x 8 and smaller: the packed tiles of conv3x3.hip
+  if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15)) return 0;
+  const int64_t px = (int64_t)d->N * d->Hin * d->Win;
+  const int64_t in_bytes = px * d->Cin * 2, out_bytes = px * d->Cout * 2, w_bytes = (int64_t)9 * d->Cout * d->Cin * 2;
+  if (in_bytes >= ((int64_t)1 << 31) || out_bytes >= ((int64_t)1 << 31)) return 0;
+  ConvDmaP p;
+  p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
+  p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
+  p.flip = d->mode == 1;
+  p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
+  p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
+  p.tiles_y = (p.H + DM_TH - 1) / DM_TH;
+  p.tiles_x = (p.W + 15) / 16;
+  const int64_t ntiles = (int64_t)p.N * p.tiles_y * p.tiles_x;
+  // below ~a third of the chip's CUs the 8 x 64 tiles of conv3x3.hip (twice the workgroups) fill it better
+  if (ntiles * (p.Cout / 64) < min_wg || ntiles >= ((int64_t)1 << 30)) return 0;
+  p.ntiles = (int)ntiles;
+  p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
+  if (res && aux) launch_dma<true, true>(p, st);
+  else if (res) launch_dma<true, false>(p, st);
+  else if (aux) launch_dma<false, true>(p, st);
+  else launch_dma<false, false>(p, st);
+  return 1;
+}

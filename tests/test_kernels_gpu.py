@@ -905,12 +905,13 @@ def test_bicubic_quad_kernel_state_output(dtype):
 # ---- narrow images packed side by side in one tile row (conv3x3.hip PACK = 2 / 4) -------------------------------------
 PACK_CASES = [
     # N, H, W, Cin, Cout, flip, res, aux, act
-    (6, 8, 8, 128, 128, False, False, False, ACT_RELU),       # VGG conv5-like geometry: two 8x8 images per tile row
-    (5, 8, 8, 64, 64, False, True, False, ACT_NONE),          # odd image count (last group half empty), residual
-    (9, 4, 4, 256, 256, False, False, False, ACT_LRELU),      # four 4x4 images per row, ragged last group
-    (3, 8, 6, 128, 64, True, False, True, ACT_NONE),          # W = 6 < 8, input-gradient form with ReLU mask
-    (4, 16, 8, 64, 128, False, False, False, ACT_RELU),       # H = 16: two tiles per image column
-    (7, 3, 3, 128, 64, True, True, True, ACT_NONE),           # 3x3 images, H <= 4
+    # (image counts: the packed tiles are only selected for chip-filling layers, pixels x channel tiles >= 16384)
+    (130, 8, 8, 128, 128, False, False, False, ACT_RELU),     # VGG conv5-like geometry: two 8x8 images per tile row
+    (257, 8, 8, 64, 64, False, True, False, ACT_NONE),        # odd image count (last group half empty), residual
+    (257, 4, 4, 256, 256, False, False, False, ACT_LRELU),    # four 4x4 images per row, ragged last group
+    (343, 8, 6, 128, 64, True, False, True, ACT_NONE),        # W = 6 < 8, input-gradient form with ReLU mask
+    (66, 16, 8, 64, 128, False, False, False, ACT_RELU),      # H = 16: two tiles per image column
+    (1823, 3, 3, 128, 64, True, True, True, ACT_NONE),        # 3x3 images, H <= 4, ragged last group
 ]
 
 
@@ -945,6 +946,51 @@ def test_conv3x3_packed_narrow_images(case):
     assert ents and "pack" in ents[0]["name"], "the packed-tile instantiation was not selected: %s" % ents
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 3e-2).all(), "%s: max err %g" % (case, err.max().item())
+
+
+# ---- conv3x3_dma.hip: double-buffered LDS-DMA stages for the wide layers (Cin a multiple of 32, > 64) ------------------
+DMA_CASES = [
+    # N, H, W, Cin, Cout, flip, res, aux, act
+    (6, 32, 32, 256, 256, False, False, False, ACT_RELU),     # VGG conv3_x geometry: 4 tiles per image, 8 chunks
+    (40, 16, 16, 512, 512, False, False, False, ACT_RELU),    # VGG conv4_x: one tile per image, 16 chunks, grid.y = 8
+    (3, 64, 64, 128, 128, True, False, True, ACT_NONE),       # conv2_2 input gradient: mirrored taps + ReLU mask
+    (5, 40, 27, 96, 64, False, True, False, ACT_LRELU),       # ragged right / bottom edges, Cin = 96 (3 chunks), residual
+    (2, 128, 128, 128, 64, True, True, True, ACT_NONE),       # many tiles per workgroup (persistent loop), res + mask
+    (97, 16, 16, 128, 128, False, False, False, ACT_NONE),    # FNet level-2 geometry; tile count not a multiple of the grid
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_conv3x3_wide_layer_dma_kernel(case):
+    N, H, W, Cin, Cout, flip, has_res, has_aux, act = case
+    x = rnd(N, H, W, Cin, seed=1).bfloat16()
+    w = rnd(3, 3, Cin, Cout, seed=2, scale=0.05).bfloat16()
+    b = None if flip else rnd(Cout, seed=3)
+    res = rnd(N, H, W, Cout, seed=4).bfloat16() if has_res else None
+    aux = rnd(N, H, W, Cout, seed=5).bfloat16() if has_aux else None
+    alpha = 0.2 if act == ACT_LRELU else 0.0
+    ref = O.conv2(x.float(), w.float().flip(0, 1) if flip else w.float(), b, 1)
+    if act == ACT_RELU:
+        ref = torch.relu(ref)
+    elif act == ACT_LRELU:
+        ref = torch.where(ref > 0, ref, ref * alpha)
+    if has_res:
+        ref = ref + res.float()
+    if has_aux:
+        ref = ref * (aux.float() > 0).float()
+    wt = w.permute(0, 1, 3, 2).reshape(9, Cout, Cin).contiguous().to(DEV)
+    out = torch.full((N, H, W, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
+    d = K.conv_desc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1 if flip else 0, TG_BF16, TG_BF16, act, alpha,
+                    ACT_RELU if has_aux else ACT_NONE, 0.0)
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_forward(d, x.to(DEV), wt, None if b is None else b.to(DEV), None if res is None else res.to(DEV),
+                   None if aux is None else aux.to(DEV), out)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"].startswith("conv3x3_dma"), "the wide-layer DMA kernel was not selected: %s" % ents
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
 
 
 @pytest.mark.parametrize("case", [(1, 270, 480, 64, 64), (2, 128, 128, 32, 64), (1, 133, 245, 64, 128)])

@@ -90,6 +90,14 @@ def main():
         ("conv3x3 D-in [24,128,128,32->64]", conv_case(24, 128, 128, 32, 64, dtype=dt)),
         ("conv3x3 fnet [72,32,32,64->64]", conv_case(72, 32, 32, 64, 64, dtype=dt)),
         ("conv3x3 inf  [1,1080,1920,64->3]", conv_case(1, 1080, 1920, 64, 3, dtype=dt)),
+        ("conv3x3 wide [40,64,64,128->128]", conv_case(40, 64, 64, 128, 128, dtype=dt)),
+        ("conv3x3 wide [20,64,64,128->128]", conv_case(20, 64, 64, 128, 128, dtype=dt)),
+        ("conv3x3 wide [40,32,32,256->256]", conv_case(40, 32, 32, 256, 256, dtype=dt)),
+        ("conv3x3 wide [20,32,32,256->256]", conv_case(20, 32, 32, 256, 256, dtype=dt)),
+        ("conv3x3 wide [40,16,16,512->512]", conv_case(40, 16, 16, 512, 512, dtype=dt)),
+        ("conv3x3 wide [20,16,16,512->512]", conv_case(20, 16, 16, 512, 512, dtype=dt)),
+        ("conv3x3 wide [72,16,16,128->128]", conv_case(72, 16, 16, 128, 128, dtype=dt)),
+        ("conv3x3 wide [76,64,64,64->128]", conv_case(76, 64, 64, 64, 128, dtype=dt)),
         ("wgrad gen    [40,32,32,64->64]", wgrad_case(40, 32, 32, 64, 64, dtype=dt)),
         ("wgrad tran2  [40,128,128,64] s2", wgrad_case(40, 128, 128, 64, 64, 3, 2, dtype=dt)),
         ("wgrad fnet   [36,32,32,32->32]", wgrad_case(36, 32, 32, 32, 32, dtype=dt)),
