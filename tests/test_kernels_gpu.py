@@ -907,7 +907,7 @@ PACK_CASES = [
     # N, H, W, Cin, Cout, flip, res, aux, act
     # (image counts: the packed tiles are only selected for chip-filling layers, pixels x channel tiles >= 16384)
     (130, 8, 8, 128, 128, False, False, False, ACT_RELU),     # VGG conv5-like geometry: two 8x8 images per tile row
-    (257, 8, 8, 64, 64, False, True, False, ACT_NONE),        # odd image count (last group half empty), residual
+    (257, 8, 8, 128, 64, False, True, False, ACT_NONE),       # odd image count (last group half empty), residual
     (257, 4, 4, 256, 256, False, False, False, ACT_LRELU),    # four 4x4 images per row, ragged last group
     (343, 8, 6, 128, 64, True, False, True, ACT_NONE),        # W = 6 < 8, input-gradient form with ReLU mask
     (66, 16, 8, 64, 128, False, False, False, ACT_RELU),      # H = 16: two tiles per image column
@@ -954,7 +954,7 @@ DMA_CASES = [
     (6, 32, 32, 256, 256, False, False, False, ACT_RELU),     # VGG conv3_x geometry: 4 tiles per image, 8 chunks
     (40, 16, 16, 512, 512, False, False, False, ACT_RELU),    # VGG conv4_x: one tile per image, 16 chunks, grid.y = 8
     (3, 64, 64, 128, 128, True, False, True, ACT_NONE),       # conv2_2 input gradient: mirrored taps + ReLU mask
-    (5, 40, 27, 96, 64, False, True, False, ACT_LRELU),       # ragged right / bottom edges, Cin = 96 (3 chunks), residual
+    (35, 40, 27, 96, 64, False, True, False, ACT_LRELU),      # ragged right / bottom edges, Cin = 96 (3 chunks), residual
     (2, 128, 128, 128, 64, True, True, True, ACT_NONE),       # many tiles per workgroup (persistent loop), res + mask
     (97, 16, 16, 128, 128, False, False, False, ACT_NONE),    # FNet level-2 geometry; tile count not a multiple of the grid
 ]
