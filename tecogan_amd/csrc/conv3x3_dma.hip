@@ -56,8 +56,23 @@ constexpr int DM_WOFF = DM_WBASE_INST * 1024;                             // wei
 constexpr int DM_BUF = DM_INST * 1024;                                    // 61440 bytes per stage buffer
 constexpr int DM_KPW = (DM_INST + 7) / 8;                                 // DMA rounds per wave (8; the last one: waves 0..3)
 constexpr unsigned DM_OOB = 0x80000000u;
-static_assert(DM_WOFF % 512 == 0, "the weight panel must start on a multiple of 8 rows (swizzle period)");
+static_assert(DM_KPW % 2 == 0 && DM_WOFF % 512 == 0, "the weight panel must start on a multiple of 8 rows (swizzle period)");
 }  // namespace
+
+// Cycle stamps (tools/trace_dma.py builds a private -DTG_DMA_TRACE copy of the library; the product build has none of it).
+#ifdef TG_DMA_TRACE
+__device__ unsigned long long tg_dma_trace_buf[64];
+#define DM_STAMP(i)                                                                                          \
+  do {                                                                                                       \
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0 && (i) < 64)                      \
+      tg_dma_trace_buf[(i)] = (unsigned long long)clock64();                                                 \
+  } while (0)
+extern "C" int tg_debug_dma_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_dma_trace_buf), sizeof(unsigned long long) * 64);
+}
+#else
+#define DM_STAMP(i) do { } while (0)
+#endif
 
 template <bool HAS_RES, bool HAS_AUX>
 __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
@@ -99,32 +114,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     }
   }
 
-  auto issue_dma = [&](int tile, int chunk, int buf) {
+  // One DMA round (k compile-time after unrolling) of the stage described by (y0, x0, base, wofs) into `dst`.
+  int d_y0 = 0, d_x0 = 0, d_base = 0, d_wofs = 0;
+  unsigned char* d_dst = smem;
+  auto dma_setup = [&](int tile, int chunk, int buf) {
     const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
     const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-    const int y0 = ty * DM_TH - 1, x0 = tx * 16 - 1;
-    const int base = ((n * p.H + y0) * p.W + x0) * row_bytes + chunk * 64;   // wave-uniform
-    unsigned char* dst = smem + buf * DM_BUF;
-#pragma unroll
-    for (int k = 0; k < DM_KPW; ++k) {
-      const int inst = wave + 8 * k;                                          // wave-uniform
-      if (k < DM_HALO_ROUNDS) {
-        if (k + 1 < DM_HALO_ROUNDS || inst < DM_HALO_INST) {
+    d_y0 = ty * DM_TH - 1;
+    d_x0 = tx * 16 - 1;
+    d_base = ((n * p.H + d_y0) * p.W + d_x0) * row_bytes + chunk * 64;      // wave-uniform
+    d_wofs = chunk * 64;
+    d_dst = smem + buf * DM_BUF;
+  };
+  auto dma_round = [&](int k) {
+    const int inst = wave + 8 * k;                                          // wave-uniform
+    if (k < DM_HALO_ROUNDS) {
+      if (k + 1 < DM_HALO_ROUNDS || inst < DM_HALO_INST) {
         const int dy = code[k] & 255, dx = (code[k] >> 8) & 255;
-        const bool ok = (code[k] >> 24) && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
-        const unsigned off = ok ? (unsigned)(base + rel[k]) : DM_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
-        }
-      } else if (k + 1 < DM_KPW || inst < DM_INST) {
-        const unsigned off = rel[k] >= 0 ? (unsigned)(rel[k] + chunk * 64) : DM_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
+        const bool ok = (code[k] >> 24) && (unsigned)(d_y0 + dy) < (unsigned)p.H && (unsigned)(d_x0 + dx) < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)(d_base + rel[k]) : DM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(d_dst + inst * 1024), 16, (int)off, 0, 0, 0);
       }
+    } else if (k + 1 < DM_KPW || inst < DM_INST) {
+      const unsigned off = rel[k] >= 0 ? (unsigned)(rel[k] + d_wofs) : DM_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(d_dst + inst * 1024), 16, (int)off, 0, 0, 0);
     }
   };
 
   int tile = blockIdx.x;
   if (tile >= p.ntiles) return;
-  issue_dma(tile, 0, 0);
+  DM_STAMP(0);
+  dma_setup(tile, 0, 0);
+#pragma unroll
+  for (int k = 0; k < DM_KPW; ++k) dma_round(k);
+  DM_STAMP(1);
 
   float bv[2][4];
 #pragma unroll
@@ -147,6 +170,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
 
   f32x4 acc[4][2];
   int chunk = 0, buf = 0;
+  [[maybe_unused]] int it = 0;
   bool prev_epi = false;
   while (true) {
     int ntile = tile, nch = chunk + 1;
@@ -159,9 +183,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     if (prev_epi) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DM_STAMP(2 + 4 * it);
     __builtin_amdgcn_s_barrier();                           // every wave's slots landed; nobody still reads the other buffer
-    if (ntile < p.ntiles) issue_dma(ntile, nch, buf ^ 1);   // flies during the MFMA block below
-    __builtin_amdgcn_sched_barrier(0);
+    DM_STAMP(3 + 4 * it);
+    // The next stage's DMA is issued IN BETWEEN the MFMA groups below (two rounds after each of the first four groups of
+    // 8 MFMAs): issuing the 8 rounds back to back cost each wave ~1000 cycles (an LDS-DMA instruction takes 60-180 cycles
+    // to issue, MI355X_MICROARCH.md) during which BOTH waves of a SIMD -- they leave the barrier together -- fed no MFMA.
+    const bool has_next = ntile < p.ntiles;
+    if (has_next) dma_setup(ntile, nch, buf ^ 1);
 
     if (chunk == 0) {
 #pragma unroll
@@ -190,8 +219,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
                                                                 __builtin_bit_cast(bf16x8, af[i + kh]), acc[i][j], 0, 0, 0);
+        const int grp = kw * 3 + kh;                        // compile time
+        if (grp < DM_KPW / 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (has_next) {
+            dma_round(2 * grp);
+            dma_round(2 * grp + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
+    DM_STAMP(4 + 4 * it);
 
     prev_epi = chunk == nchunk - 1;
     if (prev_epi) {
@@ -252,10 +291,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
         }
       }
     }
+    DM_STAMP(5 + 4 * it);
     if (ntile >= p.ntiles) break;
     tile = ntile;
     chunk = nch;
     buf ^= 1;
+    ++it;
   }
 }
 

@@ -12,6 +12,14 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from knames import tg_name
 
 
+def short(n):
+    t = tg_name(n)
+    if t:
+        return t
+    n = n.replace("void ", "")
+    return n.split("(")[0][:60]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
@@ -33,7 +41,7 @@ def main():
     with open(a.out, "w") as o:
         o.write("start_us,end_us,queue,stream,kernel\n")
         for s, e, q, st, n in rows:
-            o.write("%.2f,%.2f,%s,%s,%s\n" % ((s - t0) / 1e3, (e - t0) / 1e3, q, st, tg_name(n).replace(",", ";")))
+            o.write("%.2f,%.2f,%s,%s,%s\n" % ((s - t0) / 1e3, (e - t0) / 1e3, q, st, short(n).replace(",", ";")))
     print("wrote %d dispatches to %s" % (len(rows), a.out))
 
 
