@@ -55,6 +55,9 @@ typedef struct tg_prof_entry {
 } tg_prof_entry;
 int tg_prof_enable(int on);
 int tg_prof_collect(tg_prof_entry* out, int max_entries, int* count /* total distinct kernels */);
+/* *dst (device, uint64) = the device's 100 MHz wall clock when the stream reaches this point; capturable, so it can mark
+ * segment boundaries inside a replayed hipGraph. */
+int tg_prof_stamp(void* dst, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Convolution engine (implicit GEMM on MFMA).

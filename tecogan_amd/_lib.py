@@ -78,6 +78,7 @@ SIGNATURES["tg_gauss_down4_preprocess"] = [_P, _P, _P, _I, _I, _I, _I, C.POINTER
 SIGNATURES["tg_frame_to_u8"] = [_P, _P, _L, _I, _P]
 SIGNATURES["tg_prof_enable"] = [_I]
 SIGNATURES["tg_prof_collect"] = [C.POINTER(ProfEntry), _I, C.POINTER(C.c_int)]
+SIGNATURES["tg_prof_stamp"] = [_P, _P]
 
 _lib = None
 

@@ -88,3 +88,15 @@ extern "C" int tg_prof_collect(tg_prof_entry* out, int max_entries, int* count) 
   if (rc != TG_OK) tg_set_error("tg_prof_collect: an event pair could not be read (launch under stream capture?)");
   return rc;
 }
+
+// Device-side wall-clock stamp (100 MHz constant clock) as a one-thread kernel: the only timing probe that works INSIDE a
+// captured hipGraph.  The engine places one at the start and end of every segment (TG_SEG_STAMPS=1) to read the real
+// segment schedule of a replayed step without a tracing tool in the way (tools/seg_timeline.py).
+__global__ void prof_stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
+extern "C" int tg_prof_stamp(void* dst, void* stream) {
+  TG_CHECK_ARG(dst != nullptr && (((uintptr_t)dst) & 7) == 0, "dst must be an 8-byte aligned device pointer");
+  hipLaunchKernelGGL(prof_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), (unsigned long long*)dst);
+  TG_CHECK_LAUNCH();
+  return TG_OK;
+}

@@ -95,6 +95,9 @@ class TrainEngine:
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
+        # measurement mode: device wall-clock stamps at every segment boundary (one-thread kernels, captured with the segment)
+        self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
+        self.seg_stamp_names = {}
         self._pools = {}
         self._done, self._mode, self._main, self._d_vgg, self._d_vgg_mid = {}, "flat", None, None, None
         # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
@@ -160,17 +163,28 @@ class TrainEngine:
             for d in deps:
                 st.wait_event(self._done[d][0])
             with torch.cuda.stream(st):
+                self._stamp(name, 0)
                 yield
+                self._stamp(name, 1)
             ev = torch.cuda.Event()
             ev.record(st)
             self._done[name] = (ev, skey)
             return
         g = torch.cuda.CUDAGraph()                     # capture
         with torch.cuda.graph(g, pool=self._pool(skey)):
+            self._stamp(name, 0)
             yield
+            self._stamp(name, 1)
         seg = dict(name=name, skey=skey, deps=deps, graph=g, fn=None, event=torch.cuda.Event())
         self._segs.append(seg)
         self._done[name] = (seg["event"], skey)
+
+    def _stamp(self, name, end):
+        """TG_SEG_STAMPS=1: device wall-clock stamps at the segment's first and last node (tools/seg_timeline.py)."""
+        if self.seg_stamps is None:
+            return
+        i = self.seg_stamp_names.setdefault(name, len(self.seg_stamp_names))
+        K.prof_stamp(self.seg_stamps[2 * i + end:2 * i + end + 1])
 
     def _seg_call(self, name, skey, after, fn):
         """A segment that cannot be captured (a gloo all-reduce): `fn` runs eagerly on the segment's stream every step."""

@@ -294,6 +294,11 @@ def prof_enable(on=True):
     check(lib().tg_prof_enable(int(bool(on))), "tg_prof_enable")
 
 
+def prof_stamp(dst):
+    """dst: one int64 element (device) <- the device wall clock (100 MHz) when the current stream gets here; capturable."""
+    check(lib().tg_prof_stamp(_p(dst), _stream()), "tg_prof_stamp")
+
+
 def prof_collect(max_entries=256):
     """Synchronise, aggregate and clear the launch records: list of dicts sorted by total time (descending)."""
     buf = (L.ProfEntry * max_entries)()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Segment schedule of a replayed training step, read from device wall-clock stamps captured at every segment boundary
+(TG_SEG_STAMPS=1; no tracing tool attached, so launch gaps are the real ones).
+    python tools/seg_timeline.py [--config tecogan] [--steps 20]"""
+import argparse
+import os
+import sys
+
+os.environ["TG_SEG_STAMPS"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="tecogan")
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    eng = bench.new_engine(a.config, "bf16", dev)
+    F = bench.make_flags(a.config)
+    eng.set_batch(*bench.synthetic_batch(F, 1, dev))
+    for _ in range(a.steps):
+        eng.step()
+    torch.cuda.synchronize()
+    t = eng.seg_stamps.cpu().tolist()
+    names = sorted(eng.seg_stamp_names.items(), key=lambda kv: t[2 * kv[1]])
+    t0 = min(t[2 * i] for _, i in names)
+    skey = {s["name"]: s["skey"] for s in (eng._segs or [])}
+    print("segment schedule of the last of %d replayed steps (ms from the first segment's start; 100 MHz device clock)" % a.steps)
+    print("%-12s %-3s %9s %9s %9s" % ("segment", "st", "start", "end", "length"))
+    for n, i in names:
+        s, e = (t[2 * i] - t0) / 1e5, (t[2 * i + 1] - t0) / 1e5
+        print("%-12s %-3s %9.3f %9.3f %9.3f" % (n, skey.get(n, "M"), s, e, e - s))
+    # idle time of the main stream between consecutive M segments
+    ms = [(t[2 * i], t[2 * i + 1], n) for n, i in names if skey.get(n, "M") == "M"]
+    for (s0, e0, n0), (s1, e1, n1) in zip(ms, ms[1:]):
+        print("main stream idle between %-8s and %-8s: %7.3f ms" % (n0, n1, (s1 - e0) / 1e5))
+
+
+if __name__ == "__main__":
+    main()
