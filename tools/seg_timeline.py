@@ -23,10 +23,18 @@ def main():
     eng = bench.new_engine(a.config, "bf16", dev)
     F = bench.make_flags(a.config)
     eng.set_batch(*bench.synthetic_batch(F, 1, dev))
-    for _ in range(a.steps):
+    import time
+    prev = torch.zeros_like(eng.seg_stamps)
+    host = []
+    for i in range(a.steps):
+        if i == a.steps - 1:
+            prev.copy_(eng.seg_stamps)          # on the main stream, between the two steps: the previous step's stamps
+        h0 = time.perf_counter()
         eng.step()
+        host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     t = eng.seg_stamps.cpu().tolist()
+    tp = prev.cpu().tolist()
     names = sorted(eng.seg_stamp_names.items(), key=lambda kv: t[2 * kv[1]])
     t0 = min(t[2 * i] for _, i in names)
     skey = {s["name"]: s["skey"] for s in (eng._segs or [])}
@@ -35,6 +43,9 @@ def main():
     for n, i in names:
         s, e = (t[2 * i] - t0) / 1e5, (t[2 * i + 1] - t0) / 1e5
         print("%-12s %-3s %9.3f %9.3f %9.3f" % (n, skey.get(n, "M"), s, e, e - s))
+    last_prev = max(tp[2 * i + 1] for _, i in names)
+    print("previous step's last segment end -> this step's first segment start: %.3f ms" % ((t0 - last_prev) / 1e5))
+    print("host time inside step() (ms), last 6 steps: %s" % " ".join("%.2f" % (h * 1e3) for h in host[-6:]))
     # idle time of the main stream between consecutive M segments
     ms = [(t[2 * i], t[2 * i + 1], n) for n, i in names if skey.get(n, "M") == "M"]
     for (s0, e0, n0), (s1, e1, n1) in zip(ms, ms[1:]):
