@@ -43,6 +43,10 @@ def main():
     for n, i in names:
         s, e = (t[2 * i] - t0) / 1e5, (t[2 * i + 1] - t0) / 1e5
         print("%-12s %-3s %9.3f %9.3f %9.3f" % (n, skey.get(n, "M"), s, e, e - s))
+    print("the step before it (same clock origin):")
+    for n, i in names:
+        s_, e_ = (tp[2 * i] - t0) / 1e5, (tp[2 * i + 1] - t0) / 1e5
+        print("%-12s %-3s %9.3f %9.3f %9.3f" % (n, skey.get(n, "M"), s_, e_, e_ - s_))
     last_prev = max(tp[2 * i + 1] for _, i in names)
     print("previous step's last segment end -> this step's first segment start: %.3f ms" % ((t0 - last_prev) / 1e5))
     print("host time inside step() (ms), last 6 steps: %s" % " ".join("%.2f" % (h * 1e3) for h in host[-6:]))
