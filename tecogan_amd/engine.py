@@ -95,6 +95,7 @@ class TrainEngine:
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
+        self.lazy_side = os.environ.get("TG_LAZY_SIDE", "1") == "1"     # A/B switch: just-in-time side-stream launches
         # measurement mode: device wall-clock stamps at every segment boundary (one-thread kernels, captured with the segment)
         self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
         self.seg_stamp_names = {}
@@ -211,7 +212,8 @@ class TrainEngine:
     def _replay(self):
         main = torch.cuda.current_stream()
         evs = {}
-        for seg in self._segs:
+
+        def launch(seg):
             st = main if seg["skey"] == "M" else self.streams[seg["skey"]]
             for d in seg["deps"]:
                 st.wait_event(evs[d])
@@ -222,6 +224,37 @@ class TrainEngine:
                     seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
             seg["event"].record(st)
             evs[seg["name"]] = seg["event"]
+
+        if not self.lazy_side:
+            for seg in self._segs:
+                launch(seg)
+            return
+        # Just-in-time launch of the side-stream segments.  A side segment enqueued ahead of time sits in its hardware
+        # queue behind a barrier packet until the main stream reaches its dependency, and while it waits there EVERY
+        # dispatch of the main stream's queue costs ~0.9 us more (the same tax a forked graph branch has; measured with
+        # device stamps: the BPTT segment 6.22 ms with the next step's first side segment pending, 5.26 ms without,
+        # profiles/r02o_seg_timeline.txt).  So the host enqueues the main-stream segments as far ahead as their
+        # dependencies allow, and launches a side segment only once its dependencies have COMPLETED (a host wait on their
+        # events) -- the main stream always has at least one whole segment queued behind the awaited one.
+        todo = list(self._segs)
+        while todo:
+            rest, blocked = [], set()
+            for seg in todo:                                    # main / communication segments: as far ahead as possible
+                ok = seg["skey"] != "S" and seg["skey"] not in blocked and all(d in evs for d in seg["deps"])
+                if ok:
+                    launch(seg)
+                else:
+                    blocked.add(seg["skey"])
+                    rest.append(seg)
+            todo = rest
+            for i, seg in enumerate(todo):                      # then the first side segment, once its inputs exist
+                if seg["skey"] == "S":
+                    assert all(d in evs for d in seg["deps"]), "side segment %s depends on an unlaunched segment" % seg["name"]
+                    for d in seg["deps"]:
+                        evs[d].synchronize()
+                    launch(seg)
+                    del todo[i]
+                    break
 
     def _capture(self):
         # warm-up run (allocator pools, lazy module loads, the real two-stream schedule), state restored afterwards
