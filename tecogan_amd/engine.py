@@ -109,15 +109,16 @@ class TrainEngine:
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
-        # frames, 8 D's own-gradient passes, 16 VGG pass of the middle frames beside the first part of the BPTT.  (Generator
+        # frames, 8 D's own-gradient passes, 16 VGG pass of the middle frames beside the first part of the BPTT,
+        # 32 the generator's weight gradients beside FNet's backward pass.  (Generator
         # weight gradients of finished frames beside the BPTT were measured a loss twice -- 6.16 vs 6.00 ms in round 1,
         # 4.35 vs 3.73 ms FRVSR with capped residency -- and are gone.)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "15")) & 31) if self.overlap else 0
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "15")) & 63) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
-        uses_side = (self.use_vgg and self.ov_parts & 21) or (gan and self.ov_parts & 10)
+        uses_side = (self.use_vgg and self.ov_parts & 21) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 32)
         self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
         # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
         # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
@@ -229,7 +230,7 @@ class TrainEngine:
             for seg in self._segs:
                 launch(seg)
             return
-        # Just-in-time launch of the side-stream segments.  A side segment enqueued ahead of time sits in its hardware
+        # Just-in-time launch of the side-stream (and communication-stream) segments.  A side segment enqueued ahead of time sits in its hardware
         # queue behind a barrier packet until the main stream reaches its dependency, and while it waits there EVERY
         # dispatch of the main stream's queue costs ~0.9 us more (the same tax a forked graph branch has; measured with
         # device stamps: the BPTT segment 6.22 ms with the next step's first side segment pending, 5.26 ms without,
@@ -239,16 +240,16 @@ class TrainEngine:
         todo = list(self._segs)
         while todo:
             rest, blocked = [], set()
-            for seg in todo:                                    # main / communication segments: as far ahead as possible
-                ok = seg["skey"] != "S" and seg["skey"] not in blocked and all(d in evs for d in seg["deps"])
+            for seg in todo:                                    # main-stream segments: as far ahead as possible
+                ok = seg["skey"] == "M" and "M" not in blocked and all(d in evs for d in seg["deps"])
                 if ok:
                     launch(seg)
                 else:
                     blocked.add(seg["skey"])
                     rest.append(seg)
             todo = rest
-            for i, seg in enumerate(todo):                      # then the first side segment, once its inputs exist
-                if seg["skey"] == "S":
+            for i, seg in enumerate(todo):                      # then the first side / communication segment, once its inputs exist
+                if seg["skey"] != "M":
                     assert all(d in evs for d in seg["deps"]), "side segment %s depends on an unlaunched segment" % seg["name"]
                     for d in seg["deps"]:
                         evs[d].synchronize()
@@ -295,12 +296,12 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
-        after = ["down"]
+        after = ["down", "wgrad"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["down", "ar_d", "ar_g", "ar_f"]
+            after = ["down", "wgrad", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
 
@@ -424,15 +425,10 @@ class TrainEngine:
                 gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
                 self._gan_losses(gd)
         hold.append(d_gen)
-        # ---- side: VGG pass of the MIDDLE frames [tc, tm) beside the first part of the BPTT (which only needs the last ones)
+        # ---- side: VGG pass of the MIDDLE frames [tc, tm) beside the first part of the BPTT (which only needs the last ones);
+        #      queued BEHIND D's own-gradient passes on the side stream, so that it runs beside the chain and not beside the
+        #      main stream's own VGG pass of the last frames
         tm = tc + (T - tc + 1) // 2 if (self.use_vgg and (self.ov_parts & 16) and self._mode != "flat" and T - tc >= 2) else tc
-        d_vgg_mid = None
-        if tm > tc:
-            d_vgg_mid = self._d_vgg_mid = (torch.empty(tm - tc, B, H, H, 3, device=self.dev) if self._d_vgg_mid is None
-                                           else self._d_vgg_mid)
-            with seg("vgg_mid", "S", ["fwd_b"]):
-                # _vgg_chunk writes dst[t0:t1]: hand it a view whose index tc is the scratch tensor's first frame
-                self._vgg_chunk(gen, taps_t, tc, tm, _Shifted(d_vgg_mid, tc), K.CONV_COEXIST, zero=True)
         if self.gan:
             sk, cx = part(8)
             with seg("down", sk, ["fwd_b"]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
@@ -440,9 +436,17 @@ class TrainEngine:
                 self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
             self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
+        d_vgg_mid = None
+        if tm > tc:
+            d_vgg_mid = self._d_vgg_mid = (torch.empty(tm - tc, B, H, H, 3, device=self.dev) if self._d_vgg_mid is None
+                                           else self._d_vgg_mid)
+            with seg("vgg_mid", "S", ["fwd_b"]):
+                # _vgg_chunk writes dst[t0:t1]: hand it a view whose index tc is the scratch tensor's first frame
+                self._vgg_chunk(gen, taps_t, tc, tm, _Shifted(d_vgg_mid, tc), K.CONV_COEXIST, zero=True)
         # ---- backward through the recurrence ------------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
         tail_split = self.exchange_mode == "captured"    # the RCCL segments hook in after wgrad and after FNet's backward
+        gw_side = bool(self.ov_parts & 32) and self._mode != "flat"
 
         def backward_frames(t1, t0):
             for t in range(t1 - 1, t0 - 1, -1):
@@ -466,11 +470,11 @@ class TrainEngine:
             if self.use_vgg:
                 K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)      # early frames (computed beside the chain)
             backward_frames(tm if tm > tc else T, 0)
-            if not tail_split:
+            if not tail_split and not gw_side:
                 self.G.wgrad_sequence(0, T)
                 self.Fn.backward(fsaved, d_flow)
-        if tail_split:
-            with seg("wgrad"):
+        if tail_split or gw_side:
+            with seg("wgrad", "S" if gw_side else "M", ["bwd_b"]):       # (bit 32: beside FNet's backward pass)
                 self.G.wgrad_sequence(0, T)
             self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
             with seg("fnet_bwd"):
