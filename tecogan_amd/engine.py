@@ -95,6 +95,7 @@ class TrainEngine:
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
+        self.vgg_cuts = [int(c) for c in os.environ.get("TG_VGG_CUTS", "").split(",") if c.strip()]
         self.lazy_side = os.environ.get("TG_LAZY_SIDE", "1") == "1"     # A/B switch: just-in-time side-stream launches
         # measurement mode: device wall-clock stamps at every segment boundary (one-thread kernels, captured with the segment)
         self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
@@ -113,7 +114,7 @@ class TrainEngine:
         # 32 the generator's weight gradients beside FNet's backward pass.  (Generator
         # weight gradients of finished frames beside the BPTT were measured a loss twice -- 6.16 vs 6.00 ms in round 1,
         # 4.35 vs 3.73 ms FRVSR with capped residency -- and are gone.)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "15")) & 63) if self.overlap else 0
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "47")) & 63) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
@@ -390,7 +391,13 @@ class TrainEngine:
         # ---- recurrent generator (lib/Teco.py:125-155); side: VGG pass of the early frames ----------------------
         gen = torch.empty(T, B, H, H, 3, device=self.dev) if self.gen is None else self.gen
         self.gen = gen
-        tc = (T + 1) // 2 if T > 1 else T                # frames [0, tc): early chunk (side), [tc, T): late chunk (main)
+        # frames [0, tc): early chunks (VGG pass on the side stream, beside the forward recurrence of the LATER frames),
+        # [tc, T): late chunk (main stream, after the forward pass).  TG_VGG_CUTS="6,12,16": the early part in several pieces,
+        # each launched as soon as its frames exist -- the more frames the side stream takes, the shorter the exposed VGG
+        # pass on the main stream before the BPTT can start.
+        cuts = [c for c in self.vgg_cuts if 0 < c < T] if (self.use_vgg and T > 1) else []
+        cuts = sorted(set(cuts)) or [(T + 1) // 2 if T > 1 else T]
+        tc = cuts[-1]
         d_vgg = None
         if self.use_vgg:
             d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
@@ -402,14 +409,22 @@ class TrainEngine:
                 self.G.forward_t(t, gen[t])
 
         early_on_side = self.use_vgg and bool(self.ov_parts & 4) and self._mode != "flat"
-        with seg("fwd_a"):
-            if self.G.seq is None or self._mode != "capture":
-                self.G.begin_sequence(T, B, h, h, self.dev)
-            forward_frames(0, tc if early_on_side else T)
-        if self.use_vgg:
-            sk, cx = part(4)
-            with seg("vgg_early", sk, ["fwd_a", "vggt"]):
-                self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx if early_on_side else 0, zero=True)
+        if not early_on_side:
+            cuts = cuts[-1:]
+        vgg_segs, prev = [], 0
+        for i, c in enumerate(cuts):
+            tag = "" if len(cuts) == 1 else str(i)
+            with seg("fwd_a" + tag):
+                if i == 0 and (self.G.seq is None or self._mode != "capture"):
+                    self.G.begin_sequence(T, B, h, h, self.dev)
+                forward_frames(prev, c if early_on_side else T)
+            if self.use_vgg:
+                sk, cx = part(4)
+                name = "vgg_early" + tag
+                with seg(name, sk, ["fwd_a" + tag, "vggt"]):
+                    self._vgg_chunk(gen, taps_t, prev, c, d_vgg, cx if early_on_side else 0, zero=True)
+                vgg_segs.append(name)
+            prev = c
         with seg("fwd_b", "M", ["dreal", "vggt"]):
             if early_on_side:
                 forward_frames(tc, T)
@@ -464,7 +479,7 @@ class TrainEngine:
                 self._vgg_chunk(gen, taps_t, tm, T, d_gen, 0, zero=False)
             if tm > tc:
                 backward_frames(T, tm)                               # ... and their BPTT, while the side stream does [tc, tm)
-        with seg("bwd_b", "M", ["vgg_mid", "vgg_early"]):
+        with seg("bwd_b", "M", ["vgg_mid"] + vgg_segs):
             if tm > tc:
                 K.lincomb(d_vgg_mid, None, d_gen[tc:tm], 1.0, 0.0, accumulate=True)
             if self.use_vgg:
