@@ -425,28 +425,31 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
 // slim.batch_norm(is_training=True, scale=False, eps=1e-3, decay=.9) + lrelu(0.2)
 // reference lib/ops.py:88-90, lib/Teco.py:38-39  [TF1] A.7.   x viewed as [rows][C].
 // pass 0: mean; pass 1: biased variance around that mean (two-pass, no E[x^2]-E[x]^2 cancellation).
+// Per-thread and per-workgroup partial sums in DOUBLE (this generic form is the fp32 parity mode's): the discriminator's
+// gradients subtract sums over 1e5 pixels that nearly cancel, and with float partials the D input-conv gradient moved
+// between 2e-3 and 5e-3 (relative L2 against the fp64 oracle) from run to run with the order of the atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t rows, int C,
                                                        float* __restrict__ stats, int pass) {
-  __shared__ float red[256];
+  __shared__ double red[256];
   const int Cb = C < 256 ? C : 256, lpc = 256 / Cb;
-  const float inv = 1.f / (float)rows;
+  const double inv = 1.0 / (double)rows;
   for (int c0 = blockIdx.y * Cb; c0 < C; c0 += gridDim.y * Cb) {
     const int c = c0 + (threadIdx.x % Cb), rsub = threadIdx.x / Cb;
-    float s = 0.f;
+    double s = 0.0;
     if (rsub < lpc && c < C) {
       const float mu = pass ? stats[c] : 0.f;
       for (int64_t r = (int64_t)blockIdx.x * lpc + rsub; r < rows; r += (int64_t)gridDim.x * lpc) {
         const float v = Elem<T>::ld(x + r * C + c) - mu;
-        s += pass ? v * v : v;
+        s += pass ? (double)v * v : (double)v;
       }
     }
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < Cb && c < C) {
-      float t = 0.f;
+      double t = 0.0;
       for (int k = 0; k < lpc; ++k) t += red[k * Cb + threadIdx.x];
-      unsafeAtomicAdd(stats + pass * C + c, t * inv);
+      unsafeAtomicAdd(stats + pass * C + c, (float)(t * inv));
     }
     __syncthreads();
   }
@@ -478,30 +481,30 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T* __restrict__ 
                                                           const T* __restrict__ dy, int64_t rows, int C,
                                                           const float* __restrict__ stats, float eps, float alpha,
                                                           float* __restrict__ sums) {
-  __shared__ float red0[256], red1[256];
+  __shared__ double red0[256], red1[256];                 // double partials: see bn_stats_kernel
   const int Cb = C < 256 ? C : 256, lpc = 256 / Cb;
   for (int c0 = blockIdx.y * Cb; c0 < C; c0 += gridDim.y * Cb) {
     const int c = c0 + (threadIdx.x % Cb), rsub = threadIdx.x / Cb;
-    float s0 = 0.f, s1 = 0.f;
+    double s0 = 0.0, s1 = 0.0;
     if (rsub < lpc && c < C) {
       const float mu = stats[c], rstd = rsqrtf(stats[C + c] + eps);
       for (int64_t r = (int64_t)blockIdx.x * lpc + rsub; r < rows; r += (int64_t)gridDim.x * lpc) {
         const float dz = Elem<T>::ld(dy + r * C + c) * (Elem<T>::ld(y + r * C + c) > 0.f ? 1.f : alpha);
-        s0 += dz;
-        s1 += dz * (Elem<T>::ld(x + r * C + c) - mu) * rstd;
+        s0 += (double)dz;
+        s1 += (double)dz * (double)((Elem<T>::ld(x + r * C + c) - mu) * rstd);
       }
     }
     red0[threadIdx.x] = s0;
     red1[threadIdx.x] = s1;
     __syncthreads();
     if (threadIdx.x < Cb && c < C) {
-      float t0 = 0.f, t1 = 0.f;
+      double t0 = 0.0, t1 = 0.0;
       for (int k = 0; k < lpc; ++k) {
         t0 += red0[k * Cb + threadIdx.x];
         t1 += red1[k * Cb + threadIdx.x];
       }
-      unsafeAtomicAdd(sums + c, t0);
-      unsafeAtomicAdd(sums + C + c, t1);
+      unsafeAtomicAdd(sums + c, (float)t0);
+      unsafeAtomicAdd(sums + C + c, (float)t1);
     }
     __syncthreads();
   }
