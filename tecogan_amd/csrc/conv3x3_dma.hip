@@ -49,14 +49,12 @@ namespace {
 constexpr int DM_TH = 16, DM_HW = 18, DM_HALO = (DM_TH + 2) * DM_HW;      // 324 halo pixels
 constexpr int DM_HALO_INST = (DM_HALO * 4 + 63) / 64;                     // 21 wave-wide DMA instructions (1 KB each)
 constexpr int DM_HALO_ROUNDS = (DM_HALO_INST + 7) / 8;                    // 3 rounds of 8 waves (the last: waves 0..4)
+constexpr int DM_HALO_BYTES = DM_HALO_INST * 1024;                        // 21504 = 42 * 512 (swizzle period: 8 rows)
 constexpr int DM_W_INST = 9 * 64 * 4 / 64;                                // 36
-constexpr int DM_WBASE_INST = DM_HALO_ROUNDS * 8;                         // the weight panel starts on a round boundary,
-constexpr int DM_INST = DM_WBASE_INST + DM_W_INST;                        // so a round's kind is a compile-time fact (60)
-constexpr int DM_WOFF = DM_WBASE_INST * 1024;                             // weight panel offset in a buffer (24576)
-constexpr int DM_BUF = DM_INST * 1024;                                    // 61440 bytes per stage buffer
-constexpr int DM_KPW = (DM_INST + 7) / 8;                                 // DMA rounds per wave (8; the last one: waves 0..3)
+constexpr int DM_W_ROUNDS = (DM_W_INST + 7) / 8;                          // 5 (the last: waves 0..3)
 constexpr unsigned DM_OOB = 0x80000000u;
-static_assert(DM_KPW % 2 == 0 && DM_WOFF % 512 == 0, "the weight panel must start on a multiple of 8 rows (swizzle period)");
+static_assert(DM_HALO_BYTES % 512 == 0, "regions must start on a multiple of 8 rows (swizzle period)");
+constexpr int dm_buf_bytes(int nt) { return nt * DM_HALO_BYTES + DM_W_INST * 1024; }       // 58368 / 79872
 }  // namespace
 
 // Cycle stamps (tools/trace_dma.py builds a private -DTG_DMA_TRACE copy of the library; the product build has none of it).
@@ -74,9 +72,16 @@ extern "C" int tg_debug_dma_trace(unsigned long long* out) {
 #define DM_STAMP(i) do { } while (0)
 #endif
 
-template <bool HAS_RES, bool HAS_AUX>
+// NT = pixel tiles per stage.  The kernel is bound by the L2 -> LDS stream, not by MFMA issue (stage trace, tools/trace_dma.py:
+// ~3900 cycles per stage against 2304 of MFMA work, the waves waiting on their DMA), and 64 % of a stage's bytes are the
+// weight panel.  NT = 2 multiplies one weight panel with the halos of TWO tiles (any two: consecutive in the tile order, so
+// also two 16 x 16 images): 39 instead of 57 KB per 256 output pixels.  2 x 78 KB of LDS leave no room for a workgroup of the
+// recurrent chain beside it, so launches that carry TG_CONV_COEXIST take NT = 1.
+template <bool HAS_RES, bool HAS_AUX, int NT>
 __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x DM_BUF
+  constexpr int BUF = dm_buf_bytes(NT), WOFF = NT * DM_HALO_BYTES;
+  constexpr int ROUNDS = NT * DM_HALO_ROUNDS + DM_W_ROUNDS;                 // 8 / 11 DMA rounds per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x BUF
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;                  // 4 x 2 waves: 4 pixel rows x 32 channels each
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   const int cbase = n0 + wn * 32;
   const int row_bytes = p.Cin * 2;
   const int nchunk = p.Cin >> 5;
+  const int nunits = (p.ntiles + NT - 1) / NT;              // a work unit = NT consecutive tiles
 
   const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
@@ -92,61 +98,74 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_RES ? p.res : p.out), 0, (int)p.out_bytes, 0x00020000);
   const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.out), 0, (int)p.out_bytes, 0x00020000);
 
-  // ---- LDS-DMA slot descriptors of this lane (stage-independent).  Instruction `inst` = wave + 8k fills the 64
-  //      16-byte slots S = 64 inst + lane of the stage buffer: row q = S / 4, position S % 4, which holds channel group
-  //      (S % 4) ^ 2*((q >> 2) & 1) of that row.  Rounds 0..2: halo pixel q (instructions 21..23 would be all padding and
-  //      are not issued); rounds 3..7: weight row q - 384 = tap * 64 + channel.
-  int rel[DM_KPW], code[DM_KPW];
+  // ---- LDS-DMA slot descriptors of this lane (stage-independent).  A wave-wide DMA instruction fills 64 consecutive
+  //      16-byte slots; slot S of a region is row q = S / 4, position S % 4, and holds channel group (S % 4) ^ 2*((q >> 2) & 1)
+  //      of that row (the swizzle).  Halo regions: row = halo pixel (instruction wave + 8k, k < 3; 21 instructions, the
+  //      same descriptors for every tile of the stage); weight region: row = tap * 64 + channel (wave + 8k, k < 5; 36).
+  int hrel[DM_HALO_ROUNDS], hcode[DM_HALO_ROUNDS], wrel[DM_W_ROUNDS];
 #pragma unroll
-  for (int k = 0; k < DM_KPW; ++k) {
-    const int inst = wave + 8 * k;
-    const int S = inst * 64 + lane;
+  for (int k = 0; k < DM_HALO_ROUNDS; ++k) {
+    const int S = (wave + 8 * k) * 64 + lane;
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
-    if (k < DM_HALO_ROUNDS) {
-      const int dy = q / DM_HW, dx = q - DM_HW * dy;
-      rel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
-      code[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
-    } else {
-      const int r = q - DM_WOFF / 64, tap = r >> 6, co = n0 + (r & 63);
-      const int wt = p.flip ? 8 - tap : tap;
-      rel[k] = (inst < DM_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
-      code[k] = 0;
-    }
+    const int dy = q / DM_HW, dx = q - DM_HW * dy;
+    hrel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
+    hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < DM_W_ROUNDS; ++k) {
+    const int S = (wave + 8 * k) * 64 + lane;
+    const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
+    const int tap = q >> 6, co = n0 + (q & 63);
+    const int wt = p.flip ? 8 - tap : tap;
+    wrel[k] = (wave + 8 * k < DM_W_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
   }
 
-  // One DMA round (k compile-time after unrolling) of the stage described by (y0, x0, base, wofs) into `dst`.
-  int d_y0 = 0, d_x0 = 0, d_base = 0, d_wofs = 0;
+  // One DMA round (r compile-time after unrolling) of the stage set up by dma_setup: rounds [3t, 3t+3) = halo of tile t,
+  // the last five = the weight panel.
+  int d_y0[NT], d_x0[NT], d_base[NT], d_wofs = 0;
+  bool d_tok[NT];
   unsigned char* d_dst = smem;
-  auto dma_setup = [&](int tile, int chunk, int buf) {
-    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
-    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-    d_y0 = ty * DM_TH - 1;
-    d_x0 = tx * 16 - 1;
-    d_base = ((n * p.H + d_y0) * p.W + d_x0) * row_bytes + chunk * 64;      // wave-uniform
+  auto dma_setup = [&](int unit, int chunk, int buf) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int tile = unit * NT + t;
+      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+      d_tok[t] = tile < p.ntiles;
+      d_y0[t] = ty * DM_TH - 1;
+      d_x0[t] = tx * 16 - 1;
+      d_base[t] = ((n * p.H + d_y0[t]) * p.W + d_x0[t]) * row_bytes + chunk * 64;    // wave-uniform
+    }
     d_wofs = chunk * 64;
-    d_dst = smem + buf * DM_BUF;
+    d_dst = smem + buf * BUF;
   };
-  auto dma_round = [&](int k) {
-    const int inst = wave + 8 * k;                                          // wave-uniform
-    if (k < DM_HALO_ROUNDS) {
+  auto dma_round = [&](int r) {
+    if (r < NT * DM_HALO_ROUNDS) {
+      const int t = r / DM_HALO_ROUNDS, k = r % DM_HALO_ROUNDS;
+      const int inst = wave + 8 * k;                                        // wave-uniform
       if (k + 1 < DM_HALO_ROUNDS || inst < DM_HALO_INST) {
-        const int dy = code[k] & 255, dx = (code[k] >> 8) & 255;
-        const bool ok = (code[k] >> 24) && (unsigned)(d_y0 + dy) < (unsigned)p.H && (unsigned)(d_x0 + dx) < (unsigned)p.W;
-        const unsigned off = ok ? (unsigned)(d_base + rel[k]) : DM_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(d_dst + inst * 1024), 16, (int)off, 0, 0, 0);
+        const int dy = hcode[k] & 255, dx = (hcode[k] >> 8) & 255;
+        const bool ok = (hcode[k] >> 24) && d_tok[t] && (unsigned)(d_y0[t] + dy) < (unsigned)p.H &&
+                        (unsigned)(d_x0[t] + dx) < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)(d_base[t] + hrel[k]) : DM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(d_dst + t * DM_HALO_BYTES + inst * 1024), 16, (int)off, 0, 0, 0);
       }
-    } else if (k + 1 < DM_KPW || inst < DM_INST) {
-      const unsigned off = rel[k] >= 0 ? (unsigned)(rel[k] + d_wofs) : DM_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(d_dst + inst * 1024), 16, (int)off, 0, 0, 0);
+    } else {
+      const int k = r - NT * DM_HALO_ROUNDS;
+      const int inst = wave + 8 * k;
+      if (k + 1 < DM_W_ROUNDS || inst < DM_W_INST) {
+        const unsigned off = wrel[k] >= 0 ? (unsigned)(wrel[k] + d_wofs) : DM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(d_dst + WOFF + inst * 1024), 16, (int)off, 0, 0, 0);
+      }
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile >= p.ntiles) return;
+  int unit = blockIdx.x;
+  if (unit >= nunits) return;
   DM_STAMP(0);
-  dma_setup(tile, 0, 0);
+  dma_setup(unit, 0, 0);
 #pragma unroll
-  for (int k = 0; k < DM_KPW; ++k) dma_round(k);
+  for (int r = 0; r < ROUNDS; ++r) dma_round(r);
   DM_STAMP(1);
 
   float bv[2][4];
@@ -166,47 +185,55 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
 #pragma unroll
   for (int d = 0; d < 8; ++d) abase[d] = Q0 * 64 + ((fg ^ ((((Q0 & 7) + d) >> 2 & 1) << 1)) << 4);
   // weight fragment (tap, j): row tap*64 + 32 wn + 16 j + frow -- the swizzle bit is (frow >> 2) & 1
-  const int bbase = DM_WOFF + (wn * 32 + frow) * 64 + ((fg ^ (((frow >> 2) & 1) << 1)) << 4);
+  const int bbase = WOFF + (wn * 32 + frow) * 64 + ((fg ^ (((frow >> 2) & 1) << 1)) << 4);
 
-  f32x4 acc[4][2];
+  f32x4 acc[NT][4][2];
   int chunk = 0, buf = 0;
   [[maybe_unused]] int it = 0;
   bool prev_epi = false;
   while (true) {
-    int ntile = tile, nch = chunk + 1;
+    int nunit = unit, nch = chunk + 1;
     if (nch == nchunk) {
       nch = 0;
-      ntile = tile + gridDim.x;
+      nunit = unit + gridDim.x;
     }
     // This wave's DMA slots of the stage have landed.  The VMEM queue holds (oldest first) the stage's DMA and, after an
-    // epilogue, that tile's 8 stores: vmcnt retires in order, so vmcnt(8) waits for the DMA without draining the stores.
-    if (prev_epi) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue, that unit's 8 NT stores: vmcnt retires in order, so a counted wait covers the DMA without draining the stores.
+    if (prev_epi) {
+      if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     DM_STAMP(2 + 4 * it);
     __builtin_amdgcn_s_barrier();                           // every wave's slots landed; nobody still reads the other buffer
     DM_STAMP(3 + 4 * it);
-    // The next stage's DMA is issued IN BETWEEN the MFMA groups below (two rounds after each of the first four groups of
-    // 8 MFMAs): issuing the 8 rounds back to back cost each wave ~1000 cycles (an LDS-DMA instruction takes 60-180 cycles
-    // to issue, MI355X_MICROARCH.md) during which BOTH waves of a SIMD -- they leave the barrier together -- fed no MFMA.
-    const bool has_next = ntile < p.ntiles;
-    if (has_next) dma_setup(ntile, nch, buf ^ 1);
+    // The next stage's DMA is issued IN BETWEEN the MFMA groups below (two rounds after each of the first groups of 8
+    // MFMAs): issuing the rounds back to back cost each wave ~1000 cycles (an LDS-DMA instruction takes 60-180 cycles to
+    // issue, MI355X_MICROARCH.md) during which BOTH waves of a SIMD -- they leave the barrier together -- fed no MFMA.
+    const bool has_next = nunit < nunits;
+    if (has_next) dma_setup(nunit, nch, buf ^ 1);
 
     if (chunk == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const unsigned char* sb = smem + buf * DM_BUF;
+    const unsigned char* sb = smem + buf * BUF;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      u32x4d af[6];                                         // halo rows 0..5 of this wave at column offset kw
+      u32x4d af[NT][6];                                     // halo rows 0..5 of this wave at column offset kw, per tile
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const int K = r * DM_HW + kw;
-        af[r] = *reinterpret_cast<const u32x4d*>(sb + abase[K & 7] + K * 64);
-      }
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int K = r * DM_HW + kw;
+          af[t][r] = *reinterpret_cast<const u32x4d*>(sb + t * DM_HALO_BYTES + abase[K & 7] + K * 64);
+        }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         u32x4d bfr[2];
@@ -214,19 +241,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
         for (int j = 0; j < 2; ++j)
           bfr[j] = *reinterpret_cast<const u32x4d*>(sb + bbase + ((kh * 3 + kw) * 64 + j * 16) * 64);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
-                                                                __builtin_bit_cast(bf16x8, af[i + kh]), acc[i][j], 0, 0, 0);
-        const int grp = kw * 3 + kh;                        // compile time
-        if (grp < DM_KPW / 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (has_next) {
-            dma_round(2 * grp);
-            dma_round(2 * grp + 1);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
+                                                                     __builtin_bit_cast(bf16x8, af[t][i + kh]), acc[t][i][j], 0, 0, 0);
+          const int grp = (kw * 3 + kh) * NT + t;           // compile time: group of 8 MFMAs just issued
+          if (2 * grp < ROUNDS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+              dma_round(2 * grp);
+              if (2 * grp + 1 < ROUNDS) dma_round(2 * grp + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -235,92 +265,107 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     prev_epi = chunk == nchunk - 1;
     if (prev_epi) {
       // ---- epilogue in registers: accumulator r of lane (frow, fg) = pixel column frow, output channel cbase+16j+4fg+r
-      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
-      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-      const int x = tx * 16 + frow;
-      unsigned offs[4][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int y = ty * DM_TH + wm * 4 + i;
-        const bool pok = y < p.H && x < p.W;
+      for (int t = 0; t < NT; ++t) {
+        const int tile = unit * NT + t;
+        const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+        const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+        const int x = tx * 16 + frow;
+        unsigned offs[4][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int co = cbase + j * 16 + fg * 4;
-          offs[i][j] = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : DM_OOB;
+        for (int i = 0; i < 4; ++i) {
+          const int y = ty * DM_TH + wm * 4 + i;
+          const bool pok = tile < p.ntiles && y < p.H && x < p.W;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int co = cbase + j * 16 + fg * 4;
+            offs[i][j] = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : DM_OOB;
+          }
         }
-      }
-      u32x2d rr[HAS_RES ? 4 : 1][2], aa[HAS_AUX ? 4 : 1][2];
-      if constexpr (HAS_RES) {
+        u32x2d rr[HAS_RES ? 4 : 1][2], aa[HAS_AUX ? 4 : 1][2];
+        if constexpr (HAS_RES) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
-      }
-      if constexpr (HAS_AUX) {
+            for (int j = 0; j < 2; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
+        }
+        if constexpr (HAS_AUX) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
-      }
+            for (int j = 0; j < 2; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float v[4];
+          for (int j = 0; j < 2; ++j) {
+            float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[i][j][r] + bv[j][r];
-            v[r] = fmaxf(v[r], v[r] * p.nslope);
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[t][i][j][r] + bv[j][r];
+              v[r] = fmaxf(v[r], v[r] * p.nslope);
+            }
+            if constexpr (HAS_RES) {
+              v[0] += __uint_as_float(rr[i][j].x << 16);
+              v[1] += __uint_as_float(rr[i][j].x & 0xffff0000u);
+              v[2] += __uint_as_float(rr[i][j].y << 16);
+              v[3] += __uint_as_float(rr[i][j].y & 0xffff0000u);
+            }
+            if constexpr (HAS_AUX) {
+              v[0] *= __uint_as_float(aa[i][j].x << 16) > 0.f ? 1.f : p.mslope;
+              v[1] *= __uint_as_float(aa[i][j].x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+              v[2] *= __uint_as_float(aa[i][j].y << 16) > 0.f ? 1.f : p.mslope;
+              v[3] *= __uint_as_float(aa[i][j].y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
+            }
+            u32x2d o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)offs[i][j], 0, 0);
           }
-          if constexpr (HAS_RES) {
-            v[0] += __uint_as_float(rr[i][j].x << 16);
-            v[1] += __uint_as_float(rr[i][j].x & 0xffff0000u);
-            v[2] += __uint_as_float(rr[i][j].y << 16);
-            v[3] += __uint_as_float(rr[i][j].y & 0xffff0000u);
-          }
-          if constexpr (HAS_AUX) {
-            v[0] *= __uint_as_float(aa[i][j].x << 16) > 0.f ? 1.f : p.mslope;
-            v[1] *= __uint_as_float(aa[i][j].x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
-            v[2] *= __uint_as_float(aa[i][j].y << 16) > 0.f ? 1.f : p.mslope;
-            v[3] *= __uint_as_float(aa[i][j].y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
-          }
-          u32x2d o;
-          o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)offs[i][j], 0, 0);
         }
       }
     }
     DM_STAMP(5 + 4 * it);
-    if (ntile >= p.ntiles) break;
-    tile = ntile;
+    if (nunit >= nunits) break;
+    unit = nunit;
     chunk = nch;
     buf ^= 1;
     ++it;
   }
 }
 
-template <bool HAS_RES, bool HAS_AUX>
+template <bool HAS_RES, bool HAS_AUX, int NT>
 static void launch_dma(const ConvDmaP& p, hipStream_t st) {
-  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX>;
-  constexpr int LDS = 2 * DM_BUF;
+  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX, NT>;
+  constexpr int LDS = 2 * dm_buf_bytes(NT);
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int nt = p.Cout / 64;
-  // persistent over tiles: one workgroup per CU; grid.x a multiple of 8 so that the channel blocks of one pixel tile
+  const int nunits = (p.ntiles + NT - 1) / NT;
+  // persistent over work units: one workgroup per CU; grid.x a multiple of 8 so that the channel blocks of one pixel tile
   // (workgroup ids x, x + grid.x, ...) land on the SAME XCD and share its L2 copy of the halo
   int gx = 256 / nt;
   if (gx < 8) gx = 8;
   gx &= ~7;
-  if (gx > p.ntiles) gx = p.ntiles;
-  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>")
-                                           : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>");
+  if (gx > nunits) gx = nunits;
+  static const char* const pname = NT == 2 ? (HAS_RES ? (HAS_AUX ? "conv3x3_dma2<res,aux>" : "conv3x3_dma2<res>")
+                                                      : (HAS_AUX ? "conv3x3_dma2<aux>" : "conv3x3_dma2<>"))
+                                           : (HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>")
+                                                      : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>"));
   const double px = (double)p.N * p.H * p.W;
   TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
             px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(512),
             LDS, st, p);
+}
+
+template <int NT>
+static void launch_dma_nt(const ConvDmaP& p, bool res, bool aux, hipStream_t st) {
+  if (res && aux) launch_dma<true, true, NT>(p, st);
+  else if (res) launch_dma<true, false, NT>(p, st);
+  else if (aux) launch_dma<false, true, NT>(p, st);
+  else launch_dma<false, false, NT>(p, st);
 }
 
 // Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
@@ -350,9 +395,12 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   if (ntiles * (p.Cout / 64) < min_wg || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-  if (res && aux) launch_dma<true, true>(p, st);
-  else if (res) launch_dma<true, false>(p, st);
-  else if (aux) launch_dma<false, true>(p, st);
-  else launch_dma<false, false>(p, st);
+  // two tiles per stage when the launch runs alone on the chip and still fills it with half the work units
+  static const int pair_env = getenv("TG_C3DMA_PAIR") ? atoi(getenv("TG_C3DMA_PAIR")) : -1;      // A/B switch: 0 never, 1 always
+  const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;
+  const int64_t units2 = (ntiles + 1) / 2 * (p.Cout / 64);
+  const bool pair = pair_env >= 0 ? pair_env == 1 : (!coexist && units2 >= 224);
+  if (pair) launch_dma_nt<2>(p, res != nullptr, aux != nullptr, st);
+  else launch_dma_nt<1>(p, res != nullptr, aux != nullptr, st);
   return 1;
 }

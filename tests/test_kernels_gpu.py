@@ -957,6 +957,11 @@ DMA_CASES = [
     (35, 40, 27, 96, 64, False, True, False, ACT_LRELU),      # ragged right / bottom edges, Cin = 96 (3 chunks), residual
     (2, 128, 128, 128, 64, True, True, True, ACT_NONE),       # many tiles per workgroup (persistent loop), res + mask
     (97, 16, 16, 128, 128, False, False, False, ACT_NONE),    # FNet level-2 geometry; tile count not a multiple of the grid
+    # two tiles per stage (selected when half the work units still fill the chip):
+    (76, 32, 32, 256, 256, False, False, False, ACT_RELU),    # VGG conv3_x at the full batch
+    (57, 16, 16, 512, 512, False, False, False, ACT_RELU),    # odd tile count: the last unit's second tile does not exist
+    (57, 40, 27, 96, 128, False, True, False, ACT_LRELU),     # ragged edges + residual, pairs straddle image boundaries
+    (20, 64, 64, 128, 128, True, False, True, ACT_NONE),      # input-gradient form with ReLU mask
 ]
 
 
@@ -989,6 +994,8 @@ def test_conv3x3_wide_layer_dma_kernel(case):
     K.prof_enable(False)
     ents = K.prof_collect()
     assert ents and ents[0]["name"].startswith("conv3x3_dma"), "the wide-layer DMA kernel was not selected: %s" % ents
+    ntiles = N * ((H + 15) // 16) * ((W + 15) // 16)
+    assert ents[0]["name"].startswith("conv3x3_dma2") == ((ntiles + 1) // 2 * (Cout // 64) >= 224), ents[0]["name"]
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
 

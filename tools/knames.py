@@ -13,10 +13,10 @@ def tg_name(k):
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
         return "conv3x3_ws<%s>" % ",".join(tags)
-    m = re.search(r"conv3x3_dma_kernel<(true|false), (true|false)>", k)
+    m = re.search(r"conv3x3_dma_kernel<(true|false), (true|false)(?:, (\d+))?>", k)
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
-        return "conv3x3_dma<%s>" % ",".join(tags)
+        return "conv3x3_dma%s<%s>" % ("2" if m.group(3) == "2" else "", ",".join(tags))
     m = re.search(r"conv3x3_c8_kernel<(\d+)>", k)
     if m:
         return "conv3x3_c8<%s>" % m.group(1)
