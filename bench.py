@@ -330,13 +330,17 @@ def main():
     eng.set_batch(x, y)
     dt = time_steps(eng, a.steps, a.warmup, fence)
     host_ms = HOST_ENQUEUE_MS[0]
-    # host cost of enqueueing ONE step on an idle device (no queue back-pressure): the floor under which the step is host-bound
-    idle = []
+    # host cost of enqueueing ONE step on an idle device (no queue back-pressure, side segments enqueued ahead instead of
+    # just in time): the floor under which the step is host-bound.  (host_enqueue_ms_per_step is the steady-state time
+    # inside step(): the just-in-time side launches wait for the device at three points of the step, so it tracks ms_per_step.)
+    idle, lazy = [], eng.lazy_side
+    eng.lazy_side = False
     for _ in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.step()
         idle.append((time.perf_counter() - t0) * 1e3)
+    eng.lazy_side = lazy
     torch.cuda.synchronize()
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)

@@ -35,6 +35,7 @@ struct ConvDmaP {
   void* out;
   int N, H, W, Cin, Cout;
   int flip;           // 1: taps mirrored (input-gradient form)
+  int rotate;         // per-workgroup rotation of the weight panel's fetch order
   float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope
   int tiles_y, tiles_x, ntiles;
@@ -111,13 +112,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     hrel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
     hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
   }
+  // The 36 instructions of the weight panel are issued in an order ROTATED per workgroup: every workgroup of a channel
+  // block streams the same 36 KB per stage, and in lock step they would all ask the same L2 channel for the same lines at
+  // the same time (TG_C3DMA_ROT=0: A/B switch for the rotation).
+  const int rot = p.rotate ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)DM_W_INST) : 0;
+  int winst[DM_W_ROUNDS];
 #pragma unroll
   for (int k = 0; k < DM_W_ROUNDS; ++k) {
-    const int S = (wave + 8 * k) * 64 + lane;
+    const int i0 = wave + 8 * k;                            // issue slot; slots >= 36 of the last round are idle
+    winst[k] = (i0 + rot) % DM_W_INST;                      // the instruction (1 KB of the panel) this slot fetches
+    const int S = winst[k] * 64 + lane;
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
     const int tap = q >> 6, co = n0 + (q & 63);
     const int wt = p.flip ? 8 - tap : tap;
-    wrel[k] = (wave + 8 * k < DM_W_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
+    wrel[k] = (i0 < DM_W_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
   }
 
   // One DMA round (r compile-time after unrolling) of the stage set up by dma_setup: rounds [3t, 3t+3) = halo of tile t,
@@ -152,10 +160,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
       }
     } else {
       const int k = r - NT * DM_HALO_ROUNDS;
-      const int inst = wave + 8 * k;
-      if (k + 1 < DM_W_ROUNDS || inst < DM_W_INST) {
+      if (k + 1 < DM_W_ROUNDS || wave + 8 * k < DM_W_INST) {
         const unsigned off = wrel[k] >= 0 ? (unsigned)(wrel[k] + d_wofs) : DM_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(d_dst + WOFF + inst * 1024), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void_d*)(d_dst + WOFF + winst[k] * 1024), 16, (int)off, 0, 0, 0);
       }
     }
   };
@@ -386,6 +393,8 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
   p.flip = d->mode == 1;
+  static const int rot_env = getenv("TG_C3DMA_ROT") ? atoi(getenv("TG_C3DMA_ROT")) : 1;
+  p.rotate = rot_env;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   p.tiles_y = (p.H + DM_TH - 1) / DM_TH;
@@ -399,7 +408,7 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   static const int pair_env = getenv("TG_C3DMA_PAIR") ? atoi(getenv("TG_C3DMA_PAIR")) : -1;      // A/B switch: 0 never, 1 always
   const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;
   const int64_t units2 = (ntiles + 1) / 2 * (p.Cout / 64);
-  const bool pair = pair_env >= 0 ? pair_env == 1 : (!coexist && units2 >= 224);
+  const bool pair = pair_env >= 0 ? pair_env == 1 && units2 >= 224 : false;
   if (pair) launch_dma_nt<2>(p, res != nullptr, aux != nullptr, st);
   else launch_dma_nt<1>(p, res != nullptr, aux != nullptr, st);
   return 1;

@@ -1,5 +1,7 @@
 """Kernel-level parity: every HIP entry point of the C ABI against the CPU oracle (fp32: 1e-4 abs/rel
 unless stated; index shuffles bit-exact).  These call through libtecogan_hip.so via ctypes."""
+import os
+
 import pytest
 import torch
 
@@ -957,7 +959,7 @@ DMA_CASES = [
     (35, 40, 27, 96, 64, False, True, False, ACT_LRELU),      # ragged right / bottom edges, Cin = 96 (3 chunks), residual
     (2, 128, 128, 128, 64, True, True, True, ACT_NONE),       # many tiles per workgroup (persistent loop), res + mask
     (97, 16, 16, 128, 128, False, False, False, ACT_NONE),    # FNet level-2 geometry; tile count not a multiple of the grid
-    # two tiles per stage (selected when half the work units still fill the chip):
+    # big enough for the two-tiles-per-stage variant (opt-in: TG_C3DMA_PAIR=1; measured slower -- tile quantisation):
     (76, 32, 32, 256, 256, False, False, False, ACT_RELU),    # VGG conv3_x at the full batch
     (57, 16, 16, 512, 512, False, False, False, ACT_RELU),    # odd tile count: the last unit's second tile does not exist
     (57, 40, 27, 96, 128, False, True, False, ACT_LRELU),     # ragged edges + residual, pairs straddle image boundaries
@@ -995,7 +997,8 @@ def test_conv3x3_wide_layer_dma_kernel(case):
     ents = K.prof_collect()
     assert ents and ents[0]["name"].startswith("conv3x3_dma"), "the wide-layer DMA kernel was not selected: %s" % ents
     ntiles = N * ((H + 15) // 16) * ((W + 15) // 16)
-    assert ents[0]["name"].startswith("conv3x3_dma2") == ((ntiles + 1) // 2 * (Cout // 64) >= 224), ents[0]["name"]
+    pair = os.environ.get("TG_C3DMA_PAIR") == "1" and (ntiles + 1) // 2 * (Cout // 64) >= 224
+    assert ents[0]["name"].startswith("conv3x3_dma2") == pair, ents[0]["name"]
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
 
