@@ -34,8 +34,17 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}    # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                           # HBM3E spec peak (about 6300 achievable), same guide
-PMC_FILES = {"train": os.path.join(ROOT, "profiles", "r02g_pmc_train.json"),
-             "infer": os.path.join(ROOT, "profiles", "r02g_pmc_infer.json")}      # rocprofv3 --pmc passes (tools/pmc_summary.py)
+def _newest(*names):
+    for n in names:
+        f = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", names[-1])
+
+
+# rocprofv3 --pmc passes summarised by tools/pmc_summary.py (newest session first)
+PMC_FILES = {"train": _newest("r02u_pmc_train.json", "r02g_pmc_train.json"),
+             "infer": _newest("r02u_pmc_infer.json", "r02g_pmc_infer.json")}
 
 
 def parse():
