@@ -319,14 +319,10 @@ __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __re
                                                                const TI* __restrict__ gen_in, int Cpad,
                                                                float* __restrict__ out, float* __restrict__ state, int B,
                                                                int h, int w) {
-  __shared__ float4 xch[4 * 192];                           // one 3 KB exchange strip per wave
   const int H = 4 * h;
   const int n = B * H * w;                                  // < 2^31 (checked by the host)
-  // every lane of a wave runs the same trip count (the loop bound is rounded up to the wave): lanes past n compute on clamped
-  // coordinates and move nothing
-  for (int e = blockIdx.x * 256 + threadIdx.x; e - (int)(threadIdx.x & 63) < n; e += gridDim.x * 256) {
-    const int ec = min(e, n - 1);
-    const int j = ec % w, Y = (ec / w) % H, b = ec / (w * H);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int j = e % w, Y = (e / w) % H, b = e / (w * H);
     const int i = Y >> 2;
     const float* wy = kBicubic[Y & 3];
     int ry[4], rx[4];
@@ -345,24 +341,11 @@ __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __re
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[k][c] = wy[0] * p[0][c] + wy[1] * p[1][c] + wy[2] * p[2][c] + wy[3] * p[3][c];
     }
-    // o = 12 e: the wave's 64 threads own 3072 CONSECUTIVE bytes.  Global accesses go chunk-major (instruction k moves the
-    // 16-byte chunks 64k + lane: 1 KB contiguous per instruction) and are redistributed through the wave's own LDS strip to
-    // the thread-major order the arithmetic wants (thread L: chunks 3L .. 3L+2); with the thread-major float4 accesses at a
-    // 48-byte stride every load / store instruction touched all 24 cache lines of the strip (40.8 us at 1080p).
-    const int lane = threadIdx.x & 63;
-    const int64_t e0 = (int64_t)e - lane;                                    // the wave's first element (may exceed n - 64)
-    float4* strip = xch + (threadIdx.x >> 6) * 192;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int c = 64 * k + lane;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e0 + c / 3 < n) q = *reinterpret_cast<const float4*>(conv_out + 12 * e0 + 4 * c);
-      strip[c] = q;
-    }
+    const int64_t o = ((int64_t)(b * H + Y) * (4 * w) + 4 * j) * 3;          // 12 consecutive floats, 48-byte aligned
     float v[12];
-    *reinterpret_cast<float4*>(v) = strip[3 * lane];
-    *reinterpret_cast<float4*>(v + 4) = strip[3 * lane + 1];
-    *reinterpret_cast<float4*>(v + 8) = strip[3 * lane + 2];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(conv_out + o);
+    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(conv_out + o + 4);
+    *reinterpret_cast<float4*>(v + 8) = *reinterpret_cast<const float4*>(conv_out + o + 8);
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const float* wx = kBicubic[x];
@@ -373,26 +356,16 @@ __global__ __launch_bounds__(256) void bicubic_add_quad_kernel(const float* __re
       }
     }
     if (out) {
-      strip[3 * lane] = *reinterpret_cast<float4*>(v);
-      strip[3 * lane + 1] = *reinterpret_cast<float4*>(v + 4);
-      strip[3 * lane + 2] = *reinterpret_cast<float4*>(v + 8);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int c = 64 * k + lane;
-        if (e0 + c / 3 < n) *reinterpret_cast<float4*>(out + 12 * e0 + 4 * c) = strip[c];
-      }
+      *reinterpret_cast<float4*>(out + o) = *reinterpret_cast<float4*>(v);
+      *reinterpret_cast<float4*>(out + o + 4) = *reinterpret_cast<float4*>(v + 4);
+      *reinterpret_cast<float4*>(out + o + 8) = *reinterpret_cast<float4*>(v + 8);
     }
     if (state) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) v[k] = v[k] * 0.5f + 0.5f;
-      strip[3 * lane] = *reinterpret_cast<float4*>(v);
-      strip[3 * lane + 1] = *reinterpret_cast<float4*>(v + 4);
-      strip[3 * lane + 2] = *reinterpret_cast<float4*>(v + 8);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int c = 64 * k + lane;
-        if (e0 + c / 3 < n) *reinterpret_cast<float4*>(state + 12 * e0 + 4 * c) = strip[c];
-      }
+      *reinterpret_cast<float4*>(state + o) = *reinterpret_cast<float4*>(v);
+      *reinterpret_cast<float4*>(state + o + 4) = *reinterpret_cast<float4*>(v + 4);
+      *reinterpret_cast<float4*>(state + o + 8) = *reinterpret_cast<float4*>(v + 8);
     }
   }
 }
