@@ -396,7 +396,9 @@ class TrainEngine:
         # each launched as soon as its frames exist -- the more frames the side stream takes, the shorter the exposed VGG
         # pass on the main stream before the BPTT can start.
         cuts = [c for c in self.vgg_cuts if 0 < c < T] if (self.use_vgg and T > 1) else []
-        cuts = sorted(set(cuts)) or [(T + 1) // 2 if T > 1 else T]
+        # default: one cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at 10 + 9 and
+        # 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the late chunk is the exposed one, the early one has the forward pass to hide in)
+        cuts = sorted(set(cuts)) or [min((T + 3) // 2, T - 1) if T > 1 else T]
         tc = cuts[-1]
         d_vgg = None
         if self.use_vgg:
