@@ -51,6 +51,9 @@ constexpr int WS_SLOTS = WS_HALO * 9;                      // 16-byte slots of o
 constexpr int WS_NDMA = (WS_SLOTS + 63) / 64;              // wave-wide DMA instructions per tile (26)
 constexpr int WS_BUF = WS_NDMA * 1024;                     // bytes per halo buffer (26624)
 constexpr int WS_KPW = (WS_NDMA + 3) / 4;                  // DMA instructions per wave (7)
+constexpr int WS_WINST = (9 * 64 * 9 + 63) / 64;           // weight panel: 576 rows x 9 slots (8 data + 1 pad) = 81 instructions
+constexpr int WS_WPANEL = WS_WINST * 1024;                 // 82944 bytes
+constexpr int WS_WROUNDS = (WS_WINST + 3) / 4;             // 21 DMA rounds of 4 waves
 constexpr unsigned WS_OOB = 0x80000000u;
 }  // namespace
 
@@ -68,9 +71,14 @@ extern "C" int tg_debug_ws_trace(unsigned long long* out) {
 #define WS_STAMP(i) do { } while (0)
 #endif
 
-template <bool HAS_RES, bool HAS_AUX>
+// WLDS: the 9 x 64 x 64 weight panel of the workgroup's channel block comes in ONCE by LDS-DMA (73 KB + row padding) and
+// the four waves read their 36 fragments from LDS, instead of every wave pulling its own 36 KB from L2 into registers
+// through the texture path (144 KB per workgroup, 10k cycles of the prologue, tools/trace_ws.py) -- for launches with one
+// workgroup per CU and a handful of tiles each (the 1080p inference convs: 4 tiles per CU), where the prologue is a
+// quarter of the kernel.  83 KB more LDS: not with TG_CONV_COEXIST (no room left for a chain workgroup).
+template <bool HAS_RES, bool HAS_AUX, bool WLDS>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF [+ WS_WPANEL]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;                  // 2 x 2 waves: 4 pixel rows x 32 channels each
@@ -126,6 +134,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   //      loads first -- at kernel start every wave of the chip pulls its 36 KB through the texture path at once and the
   //      full drain cost 13k of the 23k prologue cycles (tools/trace_ws.py).
   u32x4w wf[9][2][2];
+  if constexpr (WLDS) {
+    // panel row R = tap * 64 + channel (of this block), 144-byte pitch as the halo; slot S = instruction * 64 + lane
+    unsigned char* wp = smem + 2 * WS_BUF;
+#pragma unroll
+    for (int k = 0; k < WS_WROUNDS; ++k) {
+      const int inst = wave + 4 * k;
+      if (k + 1 < WS_WROUNDS || inst < WS_WINST) {                          // wave-uniform
+        const int S = inst * 64 + lane;
+        const int R = S / 9, c = S - 9 * R;
+        const int tap = R >> 6, co = blockIdx.y * 64 + (R & 63);
+        const int wt = p.flip ? 8 - tap : tap;
+        const bool ok = R < 576 && c < 8 && c * 8 < p.Cin && co < p.Cout;
+        const unsigned off = ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + c * 8) * 2) : WS_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_void*)(wp + inst * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo and panel slots
+    __builtin_amdgcn_s_barrier();                              // everybody's
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            wf[kh * 3 + kw][kk][j] = *reinterpret_cast<const u32x4w*>(
+                wp + ((kh * 3 + kw) * 64 + wn * 32 + j * 16 + frow) * WS_ROWB + kk * 64 + fg * 16);
+  } else {
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -142,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
               rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
         }
       }
+  }
   float bv[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -157,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   // (vmcnt retires in issue order on gfx9-family parts) -- draining the stores too (vmcnt(0), or the vmcnt(0) that
   // __syncthreads() adds while a DMA is in flight) exposed a full store round trip per tile.  Hence also the raw s_barrier.
   WS_STAMP(2);                                              // weight loads issued
-  asm volatile("s_waitcnt vmcnt(36)" ::: "memory");         // first tile: this wave's DMA slots (all but the 36 weight loads)
+  if constexpr (!WLDS) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // first tile: this wave's DMA slots (all but the 36 weight loads)
   WS_STAMP(3);
   int buf = 0;
   [[maybe_unused]] int it = 0;
@@ -458,8 +496,28 @@ int tg_deconv3x3s2_ws_try(const tg_conv_desc* d, const void* in, const void* wei
 }
 
 template <bool HAS_RES, bool HAS_AUX>
+static void launch_ws_wlds(const ConvWsP& p, hipStream_t st) {
+  auto kern = conv3x3_ws_kernel<HAS_RES, HAS_AUX, true>;
+  constexpr int LDS = 2 * WS_BUF + WS_WPANEL;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  const int nt = p.Cout / 64;
+  int gx = p.ntiles;
+  const int cap = 256 / nt > 0 ? 256 / nt : 1;
+  if (gx > cap) gx = cap;
+  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_ws<res,aux>" : "conv3x3_ws<res>")
+                                           : (HAS_AUX ? "conv3x3_ws<aux>" : "conv3x3_ws<>");
+  const double px = (double)p.N * p.H * p.W;
+  TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
+            px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(256),
+            LDS, st, p);
+}
+
+template <bool HAS_RES, bool HAS_AUX>
 static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
-  auto kern = conv3x3_ws_kernel<HAS_RES, HAS_AUX>;
+  auto kern = conv3x3_ws_kernel<HAS_RES, HAS_AUX, false>;
   constexpr int LDS_MAX = 2 * WS_BUF + 32768;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
@@ -471,6 +529,11 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   // (measured at 1020 tiles: 16.4 us with one, 17.8 us with two; at 9728 tiles: 97 vs 95 us); TG_C3WS_PERCU forces it
   static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 0;      // A/B switch
   const int per_cu = coexist ? 1 : (per_cu_env ? (per_cu_env < 2 ? 1 : 2) : (p.ntiles >= 2048 ? 2 : 1));
+  static const bool wlds = getenv("TG_C3WS_WLDS") != nullptr && atoi(getenv("TG_C3WS_WLDS")) == 1;   // opt-in (A/B switch)
+  if (wlds && per_cu == 1 && !coexist) {
+    launch_ws_wlds<HAS_RES, HAS_AUX>(p, st);
+    return;
+  }
   const int LDS = per_cu == 1 ? LDS_MAX : 2 * WS_BUF;
   const int nt = p.Cout / 64;
   int gx = p.ntiles;
