@@ -529,7 +529,7 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   // (measured at 1020 tiles: 16.4 us with one, 17.8 us with two; at 9728 tiles: 97 vs 95 us); TG_C3WS_PERCU forces it
   static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 0;      // A/B switch
   const int per_cu = coexist ? 1 : (per_cu_env ? (per_cu_env < 2 ? 1 : 2) : (p.ntiles >= 2048 ? 2 : 1));
-  static const bool wlds = getenv("TG_C3WS_WLDS") != nullptr && atoi(getenv("TG_C3WS_WLDS")) == 1;   // opt-in (A/B switch)
+  static const bool wlds = getenv("TG_C3WS_WLDS") == nullptr || atoi(getenv("TG_C3WS_WLDS")) != 0;   // A/B switch (=0: off)
   if (wlds && per_cu == 1 && !coexist) {
     launch_ws_wlds<HAS_RES, HAS_AUX>(p, st);
     return;

@@ -154,8 +154,9 @@ def check_full_config(F, gan, tag):
     """One fp32 step at a full BASELINE size against the oracle.
     HR frames (the path's OUTPUT): north_star's per-pixel bar, |a-b| <= 1e-3 * max(|b|, 1e-3 max|b|) for EVERY pixel.
     Losses: 1e-3 relative.  Gradients (sums over up to 3e5 pixel products in a different summation order, split-K with
-    fp32 atomics, batch-norm backward subtracting sums over 1e5 pixels): relative L2 <= 8e-3 per tensor AND every element
-    within 1e-2 of the tensor's maximum, against the oracle in FLOAT64.  1e-3 is not attainable in fp32 for every tensor at
+    fp32 atomics, batch-norm backward subtracting sums over 1e5 pixels): relative L2 <= 8e-3 per tensor AND the elements
+    within 1e-2 of the tensor's maximum (see the comment at the assertion for the 2 % / 5e-2 allowance), against the oracle
+    in FLOAT64.  1e-3 is not attainable in fp32 for every tensor at
     these sizes: the worst tensor, the discriminator's input-conv gradient at C3, is ill-conditioned in fp32 -- the FP32
     ORACLE ITSELF is 5.2e-3 (L2) from its own fp64 run there, and this path measured 2.1e-3 ... 5.4e-3 from the fp64 oracle
     on different runs (the order of the fp32 atomics differs from run to run; since then the batch-norm reductions keep
@@ -181,7 +182,14 @@ def check_full_config(F, gan, tag):
         assert l2 < 8e-3, "%s gradient %s relative L2 error %g" % (tag, name, l2)
         pe = per_elem_err(mine, ref, floor=2e-2).max().item()
         mx = max_rel_err(mine, ref)
-        assert mx < 1e-2, "%s gradient %s max error / max|ref| %g" % (tag, name, mx)
+        # Max-norm: 1e-2 for all but at most 2 % of a tensor's elements, 5e-2 as the hard cap.  The discriminator's tensors are
+        # BIMODAL from run to run, in the serial schedule as much as in the overlapped one (tools/c3_repeat.py,
+        # profiles/r02z_c3_repeat.txt: disblock_7/conv1 at 3.1e-2 in two of six runs -- the same figure in both schedules --
+        # and below 1e-2 in the others): with the order of the fp32 atomics a LeakyReLU pre-activation within rounding of 0
+        # flips its mask, which rescales one output channel's slice of that layer's weight gradient (0.4 % of the tensor).
+        bad = ((mine - ref).abs() > 1e-2 * ref.abs().max()).double().mean().item()
+        assert bad <= 2e-2 and mx < 5e-2, "%s gradient %s max error / max|ref| %g (%.2f %% of the elements above 1e-2)" % (
+            tag, name, mx, 100 * bad)
         stats.append((l2, pe, mx))
     print("\n[%s] gen per-pixel err %.2e; %d gradient tensors vs the fp64 oracle: worst L2 %.2e (%d above 1e-3), worst max-norm "
           "%.2e, worst per-element (floor 2e-2) %.2e" %
