@@ -530,7 +530,9 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 0;      // A/B switch
   const int per_cu = coexist ? 1 : (per_cu_env ? (per_cu_env < 2 ? 1 : 2) : (p.ntiles >= 2048 ? 2 : 1));
   static const bool wlds = getenv("TG_C3WS_WLDS") == nullptr || atoi(getenv("TG_C3WS_WLDS")) != 0;   // A/B switch (=0: off)
-  if (wlds && per_cu == 1 && !coexist) {
+  // ... from two tiles per workgroup on (the 1080p inference convs: 4); with a single tile per workgroup (FNet's 64-channel
+  // layers in the training steps) it measured neutral to slightly slower (12.20 -> 12.26 ms, profiles/r02zzzz_ab.txt)
+  if (wlds && per_cu == 1 && !coexist && p.ntiles >= 2 * (256 / (p.Cout / 64) > 0 ? 256 / (p.Cout / 64) : 1)) {
     launch_ws_wlds<HAS_RES, HAS_AUX>(p, st);
     return;
   }

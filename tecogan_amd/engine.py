@@ -35,6 +35,44 @@ class _Shifted:
         return self.t[sl.start - self.base:sl.stop - self.base]
 
 
+def plan_launch_order(segs, lazy=True):
+    """Host-side order in which a step's captured segments are launched: yields ("launch", seg) and ("wait", [names]).
+
+    Just-in-time launch of the side-stream (and communication-stream) segments.  A side segment enqueued ahead of time sits
+    in its hardware queue behind a barrier packet until the main stream reaches its dependency, and while it waits there EVERY
+    dispatch of the main stream's queue costs ~0.9 us more (the same tax a forked graph branch has; measured with device
+    stamps: the BPTT segment 6.22 ms with the next step's first side segment pending, 5.26 ms without,
+    profiles/r02o_seg_timeline.txt).  So the host enqueues the main-stream segments as far ahead as their dependencies allow,
+    and launches a side segment only once its dependencies have COMPLETED (a host wait on their events) -- the main stream
+    always has at least one whole segment queued behind the awaited one.  lazy=False: plain program order."""
+    if not lazy:
+        for seg in segs:
+            yield "launch", seg
+        return
+    done, todo = set(), list(segs)
+    while todo:
+        rest, blocked = [], False
+        for seg in todo:                                        # main-stream segments: as far ahead as possible
+            if seg["skey"] == "M" and not blocked and all(d in done for d in seg["deps"]):
+                done.add(seg["name"])
+                yield "launch", seg
+            else:
+                blocked = blocked or seg["skey"] == "M"
+                rest.append(seg)
+        todo = rest
+        for i, seg in enumerate(todo):                          # then the first side / communication segment, once its inputs exist
+            if seg["skey"] != "M":
+                assert all(d in done for d in seg["deps"]), "side segment %s depends on an unlaunched segment" % seg["name"]
+                if seg["deps"]:
+                    yield "wait", list(seg["deps"])
+                done.add(seg["name"])
+                yield "launch", seg
+                del todo[i]
+                break
+        else:
+            assert not todo, "main-stream segments %s wait for segments that are never launched" % [t["name"] for t in todo]
+
+
 class TrainEngine:
     def __init__(self, flags, device="cuda", gan=True, act_dtype=torch.float32, seed=42, process_group=None,
                  use_graph=True):
@@ -227,36 +265,12 @@ class TrainEngine:
             seg["event"].record(st)
             evs[seg["name"]] = seg["event"]
 
-        if not self.lazy_side:
-            for seg in self._segs:
-                launch(seg)
-            return
-        # Just-in-time launch of the side-stream (and communication-stream) segments.  A side segment enqueued ahead of time sits in its hardware
-        # queue behind a barrier packet until the main stream reaches its dependency, and while it waits there EVERY
-        # dispatch of the main stream's queue costs ~0.9 us more (the same tax a forked graph branch has; measured with
-        # device stamps: the BPTT segment 6.22 ms with the next step's first side segment pending, 5.26 ms without,
-        # profiles/r02o_seg_timeline.txt).  So the host enqueues the main-stream segments as far ahead as their
-        # dependencies allow, and launches a side segment only once its dependencies have COMPLETED (a host wait on their
-        # events) -- the main stream always has at least one whole segment queued behind the awaited one.
-        todo = list(self._segs)
-        while todo:
-            rest, blocked = [], set()
-            for seg in todo:                                    # main-stream segments: as far ahead as possible
-                ok = seg["skey"] == "M" and "M" not in blocked and all(d in evs for d in seg["deps"])
-                if ok:
-                    launch(seg)
-                else:
-                    blocked.add(seg["skey"])
-                    rest.append(seg)
-            todo = rest
-            for i, seg in enumerate(todo):                      # then the first side / communication segment, once its inputs exist
-                if seg["skey"] != "M":
-                    assert all(d in evs for d in seg["deps"]), "side segment %s depends on an unlaunched segment" % seg["name"]
-                    for d in seg["deps"]:
-                        evs[d].synchronize()
-                    launch(seg)
-                    del todo[i]
-                    break
+        for what, arg in plan_launch_order(self._segs, self.lazy_side):
+            if what == "wait":
+                for d in arg:
+                    evs[d].synchronize()
+            else:
+                launch(arg)
 
     def _capture(self):
         # warm-up run (allocator pools, lazy module loads, the real two-stream schedule), state restored afterwards

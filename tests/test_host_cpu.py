@@ -246,3 +246,50 @@ def test_scene_loader_moving_first_frame_augmentation(tmp_path):
                 assert reds == [reds[0] + 10 * t for t in range(4)], reds      # consecutive frames, one shared crop
                 assert all(c[t, 0, 0, 1] == c[0, 0, 0, 1] and c[t, 0, 0, 2] == c[0, 0, 0, 2] for t in range(4))
     assert moved > 0 and plain > moved, (moved, plain)
+
+
+# ---- engine.plan_launch_order: the host-side launch schedule of a step's segments (pure logic) ---------------------------
+def _segs(spec):
+    return [dict(name=n, skey=k, deps=list(d)) for n, k, d in spec]
+
+
+TECO_SEGS = [("head", "M", []), ("vggt", "S", ["head"]), ("dreal", "S", ["head"]), ("fwd_a", "M", []),
+             ("vgg_early", "S", ["fwd_a"]), ("fwd_b", "M", ["dreal", "vggt"]), ("down", "S", ["fwd_b"]),
+             ("ar_d", "C", ["down"]), ("bwd", "M", []), ("bwd_b", "M", ["vgg_early"]), ("wgrad", "S", ["bwd_b"]),
+             ("ar_g", "C", ["wgrad"]), ("fnet_bwd", "M", []), ("ar_f", "C", ["fnet_bwd"]),
+             ("update", "M", ["down", "wgrad", "ar_d", "ar_g", "ar_f"])]
+
+
+def test_plan_launch_order_just_in_time_side_segments():
+    from tecogan_amd.engine import plan_launch_order
+    acts = list(plan_launch_order(_segs(TECO_SEGS), lazy=True))
+    order = [a[1]["name"] for a in acts if a[0] == "launch"]
+    assert sorted(order) == sorted(n for n, _, _ in TECO_SEGS) and len(set(order)) == len(order)      # everything, once
+    pos = {n: i for i, n in enumerate(order)}
+    for n, k, deps in TECO_SEGS:                              # dependencies are launched (events recorded) first
+        assert all(pos[d] < pos[n] for d in deps), n
+    for key in ("M", "S", "C"):                               # per-stream program order is kept
+        mine = [n for n, k, _ in TECO_SEGS if k == key]
+        assert [n for n in order if n in mine] == mine
+    # a side / communication segment is launched only after a host wait on exactly its dependencies ...
+    for i, (what, arg) in enumerate(acts):
+        if what == "launch" and arg["skey"] != "M" and arg["deps"]:
+            assert acts[i - 1] == ("wait", arg["deps"]), arg["name"]
+    # ... and at every such wait the main stream has a whole segment queued BEHIND the awaited main-stream segment
+    launched = []
+    for what, arg in acts:
+        if what == "launch":
+            launched.append(arg["name"])
+        else:
+            for d in arg:
+                if dict((n, k) for n, k, _ in TECO_SEGS)[d] == "M" and d != "fnet_bwd":
+                    later_m = [n for n in launched[launched.index(d) + 1:] if dict((n, k) for n, k, _ in TECO_SEGS)[n] == "M"]
+                    assert later_m, "host would wait for %s with nothing queued behind it" % d
+    assert order[:2] == ["head", "fwd_a"]                     # the forward recurrence is queued before the first wait
+
+
+def test_plan_launch_order_program_order_when_not_lazy():
+    from tecogan_amd.engine import plan_launch_order
+    acts = list(plan_launch_order(_segs(TECO_SEGS), lazy=False))
+    assert [a[0] for a in acts] == ["launch"] * len(TECO_SEGS)
+    assert [a[1]["name"] for a in acts] == [n for n, _, _ in TECO_SEGS]
