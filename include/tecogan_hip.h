@@ -95,6 +95,10 @@ typedef struct tg_conv_desc {
  * register footprint leaves room for a co-resident chain workgroup (3x3: <8,64> = 109 KB / ~300 registers instead of
  * <16,64> = 130 KB / ~400; measured: 87 % of the chain hides under VGG-sized convs, profiles/r02a_overlap.txt). */
 #define TG_CONV_COEXIST 1
+/* The launch owns the chip: wide 3x3 layers may use the deep-prefetch variant (three weight-panel buffers + two halo
+ * buffers, 150 KB of LDS; conv3x3_dma.hip).  Ignored together with TG_CONV_COEXIST.  Round 2: not yet validated on the
+ * GPU -- nothing in this repository sets it. */
+#define TG_CONV_DEEP_PREFETCH 2
 
 int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*[KH*KW][Cout][Cin]*/,
                     const float* bias /*nullable*/, const void* res /*nullable*/,

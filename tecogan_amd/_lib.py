@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libtecogan_hip.so")
 TG_F32, TG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 CONV_COEXIST = 1
+CONV_DEEP_PREFETCH = 2
 
 
 class ConvDesc(C.Structure):

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import CONV_COEXIST, ConvDesc, TG_BF16, TG_F32, check, lib  # noqa: F401
+from ._lib import CONV_COEXIST, CONV_DEEP_PREFETCH, ConvDesc, TG_BF16, TG_F32, check, lib  # noqa: F401
 
 
 def _stream():

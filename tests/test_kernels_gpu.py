@@ -967,8 +967,14 @@ DMA_CASES = [
 ]
 
 
+UNVALIDATED = pytest.mark.skipif(os.environ.get("TG_TEST_UNVALIDATED") != "1",
+                                 reason="kernel variant written after the round's GPU budget was spent: not yet run on a GPU "
+                                        "(TG_TEST_UNVALIDATED=1 runs it)")
+
+
 @pytest.mark.parametrize("case", DMA_CASES)
-def test_conv3x3_wide_layer_dma_kernel(case):
+@pytest.mark.parametrize("deep", [0, pytest.param(1, marks=UNVALIDATED)])
+def test_conv3x3_wide_layer_dma_kernel(case, deep):
     N, H, W, Cin, Cout, flip, has_res, has_aux, act = case
     x = rnd(N, H, W, Cin, seed=1).bfloat16()
     w = rnd(3, 3, Cin, Cout, seed=2, scale=0.05).bfloat16()
@@ -988,7 +994,7 @@ def test_conv3x3_wide_layer_dma_kernel(case):
     wt = w.permute(0, 1, 3, 2).reshape(9, Cout, Cin).contiguous().to(DEV)
     out = torch.full((N, H, W, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
     d = K.conv_desc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1 if flip else 0, TG_BF16, TG_BF16, act, alpha,
-                    ACT_RELU if has_aux else ACT_NONE, 0.0)
+                    ACT_RELU if has_aux else ACT_NONE, 0.0, flags=K.CONV_DEEP_PREFETCH if deep else 0)
     K.prof_collect()
     K.prof_enable(True)
     K.conv_forward(d, x.to(DEV), wt, None if b is None else b.to(DEV), None if res is None else res.to(DEV),
@@ -996,9 +1002,11 @@ def test_conv3x3_wide_layer_dma_kernel(case):
     K.prof_enable(False)
     ents = K.prof_collect()
     assert ents and ents[0]["name"].startswith("conv3x3_dma"), "the wide-layer DMA kernel was not selected: %s" % ents
+    if deep:
+        assert ents[0]["name"].startswith("conv3x3_dma3"), ents[0]["name"]
     ntiles = N * ((H + 15) // 16) * ((W + 15) // 16)
     pair = os.environ.get("TG_C3DMA_PAIR") == "1" and (ntiles + 1) // 2 * (Cout // 64) >= 224
-    assert ents[0]["name"].startswith("conv3x3_dma2") == pair, ents[0]["name"]
+    assert deep or ents[0]["name"].startswith("conv3x3_dma2") == pair, ents[0]["name"]
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
 
