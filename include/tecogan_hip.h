@@ -196,6 +196,14 @@ int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void*
                               float* out /*nullable if state*/, float* state /*nullable*/, int B, int h, int w,
                               void* stream);
 
+/* Fused HR tail of generator_F, bf16, throughput regime (lib/frvsr.py:73-87, main.py:207): second transposed conv + ReLU,
+ * output conv 64 -> 3, bicubic_four(LR) skip, value ranges -- the 64-channel HR tensor stays on chip (csrc/hr_tail.hip).
+ * t1 [N,h2,w2,64] bf16 (output of the first transposed conv), w_tran [9][64][64] in TF's [kh,kw,Cout,Cin] layout,
+ * w_out [9][3][64]; gen_in as in tg_bicubic_add_preprocess; out / state as there (either may be NULL, not both).
+ * Round 2: written after the round's GPU budget was spent -- NOT yet validated on hardware; nothing calls it by default. */
+int tg_hr_tail_forward(const void* t1, const void* w_tran, const float* b_tran, const void* w_out, const float* b_out,
+                       const void* gen_in, int Cpad, float* out, float* state, int N, int h2, int w2, void* stream);
+
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.
  * d_out and y share in_dtype; d_in has out_dtype. */

@@ -147,6 +147,16 @@ def bicubic_add_preprocess(conv_out, gen_in, out, state=None):
     return out if out is not None else state
 
 
+def hr_tail_forward(t1, w_tran, b_tran, w_out, b_out, gen_in, out, state=None):
+    """Fused second transposed conv + ReLU + output conv + bicubic skip + value ranges (csrc/hr_tail.hip; bf16 only).
+    t1 [N,h2,w2,64]; out / state fp32 [N,2 h2,2 w2,3] (either may be None).  Not yet validated on hardware (round 2)."""
+    N, h2, w2, C = t1.shape
+    assert C == 64 and t1.dtype == torch.bfloat16 and gen_in.dtype == torch.bfloat16
+    check(lib().tg_hr_tail_forward(_p(t1), _p(w_tran), _p(b_tran), _p(w_out), _p(b_out), _p(gen_in), gen_in.shape[-1], _p(out),
+                                   _p(state), N, h2, w2, _stream()), "tg_hr_tail_forward")
+    return out if out is not None else state
+
+
 def act_backward(d_out, y, d_in, act=0, alpha=0.0, scale=1.0):
     check(lib().tg_act_backward(_p(d_out), _p(y), _p(d_in), dt(d_out), dt(d_in), d_out.numel(), act, alpha, scale,
                                 _stream()), "tg_act_backward")

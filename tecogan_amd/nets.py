@@ -135,6 +135,7 @@ class Generator:
         # of another stream shares the chip, so that the chain's bigger launches (HR deconv, output conv) also pick tile
         # shapes that fit NEXT to a resident VGG workgroup instead of waiting for a CU to drain
         self.chain_flags = 0
+        self.hr_tail = os.environ.get("TG_HR_TAIL") == "1"      # fused HR tail of the stateless (inference) forward: opt-in
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -150,6 +151,16 @@ class Generator:
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
         t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU)
+        if self.hr_tail and t1.dtype == torch.bfloat16:
+            # fused HR tail (csrc/hr_tail.hip): the 64-channel HR tensor t2 is never written.  OPT-IN (TG_HR_TAIL=1) until
+            # the kernel has been validated on hardware.
+            wo, bo = p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases"
+            N, h2, w2, _ = t1.shape
+            o = None if out is False else (torch.empty(N, 2 * h2, 2 * w2, 3, device=t1.device) if out is None else out)
+            assert o is not None or state is not None
+            r = K.hr_tail_forward(t1, ps.packed(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
+                                  ps.view(bo), x_in, o, state)
+            return r, None
         t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU)
         c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1,
                      out_dtype=_F32)
