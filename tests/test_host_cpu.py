@@ -293,3 +293,73 @@ def test_plan_launch_order_program_order_when_not_lazy():
     acts = list(plan_launch_order(_segs(TECO_SEGS), lazy=False))
     assert [a[0] for a in acts] == ["launch"] * len(TECO_SEGS)
     assert [a[1]["name"] for a in acts] == [n for n, _, _ in TECO_SEGS]
+
+
+def test_engine_replay_executes_the_plan_with_streams_and_events(monkeypatch):
+    """TrainEngine._replay on fake streams / graphs / events: every segment replays once on its own stream, after waiting on
+    its dependencies' events there, records its event, and side segments are preceded by a host wait on their dependencies."""
+    import contextlib
+    import types
+
+    import torch
+
+    from tecogan_amd.engine import TrainEngine
+    log = []
+
+    class Stream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append(("stream_wait", self.name, ev.name))
+
+    class Event:
+        def __init__(self, name):
+            self.name = name
+
+        def record(self, st):
+            log.append(("record", self.name, st.name))
+
+        def synchronize(self):
+            log.append(("host_wait", self.name))
+
+    class Graph:
+        def __init__(self, name):
+            self.name = name
+
+        def replay(self):
+            log.append(("replay", self.name, current[-1].name))
+
+    main, side, comm = Stream("M"), Stream("S"), Stream("C")
+    current = [main]
+
+    @contextlib.contextmanager
+    def stream_ctx(st):
+        current.append(st)
+        try:
+            yield
+        finally:
+            current.pop()
+
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: current[-1])
+    monkeypatch.setattr(torch.cuda, "stream", stream_ctx)
+    segs = [dict(name=n, skey=k, deps=list(d), graph=Graph(n), fn=None, event=Event(n)) for n, k, d in TECO_SEGS]
+    for lazy in (True, False):
+        del log[:]
+        eng = types.SimpleNamespace(_segs=segs, streams={"S": side, "C": comm}, lazy_side=lazy)
+        TrainEngine._replay(eng)
+        replays = [e for e in log if e[0] == "replay"]
+        assert sorted(r[1] for r in replays) == sorted(n for n, _, _ in TECO_SEGS)
+        for _, name, st in replays:                             # on its own stream
+            assert st == dict((n, k) for n, k, _ in TECO_SEGS)[name]
+        for n, k, deps in TECO_SEGS:
+            i = log.index(("replay", n, k))
+            for d in deps:
+                if dict((a, b) for a, b, _ in TECO_SEGS)[d] != k or True:
+                    assert ("stream_wait", k, d) in log[:i], (n, d)          # device-side wait before the replay
+                    assert log.index(("record", d, dict((a, b) for a, b, _ in TECO_SEGS)[d])) < log.index(("stream_wait", k, d))
+                if lazy and k != "M":
+                    assert ("host_wait", d) in log[:i], (n, d)
+            assert log[i + 1] == ("record", n, k)
+        if not lazy:
+            assert not [e for e in log if e[0] == "host_wait"]
