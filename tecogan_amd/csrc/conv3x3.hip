@@ -425,8 +425,12 @@ static void launch3(Conv3P p, hipStream_t st) {
   if (gx > per) gx = per;
   static const char* const pname = [] {
     static char b[96];
-    snprintf(b, sizeof(b), PACK > 1 ? "conv3x3_tile<%s,%s,%d,%d,pack%d>" : "conv3x3_tile<%s,%s,%d,%d>",
-             sizeof(TIn) == 2 ? "bf16" : "f32", sizeof(TOut) == 2 ? "bf16" : "f32", TH, BN, PACK);
+    if constexpr (PACK > 1)
+      snprintf(b, sizeof(b), "conv3x3_tile<%s,%s,%d,%d,pack%d>", sizeof(TIn) == 2 ? "bf16" : "f32",
+               sizeof(TOut) == 2 ? "bf16" : "f32", TH, BN, PACK);
+    else
+      snprintf(b, sizeof(b), "conv3x3_tile<%s,%s,%d,%d>", sizeof(TIn) == 2 ? "bf16" : "f32", sizeof(TOut) == 2 ? "bf16" : "f32",
+               TH, BN);
     return (const char*)b;
   }();
   const double px = (double)p.N * p.H * p.W;
