@@ -806,6 +806,9 @@ static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, cons
   return tg_wgrad_row3_launch(d, 1, &x, ldx, &y, ldy, &dw, dbias ? &dbias : nullptr, st);
 }
 
+int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
+                       float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip (opt-in, TG_WGRAD_TR=1)
+
 extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
                                      const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
                                      void* stream) {
@@ -815,6 +818,7 @@ extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const vo
   bool fast = d->mode == 0 && x_dtype == TG_BF16 && y_dtype == TG_BF16 && lx % 8 == 0 && ly % 8 == 0 && lx >= d->Cin &&
               ly >= d->Cout && getenv("TG_NO_WGRAD_BF16") == nullptr;
   for (int g = 0; g < groups && fast; ++g) fast = ((((uintptr_t)x[g] | (uintptr_t)y[g])) & 15) == 0;
+  if (fast && tg_wgrad_tr_launch(d, groups, x, lx, y, ly, dw, dbias, static_cast<hipStream_t>(stream))) TG_CHECK_LAUNCH();
   if (fast && tg_wgrad_row3_launch(d, groups, x, lx, y, ly, dw, dbias, static_cast<hipStream_t>(stream)))
     TG_CHECK_LAUNCH();
   for (int g = 0; g < groups; ++g) {                        // any other geometry / dtype: one ordinary launch per layer

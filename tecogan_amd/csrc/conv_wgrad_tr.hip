@@ -1,0 +1,227 @@
+// Weight gradient of the 3x3 stride-1 SAME convolutions of the generator trunk (reference lib/frvsr.py:50-57 under
+// tf.gradients, lib/Teco.py:438-449) with TRANSPOSE READS -- gfx950, bf16, 64 -> 64 channels, 32-pixel-wide images:
+//
+//     dW[kh][kw][ci][co] = sum over (n, y, x) of  X[n, y+kh-1, x+kw-1, ci] * dY[n, y, x, co]          (X zero outside the image)
+//
+// The GEMM's K dimension is the PIXEL index, the slow axis of both operands in memory (NHWC).  conv_wgrad_row3_bf16_kernel
+// (conv_wgrad.hip) transposes both operands through registers into LDS and is bound by the issue rate of that staging code
+// (160 TFLOP/s, 11 % MFMA busy, profiles/r02u_*).  Here the [pixel][channel] tiles stay in their natural layout:
+//   * a stage = 8 image rows x 32 pixels: the X halo tile (10 x 34 pixels x 64 channels, 43 KB) and the dY tile (32 KB)
+//     arrive by LDS-DMA into a double buffer (2 x 75 KB), the next stage's DMA issued between the MFMA groups;
+//   * MFMA operands come from ds_read_b64_tr_b16 (builtin __builtin_amdgcn_ds_read_tr16_b64_v4i16): lane i of a 16-lane
+//     group receives M[4j + i/4][i%4], j = 0..3, where M[L] are the 4 consecutive 16-bit elements lane L points at -- so
+//     lane L = 4*row + chunk addresses (pixel k0 + L/4, channels c0 + 4*(L%4) ..) and lane i gets channel c0 + i of pixels
+//     k0 .. k0+3; two reads = the 8 K-values a lane feeds v_mfma_f32_16x16x32_bf16 (A: X, rows = ci; B: dY, columns = co);
+//   * a workgroup owns the full 64 x 64 block of ONE layer for all 9 taps: per 32-pixel chunk (one image row of the tile) a
+//     wave (32 ci x 32 co quadrant) reads its dY fragments once (4 reads) and its X fragments per tap (36 reads) for 36
+//     MFMAs; all 36 accumulators (144 VGPRs) stay in registers over the whole pixel range of the workgroup (split-K over
+//     tiles), and are added to dW with fp32 atomics once at the end; the bias gradient is one extra MFMA per fragment
+//     with an all-ones A operand in the waves of the first ci half.
+// Grouped like the row kernel: `groups` layers of identical geometry in one launch.
+//
+// Round-2 status: written after the round's GPU budget was spent, on the guide's description of the transpose read
+// (tools/probe_tr.hip checks it on hardware first).  Opt-in: TG_WGRAD_TR=1; GPU test gated behind TG_TEST_UNVALIDATED=1.
+#include "common.h"
+#include <mutex>
+#include <stdlib.h>
+
+#define TG_WTR_MAX_GROUPS 40
+struct WgradTrP {
+  const u16* xs[TG_WTR_MAX_GROUPS];
+  const u16* ys[TG_WTR_MAX_GROUPS];
+  float* dws[TG_WTR_MAX_GROUPS];
+  float* dbs[TG_WTR_MAX_GROUPS];
+  int groups, nsplit;
+  int N, H;             // images, rows; W = 32, channels = 64 on both sides
+  int ntiles;           // N * H / 8
+  unsigned bytes;       // extent of every X / dY tensor
+};
+
+typedef short s16x4t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4t lds_s16x4;
+
+namespace {
+constexpr int TR_W = 32, TR_TH = 8, TR_PIX = 128;                      // bytes per pixel (64 bf16 channels)
+constexpr int TR_XSLOTS = (TR_TH + 2) * (TR_W + 2) * 8;               // 2720 16-byte slots of the X halo tile
+constexpr int TR_XINST = (TR_XSLOTS + 63) / 64;                       // 43 wave-wide DMA instructions
+constexpr int TR_YINST = TR_TH * TR_W * 8 / 64;                       // 32
+constexpr int TR_YOFF = TR_XINST * 1024;                              // 44032
+constexpr int TR_STAGE = (TR_XINST + TR_YINST) * 1024;                // 76800
+constexpr int TR_XROUNDS = (TR_XINST + 3) / 4, TR_YROUNDS = TR_YINST / 4;   // 11 + 8 DMA rounds of 4 waves
+constexpr unsigned TR_OOB = 0x80000000u;
+}  // namespace
+
+// 8 consecutive K-values (pixels) of one channel for this lane: two transpose reads, 4 pixels apart
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+  const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * TR_PIX));
+  typedef short s16x8t __attribute__((ext_vector_type(8)));
+  const s16x8t v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x TR_STAGE
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                  // ci half / co half of the 64 x 64 block
+  const int frow = lane & 15, fg = lane >> 4;
+  const int grp = blockIdx.x / p.nsplit, split = blockIdx.x - grp * p.nsplit;
+  const u16* __restrict__ gx = p.xs[grp];
+  const u16* __restrict__ gy = p.ys[grp];
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.bytes, 0x00020000);
+  const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.bytes, 0x00020000);
+  const int tiles_y = p.H / TR_TH;
+
+  // ---- DMA slot descriptors.  X: slot S = (wave + 4k)*64 + lane -> halo pixel S / 8 = (dy, dx), 16-byte channel chunk S % 8
+  int xrel[TR_XROUNDS], xcode[TR_XROUNDS];
+#pragma unroll
+  for (int k = 0; k < TR_XROUNDS; ++k) {
+    const int S = (wave + 4 * k) * 64 + lane;
+    const int q = S >> 3, c = S & 7;
+    const int dy = q / (TR_W + 2), dx = q - (TR_W + 2) * dy;
+    xrel[k] = ((dy - 1) * TR_W + dx - 1) * TR_PIX + c * 16;
+    xcode[k] = dy | (dx << 8) | (S < TR_XSLOTS ? (1 << 16) : 0);
+  }
+  auto issue_dma = [&](int tile, int buf, int r0, int r1) {          // DMA rounds [r0, r1) of the stage (compile-time bounds)
+    const int n = tile / tiles_y, y0 = (tile - n * tiles_y) * TR_TH;
+    const int base = (n * p.H + y0) * TR_W * TR_PIX;                        // wave-uniform: byte offset of the tile's pixel (0,0)
+    unsigned char* dst = smem + buf * TR_STAGE;
+#pragma unroll
+    for (int r = r0; r < r1; ++r) {
+      if (r < TR_XROUNDS) {
+        const int inst = wave + 4 * r;
+        if (r + 1 < TR_XROUNDS || inst < TR_XINST) {
+          const int dy = xcode[r] & 255, dx = (xcode[r] >> 8) & 255;
+          const bool ok = (xcode[r] >> 16) && (unsigned)(y0 + dy - 1) < (unsigned)p.H && (unsigned)(dx - 1) < (unsigned)TR_W;
+          const unsigned off = ok ? (unsigned)(base + xrel[r]) : TR_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_t*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
+        }
+      } else {                                                              // dY tile: 32 KB contiguous in memory
+        const int inst = wave + 4 * (r - TR_XROUNDS);
+        const unsigned off = (unsigned)(base + inst * 1024 + lane * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_void_t*)(dst + TR_YOFF + inst * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  int tile = split;
+  if (tile >= p.ntiles) return;                             // (workgroup-uniform; its accumulators would be zero)
+  issue_dma(tile, 0, 0, TR_XROUNDS + TR_YROUNDS);
+
+  // ---- per-lane fragment bases: lane L = frow of group fg points at pixel 8 fg + L/4 (+4 for the second read), channels
+  //      c0 + 4 (L % 4); everything else (image row, tap shift, 16-channel tile) is a compile-time offset
+  const int lp = 8 * fg + (frow >> 2), lc = 4 * (frow & 3);
+  const int abase = lp * TR_PIX + (32 * wm + lc) * 2;       // halo (row 0, column lp) = image (y0 - 1, lp - 1): tap (0, 0) of row 0
+  const int bbase = TR_YOFF + lp * TR_PIX + (32 * wn + lc) * 2;
+
+  f32x4 acc[9][2][2];
+  f32x4 accb[2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  accb[0] = accb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef short s16x8o __attribute__((ext_vector_type(8)));
+  const s16x8o ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  const bool do_bias = p.dbs[grp] != nullptr && wm == 0;    // wave-uniform
+
+  int buf = 0;
+  while (true) {
+    const int ntile = tile + p.nsplit;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slots of the stage
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // everybody's; nobody still reads the other buffer
+    const bool has_next = ntile < p.ntiles;
+    const unsigned char* sb = smem + buf * TR_STAGE;
+#pragma unroll
+    for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
+      bf16x8 bq[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bq[j] = tr_frag(sb + bbase + yy * TR_W * TR_PIX + j * 32);
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          bf16x8 aq[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            aq[i] = tr_frag(sb + abase + ((yy + kh) * (TR_W + 2) + kw) * TR_PIX + i * 32);      // image (y0+yy+kh-1, lp+kw-1)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[kh * 3 + kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[j], acc[kh * 3 + kw][i][j], 0, 0, 0);
+        }
+      // the next stage's 19 DMA rounds spread over the 8 rows (an LDS-DMA instruction costs 60-180 issue cycles)
+      if (has_next) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (yy < 7) issue_dma(ntile, buf ^ 1, yy * 3, yy * 3 + 3 < TR_XROUNDS + TR_YROUNDS ? yy * 3 + 3 : TR_XROUNDS + TR_YROUNDS);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!has_next) break;
+    tile = ntile;
+    buf ^= 1;
+  }
+
+  // ---- split-K reduction: D row 4 fg + r = input channel, column frow = output channel
+  float* __restrict__ dw = p.dws[grp];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = 32 * wm + 16 * i + 4 * fg + r, co = 32 * wn + 16 * j + frow;
+          unsafeAtomicAdd(dw + (t * 64 + ci) * 64 + co, acc[t][i][j][r]);
+        }
+  if (do_bias && fg == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) unsafeAtomicAdd(p.dbs[grp] + 32 * wn + 16 * j + frow, accb[j][0]);
+  }
+}
+
+// returns 1 if launched (opt-in; geometry of the generator trunk only), 0 otherwise
+int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
+                       float* const* dw, float* const* dbias, hipStream_t st) {
+  static const bool enabled = getenv("TG_WGRAD_TR") != nullptr && atoi(getenv("TG_WGRAD_TR")) == 1;
+  if (!enabled || groups < 1 || groups > TG_WTR_MAX_GROUPS) return 0;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->mode != 0) return 0;
+  if (d->Win != TR_W || d->Wout != TR_W || d->Hin != d->Hout || d->Hin % TR_TH != 0) return 0;
+  if (d->Cin != 64 || d->Cout != 64 || ldx != 64 || ldy != 64) return 0;
+  const int64_t bytes = (int64_t)d->N * d->Hin * TR_W * TR_PIX;
+  if (bytes >= ((int64_t)1 << 31)) return 0;
+  WgradTrP p;
+  for (int g = 0; g < TG_WTR_MAX_GROUPS; ++g) {
+    const int k = g < groups ? g : 0;
+    p.xs[g] = (const u16*)x[k]; p.ys[g] = (const u16*)y[k]; p.dws[g] = dw[k]; p.dbs[g] = dbias ? dbias[k] : nullptr;
+  }
+  p.groups = groups;
+  p.N = d->N; p.H = d->Hin;
+  p.ntiles = d->N * (d->Hin / TR_TH);
+  p.bytes = (unsigned)bytes;
+  int nsplit = 256 / groups;                                // one workgroup per CU (150 KB of LDS)
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > p.ntiles) nsplit = p.ntiles;
+  p.nsplit = nsplit;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * TR_STAGE);
+  });
+  const double M = (double)d->N * d->Hin * TR_W;
+  TG_LAUNCH("conv_wgrad_tr", 2.0 * groups * M * 9.0 * 64 * 64, groups * (M * 2.0 * TR_PIX + 36.0 * 64 * 64), conv_wgrad_tr_kernel,
+            dim3((unsigned)(groups * nsplit)), dim3(256), 2 * TR_STAGE, st, p);
+  return 1;
+}

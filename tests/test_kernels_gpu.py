@@ -1061,3 +1061,31 @@ def test_hr_tail_fused_matches_the_three_kernel_path(shape):
     state2 = torch.full_like(out, 7.0)
     K.hr_tail_forward(t1.to(DEV), w_tran, bt.to(DEV), w_out, bo.to(DEV), gen_in.to(DEV), None, state2)
     assert torch.equal(state2.cpu(), state.cpu())
+
+
+# ---- csrc/conv_wgrad_tr.hip: weight gradients with transpose reads (opt-in TG_WGRAD_TR=1, not yet validated on hardware) --
+@UNVALIDATED
+@pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") != "1", reason="the transpose-read weight-gradient kernel is selected by TG_WGRAD_TR=1")
+@pytest.mark.parametrize("case", [(1, 2, 8), (3, 5, 32), (32, 76, 32)])
+def test_wgrad_transpose_read_kernel_matches_autograd(case):
+    """dW / dbias of 3x3 s1 SAME 64 -> 64 convs on 32-pixel-wide images (the generator trunk, lib/frvsr.py:50-57) against
+    torch autograd on the bf16-rounded operands; several layers per launch, image counts that do and do not divide by the split."""
+    G, N, H = case
+    d = K.conv_desc(N, H, 32, 64, H, 32, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16)
+    xs = [rnd(N, H, 32, 64, seed=10 + g).bfloat16() for g in range(G)]
+    ys = [rnd(N, H, 32, 64, seed=50 + g).bfloat16() for g in range(G)]
+    got_w = [torch.full((3, 3, 64, 64), 0.5, device=DEV) for _ in range(G)]
+    got_b = [torch.zeros(64, device=DEV) for _ in range(G)]
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_wgrad_grouped(d, [x.to(DEV) for x in xs], [y.to(DEV) for y in ys], got_w, got_b)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"] == "conv_wgrad_tr", ents
+    for g in (0, G - 1):
+        xr = xs[g].float().requires_grad_()
+        w = torch.zeros(3, 3, 64, 64, requires_grad=True)
+        b = torch.zeros(64, requires_grad=True)
+        O.conv2(xr, w, b, 1).backward(ys[g].float())
+        close(got_w[g] - 0.5, w.grad, 3e-4, "transpose-read dW layer %d %s" % (g, case))
+        close(got_b[g], b.grad, 3e-4, "transpose-read dbias layer %d %s" % (g, case))
