@@ -166,18 +166,22 @@ def run_training(FLAGS):
             raise ValueError('one of max_epoch or max_iter should be provided')
         max_iter = FLAGS.max_epoch * rdata.steps_per_epoch
     step, run_step, start = 0, eng.global_step(), time.time()
-    avg = None
+    # running averages of the loss slots as the reference prints them (update_list_avg, lib/Teco.py: EMA 0.99 updated every
+    # step, zero-initialised): one tiny device-side kernel per step, read only on display steps
+    from tecogan_amd import kernels as K
+    avg_raw, n_avg = torch.zeros_like(eng.loss), 0
     x, y = rdata.s_inputs, rdata.s_targets
     try:
         for step in range(max_iter):
             run_step = eng.global_step() + 1 if step == 0 else run_step + 1
             eng.step(x, y)
+            K.lincomb(avg_raw, eng.loss, avg_raw, 0.99, 0.01)
+            n_avg += 1
             x, y = rdata.loader.next_batch()                     # next batch is prepared while the GPU runs
             if step == 0 and rank == 0:
                 print('Optimization starts!!!(Ctrl+C to stop, will try saving the last model...)')
             if rank == 0 and (run_step % FLAGS.display_freq) == 0:
-                L = eng.losses()
-                avg = dict(L) if avg is None else {k: avg[k] - 0.01 * (avg[k] - v) for k, v in L.items()}
+                L = eng.losses(avg_raw, 1.0 - 0.99 ** n_avg)
                 rate = world * (step + 1) * FLAGS.batch_size / (time.time() - start)
                 remaining = (max_iter - step) * world * FLAGS.batch_size / rate
                 print("progress  epoch %d  step %d  image/sec %0.1fx%02d  remaining %dh%dm" %

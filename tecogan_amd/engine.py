@@ -615,10 +615,13 @@ class TrainEngine:
                 gd["d_layers"].append(d)
 
     # ------------------------------------------------------------------------------------------
-    def losses(self):
-        """Loss values of the last step under the reference's names (lib/Teco.py update_list_name)."""
+    def losses(self, vec=None, one=1.0):
+        """Loss values under the reference's names (lib/Teco.py update_list_name): of the last step, or -- with `vec` a
+        zero-initialised 0.99-EMA of the raw loss slots and `one` = 1 - 0.99^updates -- the running averages the reference
+        prints (update_list_avg: tf.train.ExponentialMovingAverage(0.99) over tensors starts from 0, no debiasing; every
+        reported quantity is affine in the slots, `one` is the EMA of the constant 1 in `1 - mean cos`)."""
         F = self.F
-        raw = OrderedDict(zip(LOSS_NAMES, self.loss.detach().cpu().tolist()))
+        raw = OrderedDict(zip(LOSS_NAMES, (self.loss if vec is None else vec).detach().cpu().tolist()))
         out = OrderedDict()
         gen_loss = raw["l2_content_loss"]
         if self.gan and F.D_LAYERLOSS:
@@ -631,7 +634,7 @@ class TrainEngine:
         if self.use_vgg:
             tot = 0.0
             for k in range(2, 6):
-                out["vgg_loss_%d" % k] = 1.0 - raw["vgg_loss_%d" % k]      # slots hold mean cos
+                out["vgg_loss_%d" % k] = one - raw["vgg_loss_%d" % k]      # slots hold mean cos
                 tot += out["vgg_loss_%d" % k]
             out["vgg_all"] = tot
             gen_loss += F.vgg_scaling * tot
