@@ -1,5 +1,5 @@
-"""Lane-level CPU emulations of the two kernels that were written after round 2's GPU budget was spent (csrc/hr_tail.hip,
-csrc/conv_wgrad_tr.hip): LDS images, fragment addresses, MFMA operand / accumulator lane layouts, the documented semantic of
+"""Lane-level CPU emulations of the kernels that were written after round 2's GPU budget was spent (csrc/hr_tail.hip,
+csrc/conv_wgrad_tr.hip, conv3x3_dma3_kernel of csrc/conv3x3_dma.hip): LDS images, fragment addresses, MFMA operand / accumulator lane layouts, the documented semantic of
 ds_read_b64_tr_b16, tile coverage and store masks, checked against the oracle / autograd.  They are what stands in for a GPU
 parity run of those kernels until round 3 (their GPU tests are gated behind TG_TEST_UNVALIDATED=1)."""
 import os
@@ -24,3 +24,8 @@ def test_fused_hr_tail_kernel_emulation_matches_oracle():
 def test_transpose_read_wgrad_kernel_emulation_matches_autograd():
     out = _run("emu_wgrad_tr.py", 2, 8, 2)                # two images, split-K over two workgroups, top and bottom padding
     assert "dW rel err" in out
+
+
+def test_deep_prefetch_wide_layer_kernel_addressing_and_wait_protocol():
+    out = _run("emu_dma3.py")                              # conv3x3_dma3_kernel: LDS images per buffer, in-order vmcnt protocol
+    assert "consistent" in out
