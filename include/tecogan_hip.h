@@ -95,23 +95,10 @@ typedef struct tg_conv_desc {
  * register footprint leaves room for a co-resident chain workgroup (3x3: <8,64> = 109 KB / ~300 registers instead of
  * <16,64> = 130 KB / ~400; measured: 87 % of the chain hides under VGG-sized convs, profiles/r02a_overlap.txt). */
 #define TG_CONV_COEXIST 1
-/* The launch owns the chip: wide 3x3 layers may use the deep-prefetch variant (three weight-panel buffers + two halo
- * buffers, 150 KB of LDS; conv3x3_dma.hip).  Ignored together with TG_CONV_COEXIST.  Round 2: not yet validated on the
- * GPU -- nothing in this repository sets it. */
-#define TG_CONV_DEEP_PREFETCH 2
 
 int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*[KH*KW][Cout][Cin]*/,
                     const float* bias /*nullable*/, const void* res /*nullable*/,
                     const void* aux /*nullable*/, void* out, void* stream);
-
-/* Fused residual block of generator_F (lib/frvsr.py:50-57) and of its backward pass, bf16, 64 channels:
- *   mid = act1(conv3x3(x, w1) + b1) [zeroed where m1 <= 0] ;  out = conv3x3(mid, w2) + b2 + x [zeroed where m2 <= 0]
- * forward : x = block input, relu1 = 1, flip = 0, w1/w2 = [9][out][in] panels of conv_1 / conv_2, mid = r, out = block output
- * backward: x = d(block output), flip = 1, w1/w2 = natural ([9][in][out]) panels of conv_2 / conv_1, m1 = r,
- *           mid = gradient w.r.t. conv_1's pre-activation, out = d(block input), m2 = ReLU output feeding the block or NULL. */
-int tg_resblock_fused(const void* x, const void* w1, const float* b1 /*nullable*/, const void* m1 /*nullable*/,
-                      void* mid, const void* w2, const float* b2 /*nullable*/, const void* m2 /*nullable*/, void* out,
-                      int N, int H, int W, int flip, int relu1, void* stream);
 
 /* Weight gradient of the gather-form convolution described by `d`
  * (X = the tensor that is gathered, [N,Hin,Win,Cin]; Y = per-output-pixel tensor

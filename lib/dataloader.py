@@ -124,24 +124,76 @@ class SceneSequences:
             seqs.append(np.ascontiguousarray(clip, dtype=np.float32))
         return np.stack(seqs)
 
+    def _validate_geometry(self):
+        """Every crop (incl. the moving-first-frame walk of up to 4 px per step) must fit the frames: checked once, up front,
+        instead of failing inside the prefetch thread."""
+        F = self.F
+        tar = F.crop_size * 4 + 2 * int(1.5 * 3.0)
+        first = _read_png(os.path.join(self.scenes[0], 'col_high_%04d.png' % 0))
+        H, W = first.shape[:2]
+        need = tar + (4 * (F.RNN_N - 1) if F.movingFirstFrame else 0)
+        if H < need or W < need:
+            raise ValueError('frames of %dx%d are too small for crop_size %d (need %d pixels%s)' % (
+                W, H, F.crop_size, need, ' incl. the movingFirstFrame walk' if F.movingFirstFrame else ''))
+
     def _worker(self):
+        """Prefetch thread.  Fills a fixed RING of pinned host buffers allocated before the thread starts (no hipHostMalloc
+        while the engine captures its hipGraphs) and hands every failure to the consumer: an exception here must not leave
+        next_batch() blocked on an empty queue."""
+        slot = 0
+        try:
+            while True:
+                ev = self._ring_events[slot]
+                if ev is not None:
+                    ev.synchronize()                    # the H2D copy that last read this buffer has finished
+                buf = self._ring[slot]
+                buf.copy_(torch.from_numpy(self._host_batch()))
+                self._q.put((slot, buf))
+                slot = (slot + 1) % len(self._ring)
+        except BaseException as e:                      # noqa: BLE001 -- re-raised in next_batch()
+            self._q.put(("error", e))
+
+    def _start_worker(self):
+        import queue
+        import threading
+        F = self.F
+        self._validate_geometry()
+        tar = F.crop_size * 4 + 2 * int(1.5 * 3.0)
+        nslot = self._prefetch + 2                      # queue depth + one being filled + one being copied to the device
+        pin = torch.cuda.is_available()
+        self._ring = [torch.empty(F.batch_size, F.RNN_N, tar, tar, 3, pin_memory=pin) for _ in range(nslot)]
+        self._ring_events = [None] * nslot
+        self._q = queue.Queue(maxsize=self._prefetch)
+        self._thread = threading.Thread(target=self._worker, daemon=True)
+        self._thread.start()
+
+    def _next_host(self):
+        import queue
         while True:
-            self._q.put(torch.from_numpy(self._host_batch()).pin_memory() if torch.cuda.is_available()
-                        else torch.from_numpy(self._host_batch()))
+            try:
+                item = self._q.get(timeout=5.0)
+                break
+            except queue.Empty:
+                if not self._thread.is_alive():
+                    raise RuntimeError('the loader thread died without reporting an error')
+        if item[0] == "error":
+            raise RuntimeError('the loader thread failed: %r' % (item[1],)) from item[1]
+        return item
 
     def next_batch(self):
         F = self.F
+        slot = None
         if self._prefetch > 0:
             if self._thread is None:
-                import queue
-                import threading
-                self._q = queue.Queue(maxsize=self._prefetch)
-                self._thread = threading.Thread(target=self._worker, daemon=True)
-                self._thread.start()
-            host = self._q.get()
+                self._start_worker()
+            slot, host = self._next_host()
         else:
             host = torch.from_numpy(self._host_batch())
         hr = host.to(self.dev, non_blocking=True)                               # [B,T,tar,tar,3] in [0,1]
+        if slot is not None and hr.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ring_events[slot] = ev                                        # the ring slot is free once this copy is done
         B, T, tar = hr.shape[0], hr.shape[1], hr.shape[2]
         lr, tgt = _ops.gauss_down_crop_preprocess(hr.reshape(B * T, tar, tar, 3), 1.5)
         cs = F.crop_size

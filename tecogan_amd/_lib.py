@@ -12,7 +12,6 @@ LIB_PATH = os.path.join(_HERE, "libtecogan_hip.so")
 TG_F32, TG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 CONV_COEXIST = 1
-CONV_DEEP_PREFETCH = 2
 
 
 class ConvDesc(C.Structure):
@@ -34,7 +33,6 @@ SIGNATURES = {
     "tg_conv_wgrad": [_D, _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "tg_conv_wgrad_grouped": [_D, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "tg_colsum": [_P, _I, _L, _I, _P, _P],
-    "tg_resblock_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tg_pack_weights": [_P, _P, _I, _P, _I, _I, _P],
     "tg_warp_s2d_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "tg_warp_s2d_backward": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

@@ -35,7 +35,6 @@ struct ConvDmaP {
   void* out;
   int N, H, W, Cin, Cout;
   int flip;           // 1: taps mirrored (input-gradient form)
-  int rotate;         // per-workgroup rotation of the weight panel's fetch order
   float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope
   int tiles_y, tiles_x, ntiles;
@@ -113,9 +112,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
   }
   // The 36 instructions of the weight panel are issued in an order ROTATED per workgroup: every workgroup of a channel
-  // block streams the same 36 KB per stage, and in lock step they would all ask the same L2 channel for the same lines at
-  // the same time (TG_C3DMA_ROT=0: A/B switch for the rotation).
-  const int rot = p.rotate ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)DM_W_INST) : 0;
+  // block streams the same 36 KB per stage (measured neutral against the fixed order, profiles/r02s_microbench.txt; kept).
+  const int rot = (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)DM_W_INST);
   int winst[DM_W_ROUNDS];
 #pragma unroll
   for (int k = 0; k < DM_W_ROUNDS; ++k) {
@@ -341,282 +339,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Deep-prefetch variant (TG_CONV_DEEP_PREFETCH): THREE weight-panel buffers + TWO halo buffers (150 KB).  The stage trace
-// of the kernel above shows every wave waiting 350-420 cycles for its own DMA and another ~550 at the barrier for the
-// slowest wave's: the 57 KB of a stage are issued one stage ahead and need ~2500-3500 cycles to land behind the traffic
-// of 255 other CUs.  The weight panel (64 % of the bytes) does not depend on the pixel tile, so it can be requested TWO
-// stages ahead without knowing more than the chunk index; only the halo (20 KB) stays one stage ahead.  Per wave and
-// stage the VMEM queue then holds, oldest first: weights(s) [issued in stage s-2], halo(s), weights(s+1) [both issued in
-// stage s-1, in this order], the stores of an epilogue -- the wait at the top of stage s leaves the weights(s+1) slots
-// and the stores in flight (counted vmcnt, in-order retirement).  No room for a chain workgroup beside it (150 + 36 KB):
-// not combined with TG_CONV_COEXIST.  Round-2 status: written and index-checked on the CPU, NOT yet run on the GPU
-// (the round's GPU budget was spent); nothing selects it unless the caller sets the flag.
-namespace {
-constexpr int D3_HOFF(int b) { return b * DM_HALO_BYTES; }
-constexpr int D3_WOFF(int b) { return 2 * DM_HALO_BYTES + b * DM_W_INST * 1024; }
-constexpr int D3_LDS = 2 * DM_HALO_BYTES + 3 * DM_W_INST * 1024;          // 153600
-}  // namespace
-
-template <bool HAS_RES, bool HAS_AUX>
-__global__ __launch_bounds__(512, 1) void conv3x3_dma3_kernel(ConvDmaP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // D3_LDS
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int frow = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.y * 64;
-  const int cbase = n0 + wn * 32;
-  const int row_bytes = p.Cin * 2;
-  const int nchunk = p.Cin >> 5;
-
-  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
-  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
-  const auto rsrcO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
-  const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_RES ? p.res : p.out), 0, (int)p.out_bytes, 0x00020000);
-  const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.out), 0, (int)p.out_bytes, 0x00020000);
-
-  int hrel[DM_HALO_ROUNDS], hcode[DM_HALO_ROUNDS], wrel[DM_W_ROUNDS];
-#pragma unroll
-  for (int k = 0; k < DM_HALO_ROUNDS; ++k) {
-    const int S = (wave + 8 * k) * 64 + lane;
-    const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
-    const int dy = q / DM_HW, dx = q - DM_HW * dy;
-    hrel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
-    hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
-  }
-#pragma unroll
-  for (int k = 0; k < DM_W_ROUNDS; ++k) {
-    const int S = (wave + 8 * k) * 64 + lane;
-    const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
-    const int tap = q >> 6, co = n0 + (q & 63);
-    const int wt = p.flip ? 8 - tap : tap;
-    wrel[k] = (wave + 8 * k < DM_W_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
-  }
-  // weight-panel DMA instructions this wave issues per stage: 36 over 8 waves = 5 for waves 0..3, 4 for waves 4..7
-  const int nw_wave = wave < DM_W_INST - 8 * (DM_W_ROUNDS - 1) ? DM_W_ROUNDS : DM_W_ROUNDS - 1;
-
-  auto halo_round = [&](int k, int tile, int chunk, int hb) {      // k compile time
-    const int inst = wave + 8 * k;
-    if (k + 1 < DM_HALO_ROUNDS || inst < DM_HALO_INST) {
-      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
-      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-      const int y0 = ty * DM_TH - 1, x0 = tx * 16 - 1;
-      const int base = ((n * p.H + y0) * p.W + x0) * row_bytes + chunk * 64;
-      const int dy = hcode[k] & 255, dx = (hcode[k] >> 8) & 255;
-      const bool ok = (hcode[k] >> 24) && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
-      const unsigned off = ok ? (unsigned)(base + hrel[k]) : DM_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(smem + hb * DM_HALO_BYTES + inst * 1024), 16, (int)off, 0, 0, 0);
-    }
-  };
-  auto weight_round = [&](int k, int chunk, int wb) {               // k compile time
-    const int inst = wave + 8 * k;
-    if (k + 1 < DM_W_ROUNDS || inst < DM_W_INST) {
-      const unsigned off = wrel[k] >= 0 ? (unsigned)(wrel[k] + chunk * 64) : DM_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrcW, (lds_void_d*)(smem + 2 * DM_HALO_BYTES + wb * (DM_W_INST * 1024) + inst * 1024), 16, (int)off, 0, 0, 0);
-    }
-  };
-  // counted wait: everything but the `keep` youngest operations of this wave has retired (keep is wave-uniform)
-  auto wait_all_but = [&](int keep) {
-    switch (keep) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-  };
-
-  int tile = blockIdx.x;
-  if (tile >= p.ntiles) return;
-  int chunk = 0;
-  // successor of a stage (tile, chunk)
-  auto succ = [&](int& t, int& c) {
-    if (++c == nchunk) {
-      c = 0;
-      t += gridDim.x;
-    }
-  };
-  int t1 = tile, c1 = chunk;
-  succ(t1, c1);                                             // stage s+1
-  // ---- prologue: halo(0), weights(0), weights(1)
-#pragma unroll
-  for (int k = 0; k < DM_HALO_ROUNDS; ++k) halo_round(k, tile, 0, 0);
-#pragma unroll
-  for (int k = 0; k < DM_W_ROUNDS; ++k) weight_round(k, 0, 0);
-  int young_w = 0;                                          // weight-panel operations of the NEXT stage in this wave's queue
-  if (t1 < p.ntiles) {
-#pragma unroll
-    for (int k = 0; k < DM_W_ROUNDS; ++k) weight_round(k, c1, 1);
-    young_w = nw_wave;
-  }
-
-  float bv[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = cbase + j * 16 + fg * 4 + r;
-      bv[j][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
-    }
-
-  const int Q0 = wm * 4 * DM_HW + frow;
-  int abase[8];
-#pragma unroll
-  for (int d = 0; d < 8; ++d) abase[d] = Q0 * 64 + ((fg ^ ((((Q0 & 7) + d) >> 2 & 1) << 1)) << 4);
-  const int bbase = 2 * DM_HALO_BYTES + (wn * 32 + frow) * 64 + ((fg ^ (((frow >> 2) & 1) << 1)) << 4);
-
-  f32x4 acc[4][2];
-  int hb = 0, wb = 0;                                       // halo / weight buffer of the current stage
-  bool prev_epi = false;
-  while (true) {
-    int t2 = t1, c2 = c1;
-    succ(t2, c2);                                           // stage s+2
-    const bool has1 = t1 < p.ntiles, has2 = has1 && t2 < p.ntiles;
-    // halo(s) and weights(s) have landed; weights(s+1) and the previous tile's stores may still fly
-    wait_all_but(young_w + (prev_epi ? 8 : 0));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int wb2 = wb == 0 ? 2 : wb - 1;                   // (s + 2) % 3 == (s - 1) % 3: the panel stage s-1 has finished with
-    const int wb1 = wb == 2 ? 0 : wb + 1;
-
-    if (chunk == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const unsigned char* sh = smem + hb * DM_HALO_BYTES;
-    const unsigned char* sw = smem + wb * (DM_W_INST * 1024);
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      u32x4d af[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const int K = r * DM_HW + kw;
-        af[r] = *reinterpret_cast<const u32x4d*>(sh + abase[K & 7] + K * 64);
-      }
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        u32x4d bfr[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bfr[j] = *reinterpret_cast<const u32x4d*>(sw + bbase + ((kh * 3 + kw) * 64 + j * 16) * 64);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
-                                                                __builtin_bit_cast(bf16x8, af[i + kh]), acc[i][j], 0, 0, 0);
-        // two DMA rounds after each of the first four groups of 8 MFMAs: halo(s+1) first (rounds 0..2), then weights(s+2)
-        const int grp = kw * 3 + kh;                        // compile time
-        if (grp < 4) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int rr = 2 * grp; rr < 2 * grp + 2; ++rr) {
-            if (rr < DM_HALO_ROUNDS) {
-              if (has1) halo_round(rr, t1, c1, hb ^ 1);
-            } else {
-              if (has2) weight_round(rr - DM_HALO_ROUNDS, c2, wb2);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    young_w = has2 ? nw_wave : 0;
-
-    prev_epi = chunk == nchunk - 1;
-    if (prev_epi) {
-      const int tx = tile % p.tiles_x, tq = tile / p.tiles_x;
-      const int ty = tq % p.tiles_y, n = tq / p.tiles_y;
-      const int x = tx * 16 + frow;
-      unsigned offs[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int y = ty * DM_TH + wm * 4 + i;
-        const bool pok = y < p.H && x < p.W;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int co = cbase + j * 16 + fg * 4;
-          offs[i][j] = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : DM_OOB;
-        }
-      }
-      u32x2d rr[HAS_RES ? 4 : 1][2], aa[HAS_AUX ? 4 : 1][2];
-      if constexpr (HAS_RES) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
-      }
-      if constexpr (HAS_AUX) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[i][j][r] + bv[j][r];
-            v[r] = fmaxf(v[r], v[r] * p.nslope);
-          }
-          if constexpr (HAS_RES) {
-            v[0] += __uint_as_float(rr[i][j].x << 16);
-            v[1] += __uint_as_float(rr[i][j].x & 0xffff0000u);
-            v[2] += __uint_as_float(rr[i][j].y << 16);
-            v[3] += __uint_as_float(rr[i][j].y & 0xffff0000u);
-          }
-          if constexpr (HAS_AUX) {
-            v[0] *= __uint_as_float(aa[i][j].x << 16) > 0.f ? 1.f : p.mslope;
-            v[1] *= __uint_as_float(aa[i][j].x & 0xffff0000u) > 0.f ? 1.f : p.mslope;
-            v[2] *= __uint_as_float(aa[i][j].y << 16) > 0.f ? 1.f : p.mslope;
-            v[3] *= __uint_as_float(aa[i][j].y & 0xffff0000u) > 0.f ? 1.f : p.mslope;
-          }
-          u32x2d o;
-          o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          __builtin_amdgcn_raw_buffer_store_b64(o, rsrcO, (int)offs[i][j], 0, 0);
-        }
-      }
-    }
-    if (!has1) break;
-    tile = t1;
-    chunk = c1;
-    t1 = t2;
-    c1 = c2;
-    hb ^= 1;
-    wb = wb1;
-  }
-}
-
-template <bool HAS_RES, bool HAS_AUX>
-static void launch_dma3(const ConvDmaP& p, hipStream_t st) {
-  auto kern = conv3x3_dma3_kernel<HAS_RES, HAS_AUX>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS);
-  });
-  const int nt = p.Cout / 64;
-  int gx = 256 / nt;
-  if (gx < 8) gx = 8;
-  gx &= ~7;
-  if (gx > p.ntiles) gx = p.ntiles;
-  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_dma3<res,aux>" : "conv3x3_dma3<res>")
-                                           : (HAS_AUX ? "conv3x3_dma3<aux>" : "conv3x3_dma3<>");
-  const double px = (double)p.N * p.H * p.W;
-  TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
-            px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(512),
-            D3_LDS, st, p);
-}
-
 template <bool HAS_RES, bool HAS_AUX, int NT>
 static void launch_dma(const ConvDmaP& p, hipStream_t st) {
   auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX, NT>;
@@ -633,10 +355,8 @@ static void launch_dma(const ConvDmaP& p, hipStream_t st) {
   if (gx < 8) gx = 8;
   gx &= ~7;
   if (gx > nunits) gx = nunits;
-  static const char* const pname = NT == 2 ? (HAS_RES ? (HAS_AUX ? "conv3x3_dma2<res,aux>" : "conv3x3_dma2<res>")
-                                                      : (HAS_AUX ? "conv3x3_dma2<aux>" : "conv3x3_dma2<>"))
-                                           : (HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>")
-                                                      : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>"));
+  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>")
+                                           : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>");
   const double px = (double)p.N * p.H * p.W;
   TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
             px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(512),
@@ -669,8 +389,6 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   p.in = in; p.w = weight; p.bias = bias; p.res = res; p.aux = aux; p.out = out;
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
   p.flip = d->mode == 1;
-  static const int rot_env = getenv("TG_C3DMA_ROT") ? atoi(getenv("TG_C3DMA_ROT")) : 1;
-  p.rotate = rot_env;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   p.tiles_y = (p.H + DM_TH - 1) / DM_TH;
@@ -680,17 +398,6 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   if (ntiles * (p.Cout / 64) < min_wg || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-  // two tiles per stage when the launch runs alone on the chip and still fills it with half the work units
-  static const int pair_env = getenv("TG_C3DMA_PAIR") ? atoi(getenv("TG_C3DMA_PAIR")) : -1;      // A/B switch: 0 never, 1 always
-  const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;
-  const int64_t units2 = (ntiles + 1) / 2 * (p.Cout / 64);
-  const bool pair = pair_env >= 0 ? pair_env == 1 && units2 >= 224 : false;
-  if ((d->flags & TG_CONV_DEEP_PREFETCH) && !coexist) {
-    if (res && aux) launch_dma3<true, true>(p, st);
-    else if (res) launch_dma3<true, false>(p, st);
-    else if (aux) launch_dma3<false, true>(p, st);
-    else launch_dma3<false, false>(p, st);
-  } else if (pair) launch_dma_nt<2>(p, res != nullptr, aux != nullptr, st);
-  else launch_dma_nt<1>(p, res != nullptr, aux != nullptr, st);
+  launch_dma_nt<1>(p, res != nullptr, aux != nullptr, st);
   return 1;
 }

@@ -807,7 +807,7 @@ static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, cons
 }
 
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
-                       float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip (opt-in, TG_WGRAD_TR=1)
+                       float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip
 
 extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
                                      const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,

@@ -19,8 +19,9 @@
 //     with an all-ones A operand in the waves of the first ci half.
 // Grouped like the row kernel: `groups` layers of identical geometry in one launch.
 //
-// Round-2 status: written after the round's GPU budget was spent, on the guide's description of the transpose read
-// (tools/probe_tr.hip checks it on hardware first).  Opt-in: TG_WGRAD_TR=1; GPU test gated behind TG_TEST_UNVALIDATED=1.
+// Round 3: validated on MI355X (tools/probe_tr.hip confirmed the lane map, profiles/r03a_probe_tr.txt; parity test in
+// tests/test_kernels_gpu.py) and default-on: the grouped trunk launch (32 layers x 76 images) 422.7 -> 353.1 us, 434 -> 520
+// TFLOP/s (profiles/r03b_mb_wgrad.txt).  TG_WGRAD_TR=0 is the A/B switch.
 #include "common.h"
 #include <mutex>
 #include <stdlib.h>
@@ -192,10 +193,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   }
 }
 
-// returns 1 if launched (opt-in; geometry of the generator trunk only), 0 otherwise
+// returns 1 if launched (geometry of the generator trunk only), 0 otherwise
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
                        float* const* dw, float* const* dbias, hipStream_t st) {
-  static const bool enabled = getenv("TG_WGRAD_TR") != nullptr && atoi(getenv("TG_WGRAD_TR")) == 1;
+  static const bool enabled = getenv("TG_WGRAD_TR") == nullptr || atoi(getenv("TG_WGRAD_TR")) != 0;
   if (!enabled || groups < 1 || groups > TG_WTR_MAX_GROUPS) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->mode != 0) return 0;
   if (d->Win != TR_W || d->Wout != TR_W || d->Hin != d->Hout || d->Hin % TR_TH != 0) return 0;

@@ -75,17 +75,27 @@ def plan_launch_order(segs, lazy=True):
 
 class TrainEngine:
     def __init__(self, flags, device="cuda", gan=True, act_dtype=torch.float32, seed=42, process_group=None,
-                 use_graph=True):
+                 use_graph=True, standin_world=0):
+        """standin_world=W (tests, one GPU, no process group): run the W-rank program -- communication stream, captured
+        exchange segments, 1/W folded into Adam -- with every all-reduce replaced by an in-place `x *= W` kernel on the
+        communication stream (what a sum over W ranks holding identical gradients gives).  The result must equal the
+        one-rank engine's, and every exchange segment carries real graph nodes (RCCL itself elides the kernel for a
+        one-rank communicator, so a one-rank group cannot test that)."""
         F = self.F = flags
         self.dev, self.gan, self.act_dtype = torch.device(device), gan, act_dtype
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.standin = int(standin_world) if process_group is None else 0
+        if self.standin > 1:
+            self.world = self.standin
         # Gradient exchange (SURVEY 8e).  "captured": the RCCL all-reduces are nodes of the step's hipGraph, issued on a
         # side stream as soon as a scope's gradients are final (D right after its backward passes, G after the
         # sequence-wide weight gradients) so they overlap the rest of the backward pass; "eager-split": compute graph,
         # eager collectives, update graph (any backend that cannot be captured, e.g. gloo in the plumbing tests).
         self.exchange_mode = "none"
-        if self.world > 1:
+        if self.standin > 1:
+            self.exchange_mode = "captured"
+        elif self.world > 1:
             backend = torch.distributed.get_backend(process_group)
             want = os.environ.get("TG_EXCHANGE", "captured" if backend == "nccl" else "eager")
             self.exchange_mode = "captured" if (want == "captured" and backend == "nccl") else "eager-split"
@@ -155,6 +165,7 @@ class TrainEngine:
         self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "47")) & 63) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
         uses_side = (self.use_vgg and self.ov_parts & 21) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 32)
@@ -212,7 +223,7 @@ class TrainEngine:
             self._done[name] = (ev, skey)
             return
         g = torch.cuda.CUDAGraph()                     # capture
-        with torch.cuda.graph(g, pool=self._pool(skey)):
+        with torch.cuda.graph(g, pool=self._pool(skey), capture_error_mode="thread_local"):
             self._stamp(name, 0)
             yield
             self._stamp(name, 1)
@@ -247,6 +258,7 @@ class TrainEngine:
         self._mode = mode if self.segmented else "flat"
         self._main = torch.cuda.current_stream()
         self._done = {}
+        self.exchange_segments = []
         self._program()
 
     def _replay(self):
@@ -288,23 +300,14 @@ class TrainEngine:
             m.copy_(c)
         self.ps.repack()
         torch.cuda.synchronize()
-        if self.exchange_mode == "captured":
-            try:
-                self._segs = []
-                self._run_program("capture")
-                return
-            except Exception as e:           # a collective backend that cannot be stream-captured: run it eagerly instead
-                import warnings
-                warnings.warn("captured RCCL exchange failed (%s): falling back to the eager-split exchange" % (e,))
-                self.exchange_mode = "eager-split"
-                self._pools = {}
-                torch.cuda.synchronize()
+        # (a captured RCCL exchange that fails to capture is an ERROR: a silent eager fallback on an 8-GPU node would only
+        #  show up as a slower number.  TG_EXCHANGE=eager selects the eager-split exchange explicitly.)
         self._segs = []
         if self.segmented:
             self._run_program("capture")
         else:                                # one stream, no exchange: the whole step is ONE graph
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._run_program("flat")
             self._segs.append(dict(name="step", skey="M", deps=[], graph=g, fn=None, event=torch.cuda.Event()))
 
@@ -325,15 +328,21 @@ class TrainEngine:
         ordered after the segments `after`; it overlaps whatever the compute streams do next, `update` joins."""
         if self.exchange_mode != "captured":
             return
-        import torch.distributed as dist
         with self._seg(name, "C", after):
             if with_balance and self.gan:            # every rank must take the same D-gate branch (lib/Teco.py:493-494)
                 tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
-                dist.all_reduce(tb, group=self.pg)
+                self._sum_all_reduce(tb)
                 K.affine(tb, tb, 1.0 / self.world, 0.0)
             for scope in scopes:
                 a, b = self.ps.scope_range[scope]
-                dist.all_reduce(self.ps.grad[a:b], group=self.pg)
+                self._sum_all_reduce(self.ps.grad[a:b])
+        self.exchange_segments.append(name)
+
+    def _sum_all_reduce(self, t):
+        if self.standin > 1:                         # test stand-in: W identical ranks
+            K.affine(t, t, float(self.standin), 0.0)
+        else:
+            torch.distributed.all_reduce(t, group=self.pg)
 
     def allreduce_bytes(self):
         """Bytes every rank contributes to the gradient exchange of one step (fp32 flat buffers + the balance scalar)."""

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import CONV_COEXIST, CONV_DEEP_PREFETCH, ConvDesc, TG_BF16, TG_F32, check, lib  # noqa: F401
+from ._lib import CONV_COEXIST, ConvDesc, TG_BF16, TG_F32, check, lib  # noqa: F401
 
 
 def _stream():
@@ -273,16 +273,6 @@ def affine(x, out, scale, shift):
     return out
 
 
-def resblock_fused(x, w1, b1, m1, mid, w2, b2, m2, out, flip, relu1):
-    N, H, W, Cn = x.shape
-    if Cn != 64 or x.dtype != torch.bfloat16:
-        raise L.TecoHipError("resblock_fused: bf16, 64 channels only")
-    check(lib().tg_resblock_fused(_p(x), _p(w1), _p(b1), _p(m1), _p(mid), _p(w2), _p(b2), _p(m2), _p(out), N, H, W,
-                                  int(flip), int(relu1), _stream()), "tg_resblock_fused")
-    return out
-
-
-# ---- data step before / output step after the path -----------------------------------
 def gauss_down4_preprocess(hr, weights2d, lr, target=None, border=0):
     """hr [N,H,W,3] fp32 -> lr (Gaussian k x k, stride 4, VALID); target (optional) = 2*hr[crop]-1 in the same launch."""
     N, H, W, _ = hr.shape

@@ -123,11 +123,6 @@ class Generator:
     def __init__(self, ps, num_resblock):
         self.ps, self.nres = ps, num_resblock
         self.seq = None
-        # fused residual-block kernel (csrc/resblock.hip): bf16 only, OPT-IN via TG_FUSED_RESBLOCK=1.  Measured on
-        # MI355X at the training shape [4,32,32,64] it LOSES to the two-launch path (9.7 us vs 8.2 us per block
-        # forward, 12.3 us backward; FRVSR step 6.9 ms vs 5.7 ms same box): with 128 tiles of one wave per SIMD the
-        # block is latency-bound and the halo recompute + second weight fetch cost more than one launch saves.
-        self.fused = ps.act_dtype == torch.bfloat16 and bool(os.environ.get("TG_FUSED_RESBLOCK"))
         # one grouped weight-gradient launch for all res-block convs; TG_WGRAD_GROUPED=0 is the A/B switch
         # (FRVSR step 4.25 -> 3.91 ms in the same session, profiles/r01o_grouped_wgrad_ab.txt)
         self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "1") == "1"
@@ -135,7 +130,9 @@ class Generator:
         # of another stream shares the chip, so that the chain's bigger launches (HR deconv, output conv) also pick tile
         # shapes that fit NEXT to a resident VGG workgroup instead of waiting for a CU to drain
         self.chain_flags = 0
-        self.hr_tail = os.environ.get("TG_HR_TAIL") == "1"      # fused HR tail of the stateless (inference) forward: opt-in
+        # fused HR tail of the stateless (inference) forward (csrc/hr_tail.hip); TG_HR_TAIL=0 is the A/B switch
+        # (1080p frame 1.103 -> 1.068 ms, profiles/r03a_ab.txt)
+        self.hr_tail = os.environ.get("TG_HR_TAIL", "1") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -152,8 +149,7 @@ class Generator:
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
         t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU)
         if self.hr_tail and t1.dtype == torch.bfloat16:
-            # fused HR tail (csrc/hr_tail.hip): the 64-channel HR tensor t2 is never written.  OPT-IN (TG_HR_TAIL=1) until
-            # the kernel has been validated on hardware.
+            # fused HR tail (csrc/hr_tail.hip): the 64-channel HR tensor t2 is never written
             wo, bo = p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases"
             N, h2, w2, _ = t1.shape
             o = None if out is False else (torch.empty(N, 2 * h2, 2 * w2, 3, device=t1.device) if out is None else out)
@@ -203,11 +199,6 @@ class Generator:
                      out=q["a"][0][t], flags=cf)
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
-            if self.fused:          # one launch per residual block (csrc/resblock.hip)
-                a = K.resblock_fused(a, ps.packed(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
-                                     None, q["r"][i][t], ps.packed(s + "conv_2/Conv/weights", True),
-                                     ps.view(s + "conv_2/Conv/biases"), None, q["a"][i][t], flip=False, relu1=True)
-                continue
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t], flags=cf)
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
                          out=q["a"][i][t], flags=cf)
@@ -233,12 +224,6 @@ class Generator:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
         for i in range(n, 0, -1):
             sc = p + "resblock_%d/" % i
-            if self.fused:          # dr = bwd(conv_2)(g) * relu'(r);  d a_{i-1} = bwd(conv_1)(dr) + g  [* relu'(a_0)]
-                g = K.resblock_fused(g, ps.packed(sc + "conv_2/Conv/weights", False), None, q["r"][i][t],
-                                     q["g_c1"][i][t], ps.packed(sc + "conv_1/Conv/weights", False), None,
-                                     q["a"][0][t] if i == 1 else None,
-                                     q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], flip=True, relu1=False)
-                continue
             dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
                                out=q["g_c1"][i][t], flags=cf)
             # d a_{i-1} = bwd(conv_1)(dr) + skip gradient; block 1's input is itself a ReLU output (masked here)

@@ -531,41 +531,6 @@ def test_wgrad_bf16_padded_channel_stride():
     close(dw, w.grad, 3e-4, "padded-stride bf16 wgrad")
 
 
-@pytest.mark.parametrize("shape", [(4, 32, 32), (1, 9, 21), (2, 270, 40)])
-def test_resblock_fused_forward_and_backward(shape):
-    """Fused residual block (csrc/resblock.hip) vs the oracle ops composed the same way, on bf16-rounded operands."""
-    N, H, W = shape
-    bf = lambda t: t.bfloat16().float()
-    x = bf(rnd(N, H, W, 64, seed=1))
-    w1, w2 = bf(rnd(3, 3, 64, 64, seed=2, scale=0.1)), bf(rnd(3, 3, 64, 64, seed=3, scale=0.1))
-    b1, b2 = rnd(64, seed=4, scale=0.1), rnd(64, seed=5, scale=0.1)
-    # ---- forward: r = relu(conv1(x)); out = conv2(r) + x
-    r_ref = bf(torch.relu(O.conv2(x, w1, b1, 1)))
-    out_ref = O.conv2(r_ref, w2, b2, 1) + x
-    wt = lambda w: w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16)     # [tap][out][in]
-    wn = lambda w: w.reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16)                          # [tap][in][out]
-    xd = x.to(DEV, torch.bfloat16)
-    mid, out = torch.empty_like(xd), torch.empty_like(xd)
-    K.resblock_fused(xd, wt(w1), b1.to(DEV), None, mid, wt(w2), b2.to(DEV), None, out, flip=False, relu1=True)
-    close(mid, r_ref, 1e-2, "fused fwd mid")
-    close(out, out_ref, 1e-2, "fused fwd out")
-    # ---- backward: dr = bwd_conv2(g) * relu'(r); dx = bwd_conv1(dr) + g, optionally masked by relu'(a0)
-    g = bf(rnd(N, H, W, 64, seed=6))
-    a0 = rnd(N, H, W, 64, seed=7)
-    rr = r_ref.clone().requires_grad_()
-    O.conv2(rr, w2, None, 1).backward(g)
-    dr_ref = bf(rr.grad * (r_ref > 0).float())
-    xx = torch.zeros(N, H, W, 64, requires_grad=True)
-    O.conv2(xx, w1, None, 1).backward(dr_ref)
-    dx_ref = (xx.grad + g) * (a0 > 0).float()
-    gd = g.to(DEV, torch.bfloat16)
-    dmid, dout = torch.empty_like(gd), torch.empty_like(gd)
-    K.resblock_fused(gd, wn(w2), None, r_ref.to(DEV, torch.bfloat16), dmid, wn(w1), None, a0.to(DEV, torch.bfloat16),
-                     dout, flip=True, relu1=False)
-    close(dmid, dr_ref, 1e-2, "fused bwd mid")
-    close(dout, dx_ref, 1e-2, "fused bwd out")
-
-
 # ---------------------------------------------------------------------------------------------------------
 # round 2: kernel-level parity of the loss / packing / schedule entry points (previously only covered by the
 # end-to-end step), per-element tolerance (tests/util.py)
@@ -959,7 +924,6 @@ DMA_CASES = [
     (35, 40, 27, 96, 64, False, True, False, ACT_LRELU),      # ragged right / bottom edges, Cin = 96 (3 chunks), residual
     (2, 128, 128, 128, 64, True, True, True, ACT_NONE),       # many tiles per workgroup (persistent loop), res + mask
     (97, 16, 16, 128, 128, False, False, False, ACT_NONE),    # FNet level-2 geometry; tile count not a multiple of the grid
-    # big enough for the two-tiles-per-stage variant (opt-in: TG_C3DMA_PAIR=1; measured slower -- tile quantisation):
     (76, 32, 32, 256, 256, False, False, False, ACT_RELU),    # VGG conv3_x at the full batch
     (57, 16, 16, 512, 512, False, False, False, ACT_RELU),    # odd tile count: the last unit's second tile does not exist
     (57, 40, 27, 96, 128, False, True, False, ACT_LRELU),     # ragged edges + residual, pairs straddle image boundaries
@@ -967,14 +931,8 @@ DMA_CASES = [
 ]
 
 
-UNVALIDATED = pytest.mark.skipif(os.environ.get("TG_TEST_UNVALIDATED") != "1",
-                                 reason="kernel variant written after the round's GPU budget was spent: not yet run on a GPU "
-                                        "(TG_TEST_UNVALIDATED=1 runs it)")
-
-
 @pytest.mark.parametrize("case", DMA_CASES)
-@pytest.mark.parametrize("deep", [0, pytest.param(1, marks=UNVALIDATED)])
-def test_conv3x3_wide_layer_dma_kernel(case, deep):
+def test_conv3x3_wide_layer_dma_kernel(case):
     N, H, W, Cin, Cout, flip, has_res, has_aux, act = case
     x = rnd(N, H, W, Cin, seed=1).bfloat16()
     w = rnd(3, 3, Cin, Cout, seed=2, scale=0.05).bfloat16()
@@ -994,7 +952,7 @@ def test_conv3x3_wide_layer_dma_kernel(case, deep):
     wt = w.permute(0, 1, 3, 2).reshape(9, Cout, Cin).contiguous().to(DEV)
     out = torch.full((N, H, W, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
     d = K.conv_desc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1 if flip else 0, TG_BF16, TG_BF16, act, alpha,
-                    ACT_RELU if has_aux else ACT_NONE, 0.0, flags=K.CONV_DEEP_PREFETCH if deep else 0)
+                    ACT_RELU if has_aux else ACT_NONE, 0.0)
     K.prof_collect()
     K.prof_enable(True)
     K.conv_forward(d, x.to(DEV), wt, None if b is None else b.to(DEV), None if res is None else res.to(DEV),
@@ -1002,11 +960,6 @@ def test_conv3x3_wide_layer_dma_kernel(case, deep):
     K.prof_enable(False)
     ents = K.prof_collect()
     assert ents and ents[0]["name"].startswith("conv3x3_dma"), "the wide-layer DMA kernel was not selected: %s" % ents
-    if deep:
-        assert ents[0]["name"].startswith("conv3x3_dma3"), ents[0]["name"]
-    ntiles = N * ((H + 15) // 16) * ((W + 15) // 16)
-    pair = os.environ.get("TG_C3DMA_PAIR") == "1" and (ntiles + 1) // 2 * (Cout // 64) >= 224
-    assert deep or ents[0]["name"].startswith("conv3x3_dma2") == pair, ents[0]["name"]
     err = (out.float().cpu() - ref).abs()
     assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
 
@@ -1032,8 +985,7 @@ def test_deconv3x3s2_weights_in_registers_kernel(case):
     assert (err <= 8e-3 * ref.abs() + 2e-2).all(), "%s: max err %g" % (case, err.max().item())
 
 
-# ---- csrc/hr_tail.hip: fused transposed conv + output conv + bicubic skip (opt-in, not yet validated on hardware) ---------
-@UNVALIDATED
+# ---- csrc/hr_tail.hip: fused transposed conv + output conv + bicubic skip -----------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 14, 30), (2, 22, 36), (1, 64, 64), (1, 540, 960)])
 def test_hr_tail_fused_matches_the_three_kernel_path(shape):
     """t1 -> relu(conv2d_transpose) -> conv 64->3 -> + bicubic_four(LR) -> *2-1 (lib/frvsr.py:73-87) and the recurrent state
@@ -1063,9 +1015,8 @@ def test_hr_tail_fused_matches_the_three_kernel_path(shape):
     assert torch.equal(state2.cpu(), state.cpu())
 
 
-# ---- csrc/conv_wgrad_tr.hip: weight gradients with transpose reads (opt-in TG_WGRAD_TR=1, not yet validated on hardware) --
-@UNVALIDATED
-@pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") != "1", reason="the transpose-read weight-gradient kernel is selected by TG_WGRAD_TR=1")
+# ---- csrc/conv_wgrad_tr.hip: weight gradients with transpose reads -------------------------------------------------------
+@pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") == "0", reason="TG_WGRAD_TR=0 switches the transpose-read kernel off")
 @pytest.mark.parametrize("case", [(1, 2, 8), (3, 5, 32), (32, 76, 32)])
 def test_wgrad_transpose_read_kernel_matches_autograd(case):
     """dW / dbias of 3x3 s1 SAME 64 -> 64 convs on 32-pixel-wide images (the generator trunk, lib/frvsr.py:50-57) against

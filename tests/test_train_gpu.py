@@ -304,3 +304,34 @@ def test_captured_rccl_exchange_single_rank_group():
             assert d <= 1e-3 * w.abs().max().item() + 4.0 * F.learning_rate, (name, d)
     finally:
         dist.destroy_process_group()
+
+
+def test_captured_exchange_segments_carry_nodes_standin_world2():
+    """SURVEY 8e on ONE GPU: the 2-rank program (communication stream, captured exchange segments ar_d / ar_g / ar_f,
+    t_balance reduced before the D gate, 1/world folded into Adam) with every all-reduce replaced by the in-place `x *= 2`
+    kernel a sum over two identical ranks amounts to (TrainEngine(standin_world=2)).  Unlike a one-rank RCCL communicator --
+    RCCL elides the kernel there, so the captured graph was EMPTY -- every communication segment here holds real nodes that
+    are replayed on the communication stream, and the result equals the one-rank engine's."""
+    import warnings
+    F = OT.default_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=1)
+    x, y = make_batch(1, F.RNN_N, F.crop_size, seed=5)
+    a = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        b = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True, standin_world=2)
+        for _ in range(3):
+            a.step(x.to(DEV), y.to(DEV))
+            b.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+    assert not [w for w in rec if "empty" in str(w.message).lower()], [str(w.message) for w in rec]
+    assert b.exchange_mode == "captured" and b.world == 2
+    assert b.exchange_segments == ["ar_d", "ar_g", "ar_f"]
+    csegs = [s for s in b._segs if s["skey"] == "C"]
+    assert [s["name"] for s in csegs] == ["ar_d", "ar_g", "ar_f"] and all(s["graph"] is not None for s in csegs)
+    upd = [s for s in b._segs if s["name"] == "update"][0]
+    assert {"ar_d", "ar_g", "ar_f"} <= set(upd["deps"])
+    assert b.allreduce_bytes() == 4 * (b.ps.flat.numel()) + 4
+    assert int(a.sched[8].item()) == int(b.sched[8].item())          # same number of (gated) D updates
+    for name, w in a.ps.state_dict().items():
+        d = (b.ps.view(name).cpu() - w).abs().max().item()
+        assert d <= 1e-3 * w.abs().max().item() + 6.0 * F.learning_rate, (name, d)

@@ -5,3 +5,16 @@ for name, args in (("gen40", (40, 32, 32, 64, 64)), ("tran2", (40, 128, 128, 64,
     fn, flops = wgrad_case(*args)
     t = graph_timeit(fn, chain=20)
     print("wgrad %-10s blocks=%s: %.2f us  %.1f TFLOP/s" % (name, os.environ.get("TG_WGRAD_BLOCKS"), t, flops / t / 1e6))
+
+# the generator trunk's grouped launch as the TecoGAN / FRVSR steps issue it: 2*nres layers, T*B images of 32x32x64
+from tecogan_amd import kernels as K
+for G, N in ((32, 76), (20, 40)):
+    d = K.conv_desc(N, 32, 32, 64, 32, 32, 64, 3, 3, 1, 1, 1, 0, 0, 0)
+    xs = [torch.randn(N, 32, 32, 64, device="cuda").bfloat16() for _ in range(G)]
+    ys = [torch.randn(N, 32, 32, 64, device="cuda").bfloat16() for _ in range(G)]
+    dws = [torch.zeros(3, 3, 64, 64, device="cuda") for _ in range(G)]
+    dbs = [torch.zeros(64, device="cuda") for _ in range(G)]
+    fn = lambda: K.conv_wgrad_grouped(d, xs, ys, dws, dbs, ldx=64, ldy=64)
+    t = graph_timeit(fn, chain=5)
+    fl = 2.0 * G * N * 32 * 32 * 64 * 64 * 9
+    print("wgrad grouped G=%d N=%d (TG_WGRAD_TR=%s): %.1f us  %.1f TFLOP/s" % (G, N, os.environ.get("TG_WGRAD_TR"), t, fl / t / 1e6))

@@ -49,7 +49,7 @@ def conv_case(N, H, W, Cin, Cout, k=3, s=1, mode=0, dtype=torch.bfloat16, out_hw
         (Ho, Wo), pt, pl = out_hw, 0, 0
     out = torch.empty(N, Ho, Wo, Cout, device=DEV, dtype=dtype)
     d = K.conv_desc(N, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, mode, K.dt(x), K.dt(out), ACT_RELU,
-                    flags=int(os.environ.get("MB_CONV_FLAGS", "0")))      # 1 TG_CONV_COEXIST, 2 TG_CONV_DEEP_PREFETCH
+                    flags=int(os.environ.get("MB_CONV_FLAGS", "0")))      # 1 TG_CONV_COEXIST
     flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin if mode == 0 else 2.0 * N * H * W * Cout * k * k * Cin
     return (lambda: K.conv_forward(d, x, w, b, None, None, out)), flops
 
