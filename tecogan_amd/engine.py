@@ -143,13 +143,15 @@ class TrainEngine:
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
-        self.vgg_cuts = [int(c) for c in os.environ.get("TG_VGG_CUTS", "").split(",") if c.strip()]
+        # frames per late VGG piece (the pieces run frame-DESCENDING on the side stream, the BPTT of a piece's frames starts as
+        # soon as that piece's gradient is final; bit 64 of TG_OVERLAP_PARTS)
+        self.vgg_late_chunk = max(1, int(os.environ.get("TG_VGG_LATE_CHUNK", "99")))
         self.lazy_side = os.environ.get("TG_LAZY_SIDE", "1") == "1"     # A/B switch: just-in-time side-stream launches
         # measurement mode: device wall-clock stamps at every segment boundary (one-thread kernels, captured with the segment)
         self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
         self.seg_stamp_names = {}
         self._pools = {}
-        self._done, self._mode, self._main, self._d_vgg, self._d_vgg_mid = {}, "flat", None, None, None
+        self._done, self._mode, self._main, self._d_vgg, self._d_vgg_late = {}, "flat", None, None, None
         # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
         self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
         self.host_step = 0
@@ -158,17 +160,19 @@ class TrainEngine:
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
-        # frames, 8 D's own-gradient passes, 16 VGG pass of the middle frames beside the first part of the BPTT,
-        # 32 the generator's weight gradients beside FNet's backward pass.  (Generator
-        # weight gradients of finished frames beside the BPTT were measured a loss twice -- 6.16 vs 6.00 ms in round 1,
-        # 4.35 vs 3.73 ms FRVSR with capped residency -- and are gone.)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "47")) & 63) if self.overlap else 0
+        # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass,
+        # 64 VGG pass of the LATE frames in frame-descending pieces beside D's generator-side backward pass and the BPTT of
+        # the frames above them (instead of one exposed piece on the main stream before the BPTT),
+        # 128 FNet's backward pass of the late frame pairs beside the BPTT of the early frames (their flow gradients are
+        # final once the BPTT has passed them), 256 the generator's weight gradients of the late frames beside the BPTT
+        # of the early frames.
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "239")) & 0x1ef) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
-        uses_side = (self.use_vgg and self.ov_parts & 21) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 32)
+        uses_side = (self.use_vgg and self.ov_parts & 69) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 416)
         self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
         # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
         # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
@@ -314,12 +318,12 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
-        after = ["down", "wgrad"]
+        after = ["down", "bwd", "wgrad", "wgrad_late", "fnet_late"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["down", "wgrad", "ar_d", "ar_g", "ar_f"]
+            after = ["down", "bwd", "wgrad", "wgrad_late", "fnet_late", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
 
@@ -414,15 +418,10 @@ class TrainEngine:
         # ---- recurrent generator (lib/Teco.py:125-155); side: VGG pass of the early frames ----------------------
         gen = torch.empty(T, B, H, H, 3, device=self.dev) if self.gen is None else self.gen
         self.gen = gen
-        # frames [0, tc): early chunks (VGG pass on the side stream, beside the forward recurrence of the LATER frames),
-        # [tc, T): late chunk (main stream, after the forward pass).  TG_VGG_CUTS="6,12,16": the early part in several pieces,
-        # each launched as soon as its frames exist -- the more frames the side stream takes, the shorter the exposed VGG
-        # pass on the main stream before the BPTT can start.
-        cuts = [c for c in self.vgg_cuts if 0 < c < T] if (self.use_vgg and T > 1) else []
-        # default: one cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at 10 + 9 and
-        # 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the late chunk is the exposed one, the early one has the forward pass to hide in)
-        cuts = sorted(set(cuts)) or [min((T + 3) // 2, T - 1) if T > 1 else T]
-        tc = cuts[-1]
+        # frames [0, tc): early chunk (VGG pass on the side stream, beside the forward recurrence of the LATER frames),
+        # [tc, T): late frames.  One cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at
+        # 10 + 9 and 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the early chunk has the forward pass to hide in).
+        tc = (min((T + 3) // 2, T - 1) if T > 1 else T) if self.use_vgg else T
         d_vgg = None
         if self.use_vgg:
             d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
@@ -433,23 +432,16 @@ class TrainEngine:
                                    0.5, 0.5)
                 self.G.forward_t(t, gen[t])
 
-        early_on_side = self.use_vgg and bool(self.ov_parts & 4) and self._mode != "flat"
-        if not early_on_side:
-            cuts = cuts[-1:]
-        vgg_segs, prev = [], 0
-        for i, c in enumerate(cuts):
-            tag = "" if len(cuts) == 1 else str(i)
-            with seg("fwd_a" + tag):
-                if i == 0 and (self.G.seq is None or self._mode != "capture"):
-                    self.G.begin_sequence(T, B, h, h, self.dev)
-                forward_frames(prev, c if early_on_side else T)
-            if self.use_vgg:
-                sk, cx = part(4)
-                name = "vgg_early" + tag
-                with seg(name, sk, ["fwd_a" + tag, "vggt"]):
-                    self._vgg_chunk(gen, taps_t, prev, c, d_vgg, cx if early_on_side else 0, zero=True)
-                vgg_segs.append(name)
-            prev = c
+        split = self._mode != "flat"
+        early_on_side = self.use_vgg and bool(self.ov_parts & 4) and split
+        with seg("fwd_a"):
+            if self.G.seq is None or self._mode != "capture":
+                self.G.begin_sequence(T, B, h, h, self.dev)
+            forward_frames(0, tc if early_on_side else T)
+        if self.use_vgg:
+            sk, cx = part(4)
+            with seg("vgg_early", sk, ["fwd_a", "vggt"]):
+                self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx if early_on_side else 0, zero=True)
         with seg("fwd_b", "M", ["dreal", "vggt"]):
             if early_on_side:
                 forward_frames(tc, T)
@@ -465,28 +457,44 @@ class TrainEngine:
                 gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
                 self._gan_losses(gd)
         hold.append(d_gen)
-        # ---- side: VGG pass of the MIDDLE frames [tc, tm) beside the first part of the BPTT (which only needs the last ones);
-        #      queued BEHIND D's own-gradient passes on the side stream, so that it runs beside the chain and not beside the
-        #      main stream's own VGG pass of the last frames
-        tm = tc + (T - tc + 1) // 2 if (self.use_vgg and (self.ov_parts & 16) and self._mode != "flat" and T - tc >= 2) else tc
-        if self.gan:
+        # ---- side: VGG pass of the LATE frames [tc, T) in frame-DESCENDING pieces: the BPTT needs frame T-1's gradient first.
+        #      Piece k only needs fwd_b's frames, so the whole train of pieces is queued on the side stream at once; the main
+        #      stream runs D's generator-side backward pass meanwhile and then the BPTT of a piece's frames as soon as THAT
+        #      piece is final -- the exposed part shrinks from the whole late pass (2.1 ms, profiles/r03b_seg_timeline.txt)
+        #      to what the first piece takes beyond D's backward pass.
+        late_on_side = self.use_vgg and bool(self.ov_parts & 64) and split and T > tc
+        late = []                                                    # [(t0, t1, segment name)] in BPTT order
+        # ONE piece (default): it runs beside D's two backward passes on the main stream -- throughput work beside throughput
+        # work, full-size tiles -- and the BPTT then has the chip to itself; several pieces (TG_VGG_LATE_CHUNK=<frames>) run
+        # beside the BPTT with co-residency tiles (measured slower: 2-frame pieces take 0.95 ms each, profiles/r03c_ab.txt).
+        one_piece = late_on_side and self.vgg_late_chunk >= T - tc
+        down_on_main = one_piece and os.environ.get("TG_DOWN_ON_MAIN", "1") == "1"
+        if late_on_side:
+            if self._d_vgg_late is None:
+                self._d_vgg_late = torch.empty(T - tc, B, H, H, 3, device=self.dev)
+            t1 = T
+            while t1 > tc:
+                t0 = max(tc, t1 - self.vgg_late_chunk)
+                name = "vgg_late%d" % len(late)
+                with seg(name, "S", ["fwd_b"]):
+                    self._vgg_chunk(gen, taps_t, t0, t1, _Shifted(self._d_vgg_late, tc), 0 if one_piece else K.CONV_COEXIST,
+                                    zero=True)
+                late.append((t0, t1, name))
+                t1 = t0
+        def d_own_gradients(cx):
+            self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
+            self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
+
+        if self.gan and not down_on_main:
             sk, cx = part(8)
             with seg("down", sk, ["fwd_b"]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
-                self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
-                self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
+                d_own_gradients(cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
             self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
-        d_vgg_mid = None
-        if tm > tc:
-            d_vgg_mid = self._d_vgg_mid = (torch.empty(tm - tc, B, H, H, 3, device=self.dev) if self._d_vgg_mid is None
-                                           else self._d_vgg_mid)
-            with seg("vgg_mid", "S", ["fwd_b"]):
-                # _vgg_chunk writes dst[t0:t1]: hand it a view whose index tc is the scratch tensor's first frame
-                self._vgg_chunk(gen, taps_t, tc, tm, _Shifted(d_vgg_mid, tc), K.CONV_COEXIST, zero=True)
         # ---- backward through the recurrence ------------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
         tail_split = self.exchange_mode == "captured"    # the RCCL segments hook in after wgrad and after FNet's backward
-        gw_side = bool(self.ov_parts & 32) and self._mode != "flat"
+        gw_side = bool(self.ov_parts & 32) and split
 
         def backward_frames(t1, t0):
             for t in range(t1 - 1, t0 - 1, -1):
@@ -494,32 +502,61 @@ class TrainEngine:
                 if t > 0:
                     K.warp_s2d_backward(dx_in, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
 
-        with (seg("bwd", "M", []) if (self.gan or self.use_vgg) else contextlib.nullcontext()):   # (no empty segments)
-            if self.gan:     # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
-                dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
-                K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
-                                        gd["off"], gd["merge"])
-                hold.append(dx)
-            if self.use_vgg and tm < T:                              # the last frames: straight into d_gen
-                self._vgg_chunk(gen, taps_t, tm, T, d_gen, 0, zero=False)
-            if tm > tc:
-                backward_frames(T, tm)                               # ... and their BPTT, while the side stream does [tc, tm)
-        with seg("bwd_b", "M", ["vgg_mid"] + vgg_segs):
-            if tm > tc:
-                K.lincomb(d_vgg_mid, None, d_gen[tc:tm], 1.0, 0.0, accumulate=True)
+        if self.gan or (self.use_vgg and not late_on_side and T > tc):
+            with seg("bwd", "M", []):
+                if self.gan:   # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
+                    dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
+                    K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
+                                            gd["off"], gd["merge"])
+                    hold.append(dx)
+                    if down_on_main:
+                        d_own_gradients(0)
+                if self.use_vgg and not late_on_side and T > tc:          # the late frames on the main stream: straight into d_gen
+                    self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
+            if self.gan and down_on_main:
+                self._exchange_seg("ar_d", ["tdiscriminator"], ["bwd"], with_balance=True)
+        # The BPTT in pieces.  tsplit = first frame of the "late" BPTT part: FNet's backward pass of the frame pairs >= tsplit-1
+        # (bit 128) and the generator's weight gradients of the frames >= tsplit (bit 256) can run on the side stream beside
+        # the BPTT of the frames below it.
+        tsplit = tc if self.use_vgg else (T + 1) // 2
+        fn_split = bool(self.ov_parts & 128) and split and 1 < tsplit < T
+        gw_split = bool(self.ov_parts & 256) and split and gw_side and 1 < tsplit < T
+        last_late = None
+        if late_on_side:
+            for k, (t0, t1, name) in enumerate(late):
+                last_late = "bptt%d" % k
+                with seg(last_late, "M", [name]):
+                    K.lincomb(self._d_vgg_late[t0 - tc:t1 - tc], None, d_gen[t0:t1], 1.0, 0.0, accumulate=True)
+                    backward_frames(t1, t0)
+        elif (fn_split or gw_split) and tsplit < T:
+            last_late = "bptt0"
+            with seg(last_late, "M", []):
+                backward_frames(T, tsplit)
+        bptt_from = tsplit if last_late is not None else T
+        fn_side = fn_split and last_late is not None
+        gw_late = gw_split and last_late is not None
+        if fn_side:                 # d_flow_t[t-1] is final once frame t's backward pass has run: pairs [tsplit-1, T-1)
+            with seg("fnet_late", "S", [last_late, "head"]):
+                self.Fn.backward(fsaved, d_flow, batch=((tsplit - 1) * B, (T - 1) * B), flags=K.CONV_COEXIST)
+        if gw_late:
+            with seg("wgrad_late", "S", [last_late]):
+                self.G.wgrad_sequence(tsplit, T, flags=K.CONV_COEXIST)
+        fn_rest = (0, (tsplit - 1) * B) if fn_side else None
+        gw_t1 = tsplit if gw_late else T
+        with seg("bwd_b", "M", ["vgg_early"] if self.use_vgg else []):
             if self.use_vgg:
                 K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)      # early frames (computed beside the chain)
-            backward_frames(tm if tm > tc else T, 0)
+            backward_frames(bptt_from, 0)
             if not tail_split and not gw_side:
                 self.G.wgrad_sequence(0, T)
-                self.Fn.backward(fsaved, d_flow)
+                self.Fn.backward(fsaved, d_flow, batch=fn_rest)
         if tail_split or gw_side:
             with seg("wgrad", "S" if gw_side else "M", ["bwd_b"]):       # (bit 32: beside FNet's backward pass)
-                self.G.wgrad_sequence(0, T)
-            self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
+                self.G.wgrad_sequence(0, gw_t1)
+            self._exchange_seg("ar_g", ["generator"], ["wgrad", "wgrad_late"])        # overlaps the FNet backward pass
             with seg("fnet_bwd"):
-                self.Fn.backward(fsaved, d_flow)
-            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
+                self.Fn.backward(fsaved, d_flow, batch=fn_rest)
+            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd", "fnet_late"])
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""

@@ -313,15 +313,26 @@ class FNet:
         flow = conv_fwd(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, 1, ACT_TANH, 24.0, out_dtype=_F32)
         return flow, ((saved, net, o1, flow) if keep else None)
 
-    def backward(self, saved_all, d_flow):
+    def backward(self, saved_all, d_flow, batch=None, flags=0):
+        """Backward pass (input gradient chain + weight gradients accumulated into the flat gradient buffer).
+        batch=(a, b): only the images [a, b) of the saved forward pass -- every loss is a sum over images, so the pass may run
+        in pieces (the engine runs the late frame pairs beside the BPTT of the early frames); flags: K.CONV_COEXIST for a
+        piece that runs beside the recurrent chain."""
         ps, p = self.ps, self.P
         saved, net_last, o1, flow = saved_all
+        if batch is not None:
+            a, b = batch
+            if b <= a:
+                return None
+            saved = [tuple(t[a:b] for t in trip) for trip in saved]
+            net_last, o1, flow, d_flow = net_last[a:b], o1[a:b], flow[a:b], d_flow[a:b]
         s = p + "output_stage/"
         g = K.act_backward(d_flow, flow, _empty(flow.shape, ps.act_dtype, flow), ACT_TANH, 24.0)
-        conv_wgrad(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, g)
-        g = conv_bwd_data(ps, s + "conv2/Conv/weights", g, o1.shape[1:3], 1, aux=o1, mask_act=ACT_LRELU, mask_alpha=0.2)
-        conv_wgrad(ps, s + "conv1/Conv/weights", s + "conv1/Conv/biases", net_last, g)
-        g = conv_bwd_data(ps, s + "conv1/Conv/weights", g, net_last.shape[1:3], 1)          # d (resampled map)
+        conv_wgrad(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, g, flags=flags)
+        g = conv_bwd_data(ps, s + "conv2/Conv/weights", g, o1.shape[1:3], 1, aux=o1, mask_act=ACT_LRELU, mask_alpha=0.2,
+                          flags=flags)
+        conv_wgrad(ps, s + "conv1/Conv/weights", s + "conv1/Conv/biases", net_last, g, flags=flags)
+        g = conv_bwd_data(ps, s + "conv1/Conv/weights", g, net_last.shape[1:3], 1, flags=flags)          # d (resampled map)
         for bi in range(len(FNET_BLOCKS) - 1, -1, -1):
             name = FNET_BLOCKS[bi][0]
             sc = p + name
@@ -330,12 +341,12 @@ class FNet:
                 g = K.maxpool2_backward(c2, g, torch.empty_like(c2), ACT_LRELU, 0.2)
             else:
                 g = K.upsample2_backward(g, torch.empty_like(c2), c2, ACT_LRELU, 0.2)
-            conv_wgrad(ps, sc + "/conv_2/Conv/weights", sc + "/conv_2/Conv/biases", c1, g)
+            conv_wgrad(ps, sc + "/conv_2/Conv/weights", sc + "/conv_2/Conv/biases", c1, g, flags=flags)
             g = conv_bwd_data(ps, sc + "/conv_2/Conv/weights", g, c1.shape[1:3], 1, aux=c1, mask_act=ACT_LRELU,
-                              mask_alpha=0.2)
-            conv_wgrad(ps, sc + "/conv_1/Conv/weights", sc + "/conv_1/Conv/biases", x_in, g)
+                              mask_alpha=0.2, flags=flags)
+            conv_wgrad(ps, sc + "/conv_1/Conv/weights", sc + "/conv_1/Conv/biases", x_in, g, flags=flags)
             if bi > 0:
-                g = conv_bwd_data(ps, sc + "/conv_1/Conv/weights", g, x_in.shape[1:3], 1)
+                g = conv_bwd_data(ps, sc + "/conv_1/Conv/weights", g, x_in.shape[1:3], 1, flags=flags)
         return None
 
 
