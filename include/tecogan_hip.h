@@ -220,6 +220,10 @@ int tg_affine(const float* x, float* out, int64_t n, float scale, float shift, v
  * hyper[k] = {lr_t, beta1, beta2, eps, gate, lr, 0, 0} for tg_adam_tf.  state layout: schedule.hip. */
 int tg_schedule_step(double* state, float* hyper, int nopt, int gated_opt, const float* t_balance /*nullable*/,
                      float beta1, float beta2, float eps, void* stream);
+/* Fade-in factor of the adversarial / layer losses, reference lib/Teco.py:379-380:
+ *   out[0] = min(rmax, r0 + add * state[0])   with state[0] = the device-side global step of tg_schedule_step,
+ * so that a captured step replays with a changing factor (consumed by tg_gan_losses / tg_l1_loss through their *_dev scalars). */
+int tg_dt_ratio(const double* state, float r0, float add, float rmax, float* out, void* stream);
 
 /* slim.batch_norm(train, scale=False, eps) + LeakyReLU (lib/ops.py:88-90, lib/Teco.py:38-39).
  * stats: [2][C] fp32 (mean, biased var) written by forward, read by backward. */
@@ -259,14 +263,16 @@ int tg_cosine_loss(const void* g, const void* t, int dtype, int64_t npix, int C,
                    float* cos_sum, void* d_g /*nullable*/, void* stream);
 
 /* L1 layer loss (lib/Teco.py:291-302): loss += loss_scale*sum|r-f|; d_f = -grad_scale*sign(r-f) (nullable). */
-int tg_l1_loss(const void* r, const void* f, int dtype, int64_t n, float loss_scale, float grad_scale, float* loss,
+int tg_l1_loss(const void* r, const void* f, int dtype, int64_t n, float loss_scale, float grad_scale,
+               const float* grad_scale_dev /*nullable: device scalar multiplied into grad_scale (dt_ratio)*/, float* loss,
                void* d_f /*nullable*/, void* stream);
 
 /* Adversarial losses (lib/Teco.py:374-399) on the sigmoid outputs of both D passes:
  * out = {t_adversarial_loss, t_discrim_loss, t_balance, mean(real), mean(fake)};
  * d_real_D/d_fake_D = gradient of t_discrim_loss, d_fake_G = gradient of adv_weight * t_adversarial_loss. */
-int tg_gan_losses(const float* real, const float* fake, int n, float eps, float adv_weight, float* out,
-                  float* d_real_D, float* d_fake_D, float* d_fake_G, void* stream);
+int tg_gan_losses(const float* real, const float* fake, int n, float eps, float adv_weight,
+                  const float* adv_weight_scale_dev /*nullable: device scalar multiplied into adv_weight (dt_ratio)*/,
+                  float* out, float* d_real_D, float* d_fake_D, float* d_fake_G, void* stream);
 
 /* Fused discriminator input (lib/Teco.py:180-272): for triplet k of sample b (frames 3k..3k+2 of the frame-major
  * sequence frames[T][B][4h][4w][3]): before-warp | warp with {up4(4*flow_pre[idx_pre[k]]), 0, up4(4*flow_nxt[idx_nxt[k]])}

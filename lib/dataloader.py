@@ -48,22 +48,83 @@ def inference_data_loader(FLAGS):
     return Data(paths_LR=paths, inputs=images)
 
 
+class _Prefetched:
+    """Background production of host batches into a fixed RING of pinned buffers (allocated before the thread starts: no
+    hipHostMalloc while the engine captures its hipGraphs), `prefetch` batches ahead.  Subclasses provide
+    `_host_batch() -> tuple of numpy arrays`.  A failure in the thread is handed to the consumer and re-raised by `_next_host`:
+    an exception there must not leave the training loop blocked on an empty queue.  The thread touches the buffers through
+    NUMPY views only: a torch CPU op here (`Tensor.copy_`) wakes torch's intra-op OpenMP team -- 256 threads on the GPU host --
+    and that alone stretched the launching thread's step() from 12.7 to 31 ms (tools/mb_mainloop.py, profiles/r03g_mainloop.txt)."""
+    _prefetch, _thread, _q = 0, None, None
+
+    def _worker(self):
+        slot = 0
+        try:
+            while True:
+                ev = self._ring_events[slot]
+                if ev is not None:
+                    ev.synchronize()                    # the H2D copies that last read this slot have finished
+                bufs = self._ring[slot]
+                for v, a in zip(self._ring_np[slot], self._host_batch()):
+                    np.copyto(v, a)
+                self._q.put((slot, bufs))
+                slot = (slot + 1) % len(self._ring)
+        except BaseException as e:                      # noqa: BLE001 -- re-raised in _next_host()
+            self._q.put(("error", e))
+
+    def _start_worker(self, shapes):
+        import queue
+        import threading
+        nslot = self._prefetch + 2                      # queue depth + one being filled + one being copied to the device
+        pin = torch.cuda.is_available()
+        self._ring = [[torch.empty(*sh, pin_memory=pin) for sh in shapes] for _ in range(nslot)]
+        self._ring_np = [[b.numpy() for b in bufs] for bufs in self._ring]
+        self._ring_events = [None] * nslot
+        self._q = queue.Queue(maxsize=self._prefetch)
+        self._thread = threading.Thread(target=self._worker, daemon=True)
+        self._thread.start()
+
+    def _next_host(self):
+        import queue
+        while True:
+            try:
+                item = self._q.get(timeout=5.0)
+                break
+            except queue.Empty:
+                if not self._thread.is_alive():
+                    raise RuntimeError('the loader thread died without reporting an error')
+        if item[0] == "error":
+            raise RuntimeError('the loader thread failed: %r' % (item[1],)) from item[1]
+        return item
+
+    def _to_device(self, slot, bufs):
+        out = [b.to(self.dev, non_blocking=True) for b in bufs]
+        if out and out[0].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ring_events[slot] = ev                # the ring slot is free once these copies are done
+        return out
+
+
 class SyntheticSequences:
-    """Seeded synthetic training sequences of the reference's shapes (no dataset offline)."""
+    """Seeded synthetic training sequences of the reference's shapes (no dataset offline).  On a GPU the batch is generated
+    ON THE DEVICE (a B=4 batch is 2 M random floats: ~10 ms of one host core, most of a TecoGAN step, against microseconds
+    of device time); on the CPU (tests) by the host generator."""
 
     def __init__(self, FLAGS, device, seed=1234):
-        self.F, self.dev = FLAGS, device
-        self.g = torch.Generator().manual_seed(seed)
+        self.F, self.dev = FLAGS, torch.device(device)
+        self.g = torch.Generator(device=self.dev if self.dev.type == "cuda" else "cpu").manual_seed(seed)
         self.image_count, self.steps_per_epoch = 10 ** 9, 10 ** 9 // FLAGS.batch_size
 
     def next_batch(self):
         F = self.F
-        x = torch.rand(F.batch_size, F.RNN_N, F.crop_size, F.crop_size, 3, generator=self.g)
-        y = torch.rand(F.batch_size, F.RNN_N, 4 * F.crop_size, 4 * F.crop_size, 3, generator=self.g) * 2 - 1
+        gen_dev = self.dev if self.dev.type == "cuda" else "cpu"
+        x = torch.rand(F.batch_size, F.RNN_N, F.crop_size, F.crop_size, 3, generator=self.g, device=gen_dev)
+        y = torch.rand(F.batch_size, F.RNN_N, 4 * F.crop_size, 4 * F.crop_size, 3, generator=self.g, device=gen_dev) * 2 - 1
         return x.to(self.dev, non_blocking=True), y.to(self.dev, non_blocking=True)
 
 
-class SceneSequences:
+class SceneSequences(_Prefetched):
     """Directory loader (reference lib/dataloader.py:53-167,276-348): shared random crop with a Gaussian margin, random
     flip, the moving-first-frame augmentation, GPU down-sampling + target crop + preprocess in one HIP launch.  PNG
     decoding and augmentation run in a background thread that keeps `prefetch` batches ahead (the reference uses
@@ -87,21 +148,67 @@ class SceneSequences:
         self.image_count = len(self.scenes) * (FLAGS.max_frm - FLAGS.RNN_N + 1)
         self.steps_per_epoch = self.image_count // FLAGS.batch_size
         self._q, self._thread, self._prefetch = None, None, prefetch
+        # PNG decoding is the loader's cost (B x RNN_N files per batch; a TecoGAN step is ~12 ms): decode in a thread pool
+        # (PIL releases the GIL while it inflates), FLAGS.queue_thread workers as the reference's queue runners
+        # (lib/dataloader.py:163-165), TG_LOADER_THREADS overrides
+        nthr = int(os.environ.get("TG_LOADER_THREADS", str(max(1, int(getattr(FLAGS, "queue_thread", 6))))))
+        self._pool, self._sizes = None, {}
+        # decoded-frame cache (uint8): a 352x288 PNG costs ~20 ms of one core to inflate and a TecoGAN step consumes 40 of them
+        # every ~12 ms, i.e. ~60 cores of pure decoding; scenes are revisited every epoch, so decoded frames are kept up to
+        # TG_LOADER_CACHE_GB (default 1/4 of the host RAM; 0 switches the cache off).  First-epoch batches are decode-bound.
+        try:
+            ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+        except (ValueError, OSError):
+            ram = 16 << 30
+        self._cache, self._cache_bytes = {}, 0
+        self._cache_cap = int(float(os.environ.get("TG_LOADER_CACHE_GB", str(ram / 4 / (1 << 30)))) * (1 << 30))
+        self.cache_hits = self.cache_misses = 0
+        if nthr > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=nthr)
+
+    def _decode_many(self, paths):
+        """uint8 [H,W,3] arrays (the crops are converted to float afterwards: 1/30 of the pixels at 720p)."""
+        def dec(p):
+            a = self._cache.get(p)
+            if a is not None:
+                self.cache_hits += 1
+                return a
+            from PIL import Image
+            with Image.open(p) as im:
+                a = np.asarray(im.convert("RGB"))
+            self.cache_misses += 1
+            if self._cache_bytes + a.nbytes <= self._cache_cap:     # (racing threads may both insert: same content, harmless)
+                self._cache[p] = a
+                self._cache_bytes += a.nbytes
+            return a
+        if self._pool is None or len(paths) < 2 or all(p in self._cache for p in paths):
+            return [dec(p) for p in paths]              # (all cached: no pool round trip, the fewer Python-level thread switches the better)
+        return list(self._pool.map(dec, paths))
+
+    def _frame_size(self, sd):
+        """(H, W) of a scene's frames from the PNG header (no decode), cached per scene."""
+        if sd not in self._sizes:
+            from PIL import Image
+            with Image.open(os.path.join(sd, 'col_high_%04d.png' % 0)) as im:
+                self._sizes[sd] = (im.size[1], im.size[0])
+        return self._sizes[sd]
 
     def _host_batch(self):
-        """One batch of HR crops [B,T,tar,tar,3] in [0,1] on the host (decode + augmentation)."""
+        """One batch of HR crops [B,T,tar,tar,3] in [0,1] on the host: all random decisions first (one RNG stream, fixed draw
+        order), then every PNG the batch needs decoded by the thread pool in one go, then the crops."""
         F = self.F
         border = int(1.5 * 3.0)
         tar = F.crop_size * 4 + 2 * border
-        seqs = []
+        plans, files = [], []
         for _ in range(F.batch_size):
             sd = self.scenes[self.rng.randint(len(self.scenes))]
             t0 = self.rng.randint(F.max_frm - F.RNN_N + 2)
             moving = bool(F.movingFirstFrame) and self.rng.rand() >= 0.7        # lib/dataloader.py:146 (30 % of the sequences)
-            first = _read_png(os.path.join(sd, 'col_high_%04d.png' % t0)) / 255.0
-            H, W = first.shape[:2]
+            H, W = self._frame_size(sd)
             oy, ox = self.rng.randint(H - tar + 1), self.rng.randint(W - tar + 1)
             flip = bool(F.flip) and self.rng.rand() < 0.5
+            lt = fy = fx = None
             if moving:
                 # camera-motion augmentation (lib/dataloader.py:112-125,138-146): every frame is the FIRST frame, cropped at
                 # a random walk of integer offsets in [-4, 4] per step; the walk is shifted so that all crops stay inside
@@ -112,17 +219,23 @@ class SceneSequences:
                 lt = pos - mn
                 fy = int(np.clip(oy, 0, H - tar - rng_xy[1]))
                 fx = int(np.clip(ox, 0, W - tar - rng_xy[0]))
-                src = first[:, ::-1] if flip else first
+            n = 1 if moving else F.RNN_N
+            plans.append((len(files), n, moving, flip, oy, ox, lt, fy, fx))
+            files += [os.path.join(sd, 'col_high_%04d.png' % (t0 + i)) for i in range(n)]
+        imgs = self._decode_many(files)
+        seqs = []
+        for i0, n, moving, flip, oy, ox, lt, fy, fx in plans:
+            frames = imgs[i0:i0 + n]
+            if flip:
+                frames = [f[:, ::-1] for f in frames]
+            if moving:
+                src = frames[0]
                 clip = np.stack([src[fy + lt[i, 1]:fy + lt[i, 1] + tar, fx + lt[i, 0]:fx + lt[i, 0] + tar]
                                  for i in range(F.RNN_N)])
             else:
-                frames = [first] + [_read_png(os.path.join(sd, 'col_high_%04d.png' % (t0 + i))) / 255.0
-                                    for i in range(1, F.RNN_N)]
-                if flip:
-                    frames = [f[:, ::-1] for f in frames]
                 clip = np.stack([f[oy:oy + tar, ox:ox + tar] for f in frames])
-            seqs.append(np.ascontiguousarray(clip, dtype=np.float32))
-        return np.stack(seqs)
+            seqs.append(np.ascontiguousarray(clip).astype(np.float32) / np.float32(255.0))
+        return (np.stack(seqs),)
 
     def _validate_geometry(self):
         """Every crop (incl. the moving-first-frame walk of up to 4 px per step) must fit the frames: checked once, up front,
@@ -136,64 +249,16 @@ class SceneSequences:
             raise ValueError('frames of %dx%d are too small for crop_size %d (need %d pixels%s)' % (
                 W, H, F.crop_size, need, ' incl. the movingFirstFrame walk' if F.movingFirstFrame else ''))
 
-    def _worker(self):
-        """Prefetch thread.  Fills a fixed RING of pinned host buffers allocated before the thread starts (no hipHostMalloc
-        while the engine captures its hipGraphs) and hands every failure to the consumer: an exception here must not leave
-        next_batch() blocked on an empty queue."""
-        slot = 0
-        try:
-            while True:
-                ev = self._ring_events[slot]
-                if ev is not None:
-                    ev.synchronize()                    # the H2D copy that last read this buffer has finished
-                buf = self._ring[slot]
-                buf.copy_(torch.from_numpy(self._host_batch()))
-                self._q.put((slot, buf))
-                slot = (slot + 1) % len(self._ring)
-        except BaseException as e:                      # noqa: BLE001 -- re-raised in next_batch()
-            self._q.put(("error", e))
-
-    def _start_worker(self):
-        import queue
-        import threading
-        F = self.F
-        self._validate_geometry()
-        tar = F.crop_size * 4 + 2 * int(1.5 * 3.0)
-        nslot = self._prefetch + 2                      # queue depth + one being filled + one being copied to the device
-        pin = torch.cuda.is_available()
-        self._ring = [torch.empty(F.batch_size, F.RNN_N, tar, tar, 3, pin_memory=pin) for _ in range(nslot)]
-        self._ring_events = [None] * nslot
-        self._q = queue.Queue(maxsize=self._prefetch)
-        self._thread = threading.Thread(target=self._worker, daemon=True)
-        self._thread.start()
-
-    def _next_host(self):
-        import queue
-        while True:
-            try:
-                item = self._q.get(timeout=5.0)
-                break
-            except queue.Empty:
-                if not self._thread.is_alive():
-                    raise RuntimeError('the loader thread died without reporting an error')
-        if item[0] == "error":
-            raise RuntimeError('the loader thread failed: %r' % (item[1],)) from item[1]
-        return item
-
     def next_batch(self):
         F = self.F
-        slot = None
         if self._prefetch > 0:
             if self._thread is None:
-                self._start_worker()
-            slot, host = self._next_host()
+                self._validate_geometry()
+                tar = F.crop_size * 4 + 2 * int(1.5 * 3.0)
+                self._start_worker([(F.batch_size, F.RNN_N, tar, tar, 3)])
+            hr, = self._to_device(*self._next_host())                           # [B,T,tar,tar,3] in [0,1]
         else:
-            host = torch.from_numpy(self._host_batch())
-        hr = host.to(self.dev, non_blocking=True)                               # [B,T,tar,tar,3] in [0,1]
-        if slot is not None and hr.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._ring_events[slot] = ev                                        # the ring slot is free once this copy is done
+            hr = torch.from_numpy(self._host_batch()[0]).to(self.dev, non_blocking=True)
         B, T, tar = hr.shape[0], hr.shape[1], hr.shape[2]
         lr, tgt = _ops.gauss_down_crop_preprocess(hr.reshape(B * T, tar, tar, 3), 1.5)
         cs = F.crop_size

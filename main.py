@@ -37,13 +37,16 @@ class Logger(object):
         self.log.flush()
 
 
-def save_checkpoint(eng, output_dir, step):
+def save_checkpoint(eng, output_dir, step, avg=None):
     """`<output_dir>/model-<step>` (torch file: exact resume) and, beside it, the same state as a TensorFlow tensor
-    bundle `model-<step>.index/.data-00000-of-00001` -- the files `saver.save` writes (reference main.py:365,420)."""
+    bundle `model-<step>.index/.data-00000-of-00001` -- the files `saver.save` writes (reference main.py:365,420).
+    avg = (running averages of the loss slots, their update count): the reference's EMA shadow variables are graph variables
+    and travel with its checkpoints, so the displayed averages continue after a resume instead of restarting from 0."""
     from tecogan_amd.checkpoint import save_bundle
     path = os.path.join(output_dir, "model-%d" % step)
     torch.save({"variables": eng.ps.state_dict(), "adam_m": eng.ps.m.cpu(), "adam_v": eng.ps.v.cpu(),
-                "sched": eng.sched.cpu(), "global_step": step}, path)
+                "sched": eng.sched.cpu(), "global_step": step, "avg_raw": None if avg is None else avg[0].cpu(),
+                "n_avg": 0 if avg is None else avg[1]}, path)
     steps = {scope: int(eng.sched[8 + 2 * k].item()) for k, scope in enumerate(eng.opt_scopes)}
     save_bundle(path, eng.ps, step, beta1=eng.F.beta, adam_steps=steps, tb_ema=float(eng.sched[1].item()))
     return path
@@ -75,8 +78,10 @@ def restore_training(eng, FLAGS):
             eng.ps.m.copy_(ck["adam_m"])
             eng.ps.v.copy_(ck["adam_v"])
             eng.sched.copy_(ck["sched"])
-        eng.host_step = int(eng.sched[0].item())              # dt_ratio fade-in continues where it stopped (Teco.py:379)
-        return
+        eng.host_step = int(eng.sched[0].item())
+        if ck.get("avg_raw") is not None:
+            return ck["avg_raw"], int(ck.get("n_avg", 0))
+        return None
     print('Loading weights from the pre-trained model to start a new training...')
     vals, zero = {}, 0
     for name, e in eng.ps.entries.items():
@@ -111,10 +116,18 @@ def run_inference(FLAGS):
         eng.load({k: v for k, v in saved.items() if k in eng.ps.entries})
     image_dir = FLAGS.output_dir if FLAGS.output_pre == "" else os.path.join(FLAGS.output_dir, FLAGS.output_pre)
     os.makedirs(image_dir, exist_ok=True)
-    max_iter, srtime = len(data.inputs), 0.0
+    max_iter = len(data.inputs)
     from tecogan_amd.output import FrameWriter
     writer = FrameWriter((4 * h, 4 * w, 3))                  # uint8 conversion on the GPU, async D2H, background encoding
     print('Frame evaluation starts!!')
+    try:
+        _inference_loop(FLAGS, data, eng, writer, image_dir, max_iter)
+    finally:
+        writer.close()                                        # in-flight frames are written even if the loop raises
+
+
+def _inference_loop(FLAGS, data, eng, writer, image_dir, max_iter):
+    srtime = 0.0
     for i in range(max_iter):
         frame = torch.from_numpy(data.inputs[i].copy()).float()[None].cuda()
         torch.cuda.synchronize()
@@ -129,11 +142,14 @@ def run_inference(FLAGS):
             writer.submit(os.path.join(image_dir, "%s.%s" % (filename, FLAGS.output_ext)), out[0])
         else:   # first 5 frames: mirrored warm-up, timed but not saved (reference main.py:268-269)
             print("Warming up %d" % (5 - i))
-    writer.close()
     print("total time " + str(srtime) + ", frame number " + str(max_iter))
 
 
 def run_training(FLAGS):
+    # The process drives a GPU: torch's intra-op OpenMP team (one thread per host CPU, 256 on the GPU box) is never useful here
+    # and, woken by any stray CPU tensor op, delays the thread that launches the step's graph segments (step() 12.7 -> 31 ms,
+    # tools/mb_mainloop.py).  The loader threads do their own parallel PNG decoding.
+    torch.set_num_threads(min(4, torch.get_num_threads()))
     from lib.dataloader import frvsr_gpu_data_loader
     from tecogan_amd.engine import TrainEngine
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -149,8 +165,9 @@ def run_training(FLAGS):
     rdata = frvsr_gpu_data_loader(FLAGS, device=dev, synthetic=FLAGS.synthetic, rank=rank)
     eng = TrainEngine(FLAGS, dev, gan=gan, act_dtype=tdt, seed=FLAGS.rand_seed + 41, process_group=pg)
     print('Finish building the network.')
+    restored_avg = None
     if FLAGS.checkpoint is not None:
-        restore_training(eng, FLAGS)
+        restored_avg = restore_training(eng, FLAGS)
     if FLAGS.vgg_scaling > 0.0 and FLAGS.vgg_ckpt and os.path.exists(FLAGS.vgg_ckpt):
         from tecogan_amd.checkpoint import load_variables
         vgg_vars, _ = load_variables(FLAGS.vgg_ckpt)
@@ -170,6 +187,9 @@ def run_training(FLAGS):
     # step, zero-initialised): one tiny device-side kernel per step, read only on display steps
     from tecogan_amd import kernels as K
     avg_raw, n_avg = torch.zeros_like(eng.loss), 0
+    if restored_avg is not None and restored_avg[0].numel() == avg_raw.numel():
+        avg_raw.copy_(restored_avg[0])
+        n_avg = restored_avg[1]
     x, y = rdata.s_inputs, rdata.s_targets
     try:
         for step in range(max_iter):
@@ -191,18 +211,28 @@ def run_training(FLAGS):
                 print("learning_rate", float(eng.hyper[-1, 5].item()))
                 for name, val in L.items():
                     print(name, val)
+            if rank == 0 and (run_step % FLAGS.summary_freq) == 0:
+                # reference main.py:391-402: the raw loss scalars on a VALIDATION batch (the TensorBoard summaries themselves
+                # are out of scope); an eager pass of the step's program without the update segment
+                print('Run and Recording summary!!')
+                vx, vy = rdata.val_loader.next_batch()
+                V = eng.eval_losses(vx, vy)
+                print('-----------Validation data scalars-----------')
+                for name, val in V.items():
+                    if name not in ("t_balance", "t_balance_now"):
+                        print('val_' + name, val)
             if rank == 0 and (run_step % FLAGS.save_freq) == 0:
                 print('Save the checkpoint')
-                save_checkpoint(eng, FLAGS.output_dir, run_step)
+                save_checkpoint(eng, FLAGS.output_dir, run_step, (avg_raw, n_avg))
     except KeyboardInterrupt:
         if step > 1 and rank == 0:
             print('main.py: KeyboardInterrupt->saving the checkpoint')
-            save_checkpoint(eng, FLAGS.output_dir, run_step)
+            save_checkpoint(eng, FLAGS.output_dir, run_step, (avg_raw, n_avg))
         print('main.py: quit')
         sys.exit(0)
     torch.cuda.synchronize()
     if rank == 0:
-        save_checkpoint(eng, FLAGS.output_dir, run_step)
+        save_checkpoint(eng, FLAGS.output_dir, run_step, (avg_raw, n_avg))
     print('Optimization done!!!!!!!!!!!!')
 
 

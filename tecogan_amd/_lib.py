@@ -61,8 +61,9 @@ SIGNATURES = {
     "tg_vgg_preprocess_forward": [_P, _P, _I, _L, _I, _P],
     "tg_vgg_preprocess_backward": [_P, _I, _P, _L, _I, _P],
     "tg_cosine_loss": [_P, _P, _I, _L, _I, _F, _F, _P, _P, _P],
-    "tg_l1_loss": [_P, _P, _I, _L, _F, _F, _P, _P, _P],
-    "tg_gan_losses": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
+    "tg_l1_loss": [_P, _P, _I, _L, _F, _F, _P, _P, _P, _P],
+    "tg_gan_losses": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],
+    "tg_dt_ratio": [_P, _F, _F, _F, _P, _P],
     "tg_pack_d_input_forward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "tg_pack_d_input_backward": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }

@@ -4,8 +4,12 @@ Two on-disk forms, both keyed by the TF variable names:
   * a torch file `model-<step>` = {"variables", "adam_m", "adam_v", "sched", "global_step"} (exact resume of this backend);
   * a TensorFlow tensor bundle `model-<step>.index` / `.data-00000-of-00001` (tecogan_amd/tf_bundle.py), the format the
     reference's `tf.train.Saver` reads and writes (reference main.py:224,245,307-352,365,420).  Variables are stored under
-    their TF names, Adam slots under TF's slot names (`<optimizer scope>/<variable>/Adam`, `/Adam_1`; optimizer scopes
-    `generator_train`, `tdicriminator_train` [sic], reference lib/Teco.py:420,439), plus `global_step`.
+    their TF names, Adam slots under TF's slot names (`<scope>/<variable>/Adam`, `/Adam_1`) plus `global_step`.  The scope is
+    `generator_train` for ALL THREE optimisers: slots are created by `apply_gradients`, and the reference calls it for the
+    discriminator too inside `with tf.variable_scope('generator_train')` (lib/Teco.py:438,463 -- the optimiser OBJECT is built
+    under 'tdicriminator_train' [sic], :420, but that scope owns no variable).  Interoperability status: the VARIABLE names
+    are TF's (weights-only restore of `model/TecoGAN`-style files); the optimiser-state names are read off the reference graph
+    and have never been checked against a TF-written training checkpoint (none exists offline).
 `load_variables(path)` accepts the path of a torch file, a bundle prefix (`model/TecoGAN`-style prefixes of the pre-trained
 models) or a TensorFlow V1 tensor-slice file (slim's original `vgg_19.ckpt`).
 """
@@ -17,11 +21,20 @@ import torch
 
 from . import tf_bundle
 
-OPT_SCOPE = {"generator": "generator_train", "fnet": "generator_train", "tdiscriminator": "tdicriminator_train"}
-# TF names of each optimiser's bias-correction accumulators: the generator and FNet AdamOptimizers are both created under
-# variable_scope('generator_train') (lib/Teco.py:438-440), so the second one gets the "_1" suffix.
-POWER_KEY = {"generator": "generator_train/beta1_power", "fnet": "generator_train/beta1_power_1",
-             "tdiscriminator": "tdicriminator_train/beta1_power"}
+OPT_SCOPE = {"generator": "generator_train", "fnet": "generator_train", "tdiscriminator": "generator_train"}
+LEGACY_SCOPES = ("generator_train", "tdicriminator_train")           # round-2 files wrote D's slots under the latter
+
+
+def power_keys(scopes):
+    """TF names of each optimiser's bias-correction accumulators.  They are non-slot variables created by the first
+    `apply_gradients` of each optimiser, all under variable_scope('generator_train') and uniquified in creation order:
+    GAN graph (lib/Teco.py:463-468): discriminator, generator, fnet -> beta1_power, beta1_power_1, beta1_power_2;
+    FRVSR graph (lib/Teco.py:446-449): generator, fnet -> beta1_power, beta1_power_1."""
+    order = [s for s in ("tdiscriminator", "generator", "fnet") if s in scopes]
+    return {s: "generator_train/beta1_power" + ("_%d" % i if i else "") for i, s in enumerate(order)}
+
+
+STEPS_KEY = "tecogan_amd/adam_steps/"          # this backend's exact integer Adam step counts (one int64 per optimiser scope)
 TB_EMA_KEY = "tecogan_amd/t_balance_ema"      # this backend's key for the EMA(0.99) shadow of t_balance (Teco.py:415-417)
 
 
@@ -45,17 +58,27 @@ def load_variables(path):
     r = tf_bundle.BundleReader(path)
     variables, m, v, extra = OrderedDict(), {}, {}, {}
     import math
+    keys = set(r.keys())
+    b1 = float(r.get(TB_EMA_KEY + "/beta1")) if (TB_EMA_KEY + "/beta1") in keys else 0.9
+    if TB_EMA_KEY in keys:
+        extra["tb_ema"] = float(r.get(TB_EMA_KEY))
+    scopes_here = [sc for sc in ("tdiscriminator", "generator", "fnet") if any(k.startswith(sc + "/") for k in keys)]
     steps = {}
-    for key in r.keys():
-        if key == TB_EMA_KEY:
-            extra["tb_ema"] = float(r.get(key))
+    for scope, pk in power_keys(scopes_here).items():
+        if STEPS_KEY + scope in keys:                      # exact count written by this backend
+            steps[scope] = int(r.get(STEPS_KEY + scope))
             continue
-        for scope, pk in POWER_KEY.items():
-            if key == pk:                    # TF stores beta1^(t+1) after t updates
-                p1 = float(r.get(key))
-                b1 = float(r.get(TB_EMA_KEY + "/beta1")) if (TB_EMA_KEY + "/beta1") in r.keys() else 0.9
-                if 0.0 < p1 < 1.0:
-                    steps[scope] = max(int(round(math.log(p1) / math.log(b1))) - 1, 0)
+        # TF stores beta^(t+1) after t updates.  beta2_power = 0.999^(t+1) stays a normal float32 up to t ~ 8e4, while
+        # beta1_power = 0.9^(t+1) goes denormal near t ~ 830 and underflows at ~980: prefer beta2_power.
+        pk2 = pk.replace("beta1_power", "beta2_power")
+        if pk2 in keys and 0.0 < float(r.get(pk2)) < 1.0:
+            steps[scope] = max(int(round(math.log(float(r.get(pk2))) / math.log(0.999))) - 1, 0)
+        elif pk in keys and 0.0 < float(r.get(pk)) < 1.0:
+            steps[scope] = max(int(round(math.log(float(r.get(pk))) / math.log(b1))) - 1, 0)
+    if "tdiscriminator" in scopes_here and "tdicriminator_train/beta1_power" in keys and "tdiscriminator" not in steps:
+        p1 = float(r.get("tdicriminator_train/beta1_power"))          # round-2 layout
+        if 0.0 < p1 < 1.0:
+            steps["tdiscriminator"] = max(int(round(math.log(p1) / math.log(b1))) - 1, 0)
     if steps:
         extra["adam_steps"] = steps
     for key in r.keys():
@@ -63,7 +86,7 @@ def load_variables(path):
             continue
         if key.endswith("/Adam") or key.endswith("/Adam_1"):
             base = key.rsplit("/", 1)[0]
-            for scope in set(OPT_SCOPE.values()):                     # strip the optimizer's variable scope
+            for scope in LEGACY_SCOPES:                               # strip the optimizer's variable scope
                 if base.startswith(scope + "/"):
                     base = base[len(scope) + 1:]
             (m if key.endswith("/Adam") else v)[base] = torch.from_numpy(r.get(key))
@@ -94,10 +117,12 @@ def save_bundle(prefix, ps, global_step, beta1=0.9, beta2=0.999, adam_steps=None
             out["%s/%s/Adam" % (scope, name)] = ps.view(name, ps.m).detach().cpu().numpy()
             out["%s/%s/Adam_1" % (scope, name)] = ps.view(name, ps.v).detach().cpu().numpy()
     out["global_step"] = np.asarray(int(global_step), dtype=np.int64)
-    for scope in sorted(set(e["scope"] for e in ps.entries.values() if e["scope"] in POWER_KEY)):
+    scopes = [sc for sc in ("tdiscriminator", "generator", "fnet") if any(e["scope"] == sc for e in ps.entries.values())]
+    for scope, pk in power_keys(scopes).items():
         t = max(int((adam_steps or {}).get(scope, global_step)), 0)
-        out[POWER_KEY[scope]] = np.asarray(beta1 ** (t + 1), dtype=np.float32)         # TF stores beta^(t+1) after t updates
-        out[POWER_KEY[scope].replace("beta1_power", "beta2_power")] = np.asarray(beta2 ** (t + 1), dtype=np.float32)
+        out[pk] = np.asarray(beta1 ** (t + 1), dtype=np.float32)                        # TF stores beta^(t+1) after t updates
+        out[pk.replace("beta1_power", "beta2_power")] = np.asarray(beta2 ** (t + 1), dtype=np.float32)
+        out[STEPS_KEY + scope] = np.asarray(t, dtype=np.int64)
     out[TB_EMA_KEY + "/beta1"] = np.asarray(beta1, dtype=np.float32)
     if tb_ema is not None:
         out[TB_EMA_KEY] = np.asarray(tb_ema, dtype=np.float32)

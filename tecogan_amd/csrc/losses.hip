@@ -192,8 +192,9 @@ extern "C" int tg_cosine_loss(const void* g, const void* t, int dtype, int64_t n
 // L1 feature ("layer") loss (lib/Teco.py:291-302): loss += loss_scale * sum|r-f| ; d_f = -grad_scale*sign(r-f)
 template <typename T>
 __global__ __launch_bounds__(256) void l1_loss_kernel(const T* __restrict__ r, const T* __restrict__ f, int64_t n,
-                                                      float loss_scale, float grad_scale, float* __restrict__ loss,
-                                                      T* __restrict__ d_f) {
+                                                      float loss_scale, float grad_scale, const float* __restrict__ gscale,
+                                                      float* __restrict__ loss, T* __restrict__ d_f) {
+  if (gscale) grad_scale *= gscale[0];          // device-side fade-in factor (dt_ratio, lib/Teco.py:379-380,390)
   float s = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const float d = Elem<T>::ld(r + e) - Elem<T>::ld(f + e);
@@ -204,12 +205,12 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const T* __restrict__ r, c
 }
 
 extern "C" int tg_l1_loss(const void* r, const void* f, int dtype, int64_t n, float loss_scale, float grad_scale,
-                          float* loss, void* d_f, void* stream) {
+                          const float* grad_scale_dev, float* loss, void* d_f, void* stream) {
   TG_CHECK_ARG(r && f && loss && n > 0, "bad argument");
   dim3 grid(grid_1d(n, 256 * 4, 1024));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == TG_F32) hipLaunchKernelGGL((l1_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)r, (const float*)f, n, loss_scale, grad_scale, loss, (float*)d_f);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((l1_loss_kernel<u16>), grid, dim3(256), 0, st, (const u16*)r, (const u16*)f, n, loss_scale, grad_scale, loss, (u16*)d_f);
+  if (dtype == TG_F32) hipLaunchKernelGGL((l1_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)r, (const float*)f, n, loss_scale, grad_scale, grad_scale_dev, loss, (float*)d_f);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((l1_loss_kernel<u16>), grid, dim3(256), 0, st, (const u16*)r, (const u16*)f, n, loss_scale, grad_scale, grad_scale_dev, loss, (u16*)d_f);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -220,10 +221,12 @@ extern "C" int tg_l1_loss(const void* r, const void* f, int dtype, int64_t n, fl
 //   t_balance = mean(log(real+eps)) + t_adv.
 // Gradient seeds: d_real_D, d_fake_D (of t_discrim), d_fake_G (of adv_weight * t_adv).  One block.
 __global__ __launch_bounds__(256) void gan_losses_kernel(const float* __restrict__ real, const float* __restrict__ fake,
-                                                         int n, float eps, float adv_weight, float* __restrict__ out,
+                                                         int n, float eps, float adv_weight,
+                                                         const float* __restrict__ adv_scale, float* __restrict__ out,
                                                          float* __restrict__ d_real_D, float* __restrict__ d_fake_D,
                                                          float* __restrict__ d_fake_G) {
   __shared__ float red[5][4];
+  if (adv_scale) adv_weight *= adv_scale[0];    // device-side fade-in factor (dt_ratio, lib/Teco.py:379-384)
   float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   const float inv = 1.f / (float)n;
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
@@ -258,11 +261,12 @@ __global__ __launch_bounds__(256) void gan_losses_kernel(const float* __restrict
   }
 }
 
-extern "C" int tg_gan_losses(const float* real, const float* fake, int n, float eps, float adv_weight, float* out,
-                             float* d_real_D, float* d_fake_D, float* d_fake_G, void* stream) {
+extern "C" int tg_gan_losses(const float* real, const float* fake, int n, float eps, float adv_weight,
+                             const float* adv_weight_scale_dev, float* out, float* d_real_D, float* d_fake_D, float* d_fake_G,
+                             void* stream) {
   TG_CHECK_ARG(real && fake && out && d_real_D && d_fake_D && d_fake_G && n > 0, "bad argument");
   hipLaunchKernelGGL(gan_losses_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), real, fake, n, eps,
-                     adv_weight, out, d_real_D, d_fake_D, d_fake_G);
+                     adv_weight, adv_weight_scale_dev, out, d_real_D, d_fake_D, d_fake_G);
   TG_CHECK_LAUNCH();
 }
 

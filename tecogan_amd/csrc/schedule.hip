@@ -49,3 +49,17 @@ extern "C" int tg_schedule_step(double* state, float* hyper, int nopt, int gated
                      gated_opt, t_balance, beta1, beta2, eps);
   TG_CHECK_LAUNCH();
 }
+
+// Fade-in factor of the adversarial / layer losses (lib/Teco.py:379-380): dt_ratio = min(max, r0 + add * global_step), from
+// the DEVICE-side step counter, so a captured step replays with a changing factor (no launch argument changes).
+__global__ void dt_ratio_kernel(const double* __restrict__ state, float r0, float add, float rmax, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double v = (double)r0 + (double)add * state[0];
+  out[0] = (float)(v < (double)rmax ? v : (double)rmax);
+}
+
+extern "C" int tg_dt_ratio(const double* state, float r0, float add, float rmax, float* out, void* stream) {
+  TG_CHECK_ARG(state && out, "bad argument");
+  hipLaunchKernelGGL(dt_ratio_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state, r0, add, rmax, out);
+  TG_CHECK_LAUNCH();
+}

@@ -143,36 +143,32 @@ class TrainEngine:
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
-        # frames per late VGG piece (the pieces run frame-DESCENDING on the side stream, the BPTT of a piece's frames starts as
-        # soon as that piece's gradient is final; bit 64 of TG_OVERLAP_PARTS)
-        self.vgg_late_chunk = max(1, int(os.environ.get("TG_VGG_LATE_CHUNK", "99")))
         self.lazy_side = os.environ.get("TG_LAZY_SIDE", "1") == "1"     # A/B switch: just-in-time side-stream launches
         # measurement mode: device wall-clock stamps at every segment boundary (one-thread kernels, captured with the segment)
         self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
         self.seg_stamp_names = {}
         self._pools = {}
         self._done, self._mode, self._main, self._d_vgg, self._d_vgg_late = {}, "flat", None, None, None
-        # a fading-in adversarial weight (Dt_ratio_add != 0) changes a launch argument every step: run eagerly
-        self.use_graph = use_graph and not (gan and F.Dt_ratio_add != 0.0)
+        # the fade-in factor of the adversarial / layer losses (lib/Teco.py:379-380) is a DEVICE scalar derived from the
+        # device-side step counter at the head of every step: Dt_ratio_add != 0 stays inside the captured graph
+        self.dt_ratio = torch.ones(1, device=self.dev)
+        self.use_graph = use_graph
         self.host_step = 0
+        self._skip_update = False
         self.gen = None
         self.side_stream = torch.cuda.Stream(device=self.dev)
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
-        # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass,
-        # 64 VGG pass of the LATE frames in frame-descending pieces beside D's generator-side backward pass and the BPTT of
-        # the frames above them (instead of one exposed piece on the main stream before the BPTT),
-        # 128 FNet's backward pass of the late frame pairs beside the BPTT of the early frames (their flow gradients are
-        # final once the BPTT has passed them), 256 the generator's weight gradients of the late frames beside the BPTT
-        # of the early frames.
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "239")) & 0x1ef) if self.overlap else 0
+        # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass, 64 the VGG pass
+        # of the late frames beside D's generator-side backward pass (before the BPTT)
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
-        uses_side = (self.use_vgg and self.ov_parts & 69) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 416)
+        uses_side = (self.use_vgg and self.ov_parts & 69) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 32)
         self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
         # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
         # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
@@ -196,6 +192,20 @@ class TrainEngine:
         if self._segs is None:
             self._capture()
         self._replay()
+
+    def eval_losses(self, r_inputs, r_targets):
+        """The loss scalars of `losses()` on a batch WITHOUT updating anything that training reads (reference main.py:391-402:
+        the validation fetches every summary_freq steps).  Runs the step's program eagerly and skips the update segment:
+        weights, Adam moments, the step counter and the balance average are untouched (the gradient buffer is overwritten --
+        every training step clears it first -- and D's unused batch-norm moving statistics take one more update)."""
+        self.set_batch(r_inputs, r_targets)
+        self._skip_update = True
+        try:
+            self._run_program("eager")
+        finally:
+            self._skip_update = False
+        torch.cuda.synchronize(self.dev)
+        return self.losses()
 
     # ------------------------------------------------------------------------------------------
     # Execution model: a step is a DAG of SEGMENTS.  A segment is a run of launches on one of three streams -- "M" the
@@ -318,12 +328,16 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
-        after = ["down", "bwd", "wgrad", "wgrad_late", "fnet_late"]
+        if self.gan and self._mode == "eager":
+            self.D.set_scratch(None)            # the BN scratch pool is valid inside a step only (sticky cursor)
+        if self._skip_update:
+            return
+        after = ["down", "wgrad"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["down", "bwd", "wgrad", "wgrad_late", "fnet_late", "ar_d", "ar_g", "ar_f"]
+            after = ["down", "wgrad", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
 
@@ -378,6 +392,7 @@ class TrainEngine:
             self.zbuf.zero_()
             if self.gan:
                 self.D.set_scratch(self.bn_pool)
+                K.dt_ratio(self.sched, F.Dt_ratio_0, F.Dt_ratio_add, F.Dt_ratio_max, self.dt_ratio)
             # ping-pong extension (lib/Teco.py:80-85) + [B,T] -> frame-major [T,B] in one gather each
             lr_seq = K.seq_gather(self.in_lr, torch.empty(T, B, h, h, 3, device=self.dev), self.seq_idx)
             hr_seq = K.seq_gather(self.in_hr, torch.empty(T, B, H, H, 3, device=self.dev), self.seq_idx)
@@ -457,38 +472,24 @@ class TrainEngine:
                 gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
                 self._gan_losses(gd)
         hold.append(d_gen)
-        # ---- side: VGG pass of the LATE frames [tc, T) in frame-DESCENDING pieces: the BPTT needs frame T-1's gradient first.
-        #      Piece k only needs fwd_b's frames, so the whole train of pieces is queued on the side stream at once; the main
-        #      stream runs D's generator-side backward pass meanwhile and then the BPTT of a piece's frames as soon as THAT
-        #      piece is final -- the exposed part shrinks from the whole late pass (2.1 ms, profiles/r03b_seg_timeline.txt)
-        #      to what the first piece takes beyond D's backward pass.
+        # ---- side: VGG pass of the LATE frames [tc, T) as ONE full-tile piece on the side stream, beside D's generator-side
+        #      backward pass on the main stream (throughput work beside throughput work); the BPTT starts when both are done and
+        #      D's own-gradient passes run beside it.  Measured (same box, profiles/r03e_ab.txt): 12.87 -> 12.68 ms against the
+        #      late pass on the main stream.  Frame-DESCENDING pieces of 1 / 2 / 4 frames beside the BPTT of the frames above
+        #      them were slower (16.3 / 13.8 / 12.85 ms, profiles/r03c_ab.txt: a 2-frame VGG pass takes 0.95 ms beside the chain
+        #      against 0.36 ms pro rata), and so were FNet's backward pass / the generator's weight gradients of the late frames
+        #      beside the BPTT of the early ones (neutral: their launches are latency-bound, two half-batch passes cost twice).
         late_on_side = self.use_vgg and bool(self.ov_parts & 64) and split and T > tc
-        late = []                                                    # [(t0, t1, segment name)] in BPTT order
-        # ONE piece (default): it runs beside D's two backward passes on the main stream -- throughput work beside throughput
-        # work, full-size tiles -- and the BPTT then has the chip to itself; several pieces (TG_VGG_LATE_CHUNK=<frames>) run
-        # beside the BPTT with co-residency tiles (measured slower: 2-frame pieces take 0.95 ms each, profiles/r03c_ab.txt).
-        one_piece = late_on_side and self.vgg_late_chunk >= T - tc
-        down_on_main = one_piece and os.environ.get("TG_DOWN_ON_MAIN", "1") == "1"
         if late_on_side:
             if self._d_vgg_late is None:
                 self._d_vgg_late = torch.empty(T - tc, B, H, H, 3, device=self.dev)
-            t1 = T
-            while t1 > tc:
-                t0 = max(tc, t1 - self.vgg_late_chunk)
-                name = "vgg_late%d" % len(late)
-                with seg(name, "S", ["fwd_b"]):
-                    self._vgg_chunk(gen, taps_t, t0, t1, _Shifted(self._d_vgg_late, tc), 0 if one_piece else K.CONV_COEXIST,
-                                    zero=True)
-                late.append((t0, t1, name))
-                t1 = t0
-        def d_own_gradients(cx):
-            self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
-            self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
-
-        if self.gan and not down_on_main:
+            with seg("vgg_late", "S", ["fwd_b"]):
+                self._vgg_chunk(gen, taps_t, tc, T, _Shifted(self._d_vgg_late, tc), 0, zero=True)
+        if self.gan:
             sk, cx = part(8)
             with seg("down", sk, ["fwd_b"]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
-                d_own_gradients(cx)
+                self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
+                self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
             self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
         # ---- backward through the recurrence ------------------------------------------------------------------
@@ -509,54 +510,24 @@ class TrainEngine:
                     K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
                                             gd["off"], gd["merge"])
                     hold.append(dx)
-                    if down_on_main:
-                        d_own_gradients(0)
                 if self.use_vgg and not late_on_side and T > tc:          # the late frames on the main stream: straight into d_gen
                     self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
-            if self.gan and down_on_main:
-                self._exchange_seg("ar_d", ["tdiscriminator"], ["bwd"], with_balance=True)
-        # The BPTT in pieces.  tsplit = first frame of the "late" BPTT part: FNet's backward pass of the frame pairs >= tsplit-1
-        # (bit 128) and the generator's weight gradients of the frames >= tsplit (bit 256) can run on the side stream beside
-        # the BPTT of the frames below it.
-        tsplit = tc if self.use_vgg else (T + 1) // 2
-        fn_split = bool(self.ov_parts & 128) and split and 1 < tsplit < T
-        gw_split = bool(self.ov_parts & 256) and split and gw_side and 1 < tsplit < T
-        last_late = None
-        if late_on_side:
-            for k, (t0, t1, name) in enumerate(late):
-                last_late = "bptt%d" % k
-                with seg(last_late, "M", [name]):
-                    K.lincomb(self._d_vgg_late[t0 - tc:t1 - tc], None, d_gen[t0:t1], 1.0, 0.0, accumulate=True)
-                    backward_frames(t1, t0)
-        elif (fn_split or gw_split) and tsplit < T:
-            last_late = "bptt0"
-            with seg(last_late, "M", []):
-                backward_frames(T, tsplit)
-        bptt_from = tsplit if last_late is not None else T
-        fn_side = fn_split and last_late is not None
-        gw_late = gw_split and last_late is not None
-        if fn_side:                 # d_flow_t[t-1] is final once frame t's backward pass has run: pairs [tsplit-1, T-1)
-            with seg("fnet_late", "S", [last_late, "head"]):
-                self.Fn.backward(fsaved, d_flow, batch=((tsplit - 1) * B, (T - 1) * B), flags=K.CONV_COEXIST)
-        if gw_late:
-            with seg("wgrad_late", "S", [last_late]):
-                self.G.wgrad_sequence(tsplit, T, flags=K.CONV_COEXIST)
-        fn_rest = (0, (tsplit - 1) * B) if fn_side else None
-        gw_t1 = tsplit if gw_late else T
-        with seg("bwd_b", "M", ["vgg_early"] if self.use_vgg else []):
+        with seg("bwd_b", "M", ["vgg_early", "vgg_late"]):
+            if late_on_side:
+                K.lincomb(self._d_vgg_late, None, d_gen[tc:], 1.0, 0.0, accumulate=True)
             if self.use_vgg:
                 K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)      # early frames (computed beside the chain)
-            backward_frames(bptt_from, 0)
+            backward_frames(T, 0)
             if not tail_split and not gw_side:
                 self.G.wgrad_sequence(0, T)
-                self.Fn.backward(fsaved, d_flow, batch=fn_rest)
+                self.Fn.backward(fsaved, d_flow)
         if tail_split or gw_side:
             with seg("wgrad", "S" if gw_side else "M", ["bwd_b"]):       # (bit 32: beside FNet's backward pass)
-                self.G.wgrad_sequence(0, gw_t1)
-            self._exchange_seg("ar_g", ["generator"], ["wgrad", "wgrad_late"])        # overlaps the FNet backward pass
+                self.G.wgrad_sequence(0, T)
+            self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
             with seg("fnet_bwd"):
-                self.Fn.backward(fsaved, d_flow, batch=fn_rest)
-            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd", "fnet_late"])
+                self.Fn.backward(fsaved, d_flow)
+            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""
@@ -642,14 +613,13 @@ class TrainEngine:
         seeds of the three D backward passes."""
         F = self.F
         p_real, l_real, p_fake, l_fake = gd["p_real"], gd["l_real"], gd["p_fake"], gd["l_fake"]
-        dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * (self.host_step - 1))   # Teco.py:379-380
         gd["d_real_D"], gd["d_fake_D"], gd["d_fake_G"] = (torch.empty_like(p_real) for _ in range(3))
         # the five scalars land straight in their (contiguous) loss slots
         i0 = LI["t_adversarial_loss"]
         assert LOSS_NAMES[i0:i0 + 5] == ["t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output",
                                          "t_discrim_fake_output"]
-        K.gan_losses(p_real, p_fake, F.EPS, F.ratio * dt_ratio, self.loss[i0:i0 + 5], gd["d_real_D"], gd["d_fake_D"],
-                     gd["d_fake_G"])
+        K.gan_losses(p_real, p_fake, F.EPS, F.ratio, self.loss[i0:i0 + 5], gd["d_real_D"], gd["d_fake_D"],
+                     gd["d_fake_G"], adv_scale_dev=self.dt_ratio)             # x dt_ratio (device scalar, Teco.py:379-384)
         gd["d_layers"] = None
         if F.D_LAYERLOSS:                                             # Teco.py:275-313,389-390
             gd["d_layers"] = []
@@ -657,7 +627,8 @@ class TrainEngine:
                 r, f = l_real[i], l_fake[i]
                 npix = float(r.numel() // r.shape[-1])
                 d = torch.empty_like(f)
-                K.l1_loss(r, f, 1.0 / npix, 0.02 / norm * dt_ratio / npix, self._slot("D_layer_%d_loss" % i), d)
+                K.l1_loss(r, f, 1.0 / npix, 0.02 / norm / npix, self._slot("D_layer_%d_loss" % i), d,
+                          grad_scale_dev=self.dt_ratio)
                 gd["d_layers"].append(d)
 
     # ------------------------------------------------------------------------------------------
@@ -689,7 +660,7 @@ class TrainEngine:
             if F.pp_scaling > 0:
                 gen_loss += F.pp_scaling * raw["PingPang"]
         if self.gan:
-            dt_ratio = min(F.Dt_ratio_max, F.Dt_ratio_0 + F.Dt_ratio_add * max(self.host_step - 1, 0))
+            dt_ratio = float(self.dt_ratio.item())                          # the factor the last step ran with
             for k in ("t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output", "t_discrim_fake_output"):
                 out[k] = raw[k]
             gen_loss += F.ratio * raw["t_adversarial_loss"] * dt_ratio

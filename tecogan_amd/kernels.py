@@ -231,14 +231,19 @@ def cosine_loss(g, t, cos_scale, grad_scale, cos_sum, d_g):
                                _stream()), "tg_cosine_loss")
 
 
-def l1_loss(r, f, loss_scale, grad_scale, loss, d_f):
-    check(lib().tg_l1_loss(_p(r), _p(f), dt(r), r.numel(), loss_scale, grad_scale, _p(loss), _p(d_f), _stream()),
-          "tg_l1_loss")
+def l1_loss(r, f, loss_scale, grad_scale, loss, d_f, grad_scale_dev=None):
+    check(lib().tg_l1_loss(_p(r), _p(f), dt(r), r.numel(), loss_scale, grad_scale, _p(grad_scale_dev), _p(loss), _p(d_f),
+                           _stream()), "tg_l1_loss")
 
 
-def gan_losses(real, fake, eps, adv_weight, out, d_real_D, d_fake_D, d_fake_G):
-    check(lib().tg_gan_losses(_p(real), _p(fake), real.numel(), eps, adv_weight, _p(out), _p(d_real_D), _p(d_fake_D),
-                              _p(d_fake_G), _stream()), "tg_gan_losses")
+def gan_losses(real, fake, eps, adv_weight, out, d_real_D, d_fake_D, d_fake_G, adv_scale_dev=None):
+    check(lib().tg_gan_losses(_p(real), _p(fake), real.numel(), eps, adv_weight, _p(adv_scale_dev), _p(out), _p(d_real_D),
+                              _p(d_fake_D), _p(d_fake_G), _stream()), "tg_gan_losses")
+
+
+def dt_ratio(state, r0, add, rmax, out):
+    """out[0] = min(rmax, r0 + add * state[0]) from the device-side global step (lib/Teco.py:379-380)."""
+    check(lib().tg_dt_ratio(_p(state), r0, add, rmax, _p(out), _stream()), "tg_dt_ratio")
 
 
 def _int_array(v):

@@ -313,19 +313,10 @@ class FNet:
         flow = conv_fwd(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, 1, ACT_TANH, 24.0, out_dtype=_F32)
         return flow, ((saved, net, o1, flow) if keep else None)
 
-    def backward(self, saved_all, d_flow, batch=None, flags=0):
-        """Backward pass (input gradient chain + weight gradients accumulated into the flat gradient buffer).
-        batch=(a, b): only the images [a, b) of the saved forward pass -- every loss is a sum over images, so the pass may run
-        in pieces (the engine runs the late frame pairs beside the BPTT of the early frames); flags: K.CONV_COEXIST for a
-        piece that runs beside the recurrent chain."""
+    def backward(self, saved_all, d_flow, flags=0):
+        """Backward pass (input gradient chain + weight gradients accumulated into the flat gradient buffer)."""
         ps, p = self.ps, self.P
         saved, net_last, o1, flow = saved_all
-        if batch is not None:
-            a, b = batch
-            if b <= a:
-                return None
-            saved = [tuple(t[a:b] for t in trip) for trip in saved]
-            net_last, o1, flow, d_flow = net_last[a:b], o1[a:b], flow[a:b], d_flow[a:b]
         s = p + "output_stage/"
         g = K.act_backward(d_flow, flow, _empty(flow.shape, ps.act_dtype, flow), ACT_TANH, 24.0)
         conv_wgrad(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, g, flags=flags)

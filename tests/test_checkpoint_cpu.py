@@ -168,6 +168,40 @@ def test_bundle_resume_carries_adam_counters_and_balance_ema(tmp_path):
     assert extra["global_step"] == 40
     assert extra["adam_steps"] == {"tdiscriminator": 17, "generator": 40, "fnet": 40}
     assert abs(extra["tb_ema"] - 0.3125) < 1e-7
+    # optimiser-state names as the reference graph creates them (lib/Teco.py:438,463-468): every slot under 'generator_train',
+    # bias-correction accumulators uniquified in creation order D, G, FNet
+    from tecogan_amd.tf_bundle import BundleReader
+    keys = set(BundleReader(prefix).keys())
+    d0 = "tdiscriminator/discriminator_unit/input_stage/conv/Conv/weights"
+    assert "generator_train/" + d0 + "/Adam" in keys and "generator_train/" + d0 + "/Adam_1" in keys
+    assert not [k for k in keys if k.startswith("tdicriminator_train")]
+    assert abs(float(BundleReader(prefix).get("generator_train/beta1_power")) - 0.9 ** 18) < 1e-7        # D: 17 updates
+    assert abs(float(BundleReader(prefix).get("generator_train/beta1_power_2")) - 0.9 ** 41) < 1e-7      # FNet: 40
+    assert torch.equal(extra["adam_m"][d0], ps.view(d0, ps.m))
+
+
+def test_bundle_resume_recovers_long_run_adam_counts(tmp_path):
+    """float32 beta1_power = 0.9^(t+1) underflows near t ~ 980, so the count must come from the exact integer key
+    this backend writes, or -- for a file without it -- from beta2_power = 0.999^(t+1), which stays normal up to t ~ 8e4."""
+    from collections import OrderedDict
+    from tecogan_amd import params as P, tf_bundle
+    from tecogan_amd.checkpoint import STEPS_KEY, load_variables, save_bundle
+    specs = OrderedDict(generator=P.generator_spec(1), fnet=P.fnet_spec(), tdiscriminator=P.discriminator_spec())
+    ps = P.ParamStore(specs, "cpu")
+    prefix = str(tmp_path / "model-50000")
+    want = {"tdiscriminator": 31234, "generator": 50000, "fnet": 50000}
+    save_bundle(prefix, ps, 50000, adam_steps=want)
+    _, extra = load_variables(prefix)
+    assert extra["adam_steps"] == want
+    # the same file without the backend's own keys (what a TF-written checkpoint would look like)
+    r = tf_bundle.BundleReader(prefix)
+    stripped = OrderedDict((k, r.get(k)) for k in r.keys() if not k.startswith(STEPS_KEY))
+    assert float(stripped["generator_train/beta1_power"]) == 0.0             # underflowed: useless
+    p2 = str(tmp_path / "tf-like")
+    tf_bundle.write_bundle(p2, stripped)
+    _, extra2 = load_variables(p2)
+    for sc, t in want.items():
+        assert abs(extra2["adam_steps"][sc] - t) <= max(2, int(2e-4 * t)), (sc, extra2["adam_steps"][sc], t)
 
 
 def test_data_parallel_ranks_draw_different_batches():

@@ -134,6 +134,31 @@ def test_tecogan_three_steps_graph_and_gate():
     assert eng.global_step() == 3
 
 
+def test_tecogan_fading_in_adversarial_weight_stays_captured():
+    """lib/Teco.py:379-380: dt_ratio = min(Dt_ratio_max, Dt_ratio_0 + Dt_ratio_add * global_step) scales the adversarial and
+    layer losses.  The factor is a device scalar derived from the device-side step counter, so the step is CAPTURED (round 2
+    dropped to eager launches whenever Dt_ratio_add != 0) and three replays run with 0.25, 0.5, 0.75."""
+    F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=2, Dt_ratio_0=0.25, Dt_ratio_add=0.25,
+                         Dt_ratio_max=1.0)
+    eng = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=7, use_graph=True)
+    assert eng.use_graph
+    S = OT.State(F, seed=42, gan=True)
+    eng.ps.load(S.P)
+    eng.vps.load(S.vgg)
+    x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
+    for k in range(3):
+        R = OT.train_step(S, x, y)
+        eng.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        assert abs(float(eng.dt_ratio.item()) - (0.25 + 0.25 * k)) < 1e-6
+        if k == 0:          # first step: exact comparison incl. every gradient (the factor enters G's gradients only)
+            check_step(S, eng, R, 1e-3)
+    assert eng._segs is not None and all(s["graph"] is not None for s in eng._segs)     # replayed graphs, no eager launches
+    mine, ref = eng.losses(), dict(zip(R["names"], [float(v) for v in R["vals"]]))
+    for name in ("t_adversarial_loss", "D_layer_loss_sum", "All_loss_Gen"):
+        assert abs(mine[name] - ref[name]) <= 0.1 * max(1.0, abs(ref[name])), (name, mine[name], ref[name])
+
+
 def test_tecogan_no_pingpong_backward_flow_branch():
     """GAN without ping-pong: backward motion comes from an extra FNet call (lib/Teco.py:190-199)."""
     F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=1, pingpang=False, vgg_scaling=-0.2)
