@@ -199,23 +199,44 @@ def check_full_config(F, gan, tag):
     for name, val in zip(R["names"], R["vals"]):
         if name in L:
             assert abs(L[name] - float(val)) <= 1e-3 * max(1e-6, abs(float(val))), (tag, name, L[name], float(val))
-    stats = []
+    # DERIVED bounds: the same step by the fp32 ORACLE, also measured against the fp64 run -- the rounding a
+    # correct fp32 implementation of this graph has on this batch.  Per tensor the HIP path must be within
+    # max(floor, FACTOR x the fp32 oracle's own error) of the fp64 truth, in relative L2 AND in max-norm; the blanket caps of
+    # round 2 stay as the outer bound for the (at most 2) discriminator tensors whose max-norm is decided by a LeakyReLU mask
+    # flip that the fp32 oracle may or may not share (bimodal from run to run, profiles/r02z_c3_repeat.txt).
+    from tecogan_amd.params import damp_values
+    S0 = OT.State(F, seed=42, gan=gan, dtype=torch.float64)           # the weights run_pair started from (seeded), damped
+    S32 = OT.State(F, seed=42, gan=gan, dtype=torch.float32)
+    S32.P = type(S0.P)((k, v.float()) for k, v in damp_values(S0.P).items())
+    if S0.vgg is not None:
+        S32.vgg = type(S0.vgg)((k, v.float()) for k, v in S0.vgg.items())
+    x32, y32 = make_batch(F.batch_size, F.RNN_N, F.crop_size)
+    R32 = OT.train_step(S32, x32, y32)
+    FACTOR, L2_FLOOR, MX_FLOOR = 1.5, 1e-3, 2e-3
+    stats, mask_flips, table = [], [], []
     for name, g in R["grads"].items():
         mine = eng.ps.gview(name).detach().cpu().double()
         ref = g.detach().double()
-        l2 = ((mine - ref).norm() / ref.norm().clamp_min(1e-30)).item()
-        assert l2 < 8e-3, "%s gradient %s relative L2 error %g" % (tag, name, l2)
+        o32 = R32["grads"][name].detach().double()
+        nrm = ref.norm().clamp_min(1e-30)
+        l2, l2_o = ((mine - ref).norm() / nrm).item(), ((o32 - ref).norm() / nrm).item()
+        mx, mx_o = max_rel_err(mine, ref), max_rel_err(o32, ref)
+        table.append((l2 / max(L2_FLOOR, FACTOR * l2_o), name, l2, l2_o, mx, mx_o))
+        assert l2 <= max(L2_FLOOR, FACTOR * l2_o), "%s gradient %s: relative L2 error %.3g vs the fp64 oracle, fp32 oracle's own %.3g" % (
+            tag, name, l2, l2_o)
+        if mx > max(MX_FLOOR, FACTOR * mx_o):
+            mask_flips.append((name, mx, mx_o))
         pe = per_elem_err(mine, ref, floor=2e-2).max().item()
-        mx = max_rel_err(mine, ref)
-        # Max-norm: 1e-2 for all but at most 2 % of a tensor's elements, 5e-2 as the hard cap.  The discriminator's tensors are
-        # BIMODAL from run to run, in the serial schedule as much as in the overlapped one (tools/c3_repeat.py,
-        # profiles/r02z_c3_repeat.txt: disblock_7/conv1 at 3.1e-2 in two of six runs -- the same figure in both schedules --
-        # and below 1e-2 in the others): with the order of the fp32 atomics a LeakyReLU pre-activation within rounding of 0
-        # flips its mask, which rescales one output channel's slice of that layer's weight gradient (0.4 % of the tensor).
         bad = ((mine - ref).abs() > 1e-2 * ref.abs().max()).double().mean().item()
-        assert bad <= 2e-2 and mx < 5e-2, "%s gradient %s max error / max|ref| %g (%.2f %% of the elements above 1e-2)" % (
-            tag, name, mx, 100 * bad)
+        assert l2 < 8e-3 and bad <= 2e-2 and mx < 5e-2, "%s gradient %s: outer caps: L2 %g, max-norm %g (%.2f %% of the elements above 1e-2)" % (
+            tag, name, l2, mx, 100 * bad)
         stats.append((l2, pe, mx))
+    table.sort(reverse=True)
+    print("\n[%s] closest to the derived L2 bound (ratio, tensor, L2 hip, L2 fp32-oracle, max hip, max fp32-oracle):" % tag)
+    for row in table[:4]:
+        print("    %.2f %s %.2e %.2e %.2e %.2e" % row)
+    assert len(mask_flips) <= 2 and all(n.startswith("tdiscriminator") for n, _, _ in mask_flips), \
+        "%s: max-norm beyond the derived bound on %s" % (tag, mask_flips)
     print("\n[%s] gen per-pixel err %.2e; %d gradient tensors vs the fp64 oracle: worst L2 %.2e (%d above 1e-3), worst max-norm "
           "%.2e, worst per-element (floor 2e-2) %.2e" %
           (tag, worst, len(stats), max(s[0] for s in stats), sum(s[0] > 1e-3 for s in stats), max(s[2] for s in stats),
