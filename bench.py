@@ -415,6 +415,31 @@ def main():
     F = eng.F
     x, y = synthetic_batch(F, 1234 + rank, device)
     eng.set_batch(x, y)
+    capture_failure = None
+    if world > 1:
+        assert torch.distributed.get_world_size() == a.gpus, "ranks != --gpus"
+        # The engine treats a failed capture of the RCCL collectives as an ERROR (no silent fallback).  The bench must still
+        # deliver a number on the first multi-GPU node it ever sees: a failure is caught HERE, reported on stderr and in the
+        # JSON line (config.exchange), and the run continues with the eager-split exchange.  All ranks decide together.
+        ok = torch.ones(1, device=device)
+        try:
+            eng.step()
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            capture_failure = "%s: %s" % (type(e).__name__, str(e)[:200])
+            ok.zero_()
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if ok.item() == 0:
+            print("bench.py: CAPTURED RCCL EXCHANGE FAILED on rank %d (%s) -- falling back to the eager-split exchange"
+                  % (rank, capture_failure), file=sys.stderr, flush=True)
+            capture_failure = capture_failure or "failed on another rank"
+            os.environ["TG_EXCHANGE"] = "eager"
+            del eng
+            torch.cuda.synchronize()
+            eng = new_engine(a.config, a.dtype, device, pg, use_graph=not a.no_graph)
+            eng.set_batch(x, y)
+        else:
+            capture_failure = None
     dt = time_steps(eng, a.steps, a.warmup, fence)
     host_ms = HOST_ENQUEUE_MS[0]
     # host cost of enqueueing ONE step on an idle device (no queue back-pressure, side segments enqueued ahead instead of
@@ -446,7 +471,9 @@ def main():
             cfg["collective_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
             cfg["ranks"] = torch.distributed.get_world_size()
             cfg["allreduce_bytes_per_step"] = eng.allreduce_bytes()
-            cfg["exchange"] = eng.exchange_mode
+            cfg["exchange"] = eng.exchange_mode if capture_failure is None else \
+                "eager-split (FALLBACK: the captured RCCL exchange failed: %s)" % capture_failure
+            cfg["exchange_segments"] = list(eng.exchange_segments)
         line = {"metric": "4x SR train frames/sec (G+D step)" if a.config == "tecogan" else "4x SR train frames/sec (FRVSR step, no D)",
                 "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",

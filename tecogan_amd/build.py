@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
-    if force or procs or not os.path.exists(LIB):
+    if force or procs or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -46,15 +46,24 @@ typedef unsigned int u32x2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void_d;
 
 namespace {
-constexpr int DM_TH = 16, DM_HW = 18, DM_HALO = (DM_TH + 2) * DM_HW;      // 324 halo pixels
-constexpr int DM_HALO_INST = (DM_HALO * 4 + 63) / 64;                     // 21 wave-wide DMA instructions (1 KB each)
-constexpr int DM_HALO_ROUNDS = (DM_HALO_INST + 7) / 8;                    // 3 rounds of 8 waves (the last: waves 0..4)
-constexpr int DM_HALO_BYTES = DM_HALO_INST * 1024;                        // 21504 = 42 * 512 (swizzle period: 8 rows)
+constexpr int DM_TH = 16;
+// PK = images per tile side.  PK = 1: one 16 x 16 tile of a larger image, 18 x 18 halo.  PK = 2 / 4 (PACKED tiles, images of
+// exactly 8 x 8 / 4 x 4 pixels: VGG conv5, FNet's inner levels): the 16 x 16 output pixels are PK x PK whole images; each
+// image keeps its own zero border in the halo, so the halo is (16 + 2 PK)^2 pixels and output pixel (r, c) reads halo
+// (r + 2 (r / S) + kh, c + 2 (c / S) + kw), S = 16 / PK -- a per-wave row shift and a per-lane column shift on the fragment base.
+template <int PK> struct DmGeo {
+  static constexpr int S = 16 / PK;                                 // image side (PK > 1)
+  static constexpr int HW = 16 + 2 * PK;                            // halo row pitch in pixels (18 / 20 / 24)
+  static constexpr int HALO = HW * HW;                              // 324 / 400 / 576 halo pixels
+  static constexpr int HALO_INST = (HALO * 4 + 63) / 64;            // 21 / 25 / 36 wave-wide DMA instructions (1 KB each)
+  static constexpr int HALO_ROUNDS = (HALO_INST + 7) / 8;           // 3 / 4 / 5 rounds of 8 waves
+  static constexpr int HALO_BYTES = HALO_INST * 1024;               // 21504 / 25600 / 36864
+  static_assert(HALO_BYTES % 512 == 0, "regions must start on a multiple of 8 rows (swizzle period)");
+};
 constexpr int DM_W_INST = 9 * 64 * 4 / 64;                                // 36
 constexpr int DM_W_ROUNDS = (DM_W_INST + 7) / 8;                          // 5 (the last: waves 0..3)
 constexpr unsigned DM_OOB = 0x80000000u;
-static_assert(DM_HALO_BYTES % 512 == 0, "regions must start on a multiple of 8 rows (swizzle period)");
-constexpr int dm_buf_bytes(int nt) { return nt * DM_HALO_BYTES + DM_W_INST * 1024; }       // 58368 / 79872
+template <int PK> constexpr int dm_buf_bytes() { return DmGeo<PK>::HALO_BYTES + DM_W_INST * 1024; }   // 58368 / 62464 / 73728
 }  // namespace
 
 // Cycle stamps (tools/trace_dma.py builds a private -DTG_DMA_TRACE copy of the library; the product build has none of it).
@@ -72,15 +81,16 @@ extern "C" int tg_debug_dma_trace(unsigned long long* out) {
 #define DM_STAMP(i) do { } while (0)
 #endif
 
-// NT = pixel tiles per stage.  The kernel is bound by the L2 -> LDS stream, not by MFMA issue (stage trace, tools/trace_dma.py:
-// ~3900 cycles per stage against 2304 of MFMA work, the waves waiting on their DMA), and 64 % of a stage's bytes are the
-// weight panel.  NT = 2 multiplies one weight panel with the halos of TWO tiles (any two: consecutive in the tile order, so
-// also two 16 x 16 images): 39 instead of 57 KB per 256 output pixels.  2 x 78 KB of LDS leave no room for a workgroup of the
-// recurrent chain beside it, so launches that carry TG_CONV_COEXIST take NT = 1.
-template <bool HAS_RES, bool HAS_AUX, int NT>
+// (A two-tiles-per-stage variant -- one weight panel for two halos, 39 instead of 57 KB per 256 output pixels -- lost to tile
+// quantisation, 1044 vs 1143 TFLOP/s at [76,32,32,256], profiles/r02t_microbench.txt, and was removed in round 3.)
+template <bool HAS_RES, bool HAS_AUX, int PK>
 __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
-  constexpr int BUF = dm_buf_bytes(NT), WOFF = NT * DM_HALO_BYTES;
-  constexpr int ROUNDS = NT * DM_HALO_ROUNDS + DM_W_ROUNDS;                 // 8 / 11 DMA rounds per stage
+  using G = DmGeo<PK>;
+  constexpr int NT = 1;
+  constexpr int DM_HW = G::HW, DM_HALO = G::HALO, DM_HALO_INST = G::HALO_INST, DM_HALO_ROUNDS = G::HALO_ROUNDS;
+  constexpr int DM_HALO_BYTES = G::HALO_BYTES;
+  constexpr int BUF = dm_buf_bytes<PK>(), WOFF = DM_HALO_BYTES;
+  constexpr int ROUNDS = DM_HALO_ROUNDS + DM_W_ROUNDS;                      // 8 / 9 / 10 DMA rounds per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x BUF
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,8 +118,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     const int S = (wave + 8 * k) * 64 + lane;
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
     const int dy = q / DM_HW, dx = q - DM_HW * dy;
-    hrel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
-    hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
+    if constexpr (PK == 1) {
+      hrel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
+      hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
+    } else {                  // packed: block (by, bx) = image within the tile, (ry, rx) = pixel of that image (or its border)
+      constexpr int S = G::S;
+      const int by = dy / (S + 2), ry = dy - by * (S + 2) - 1, bx = dx / (S + 2), rx = dx - bx * (S + 2) - 1;
+      const int img = by * PK + bx;
+      const bool in = q < DM_HALO && (unsigned)ry < (unsigned)S && (unsigned)rx < (unsigned)S;
+      hrel[k] = ((img * S + ry) * S + rx) * row_bytes + ch * 16;           // images are contiguous: S * S pixels each
+      hcode[k] = img | (in ? (1 << 24) : 0);
+    }
   }
   // The 36 instructions of the weight panel are issued in an order ROTATED per workgroup: every workgroup of a channel
   // block streams the same 36 KB per stage (measured neutral against the fixed order, profiles/r02s_microbench.txt; kept).
@@ -135,12 +154,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int tile = unit * NT + t;
-      const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
-      const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
       d_tok[t] = tile < p.ntiles;
-      d_y0[t] = ty * DM_TH - 1;
-      d_x0[t] = tx * 16 - 1;
-      d_base[t] = ((n * p.H + d_y0[t]) * p.W + d_x0[t]) * row_bytes + chunk * 64;    // wave-uniform
+      if constexpr (PK == 1) {
+        const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+        const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+        d_y0[t] = ty * DM_TH - 1;
+        d_x0[t] = tx * 16 - 1;
+        d_base[t] = ((n * p.H + d_y0[t]) * p.W + d_x0[t]) * row_bytes + chunk * 64;    // wave-uniform
+      } else {                // packed: the tile's first image; d_y0 = images of the batch left from there on
+        d_y0[t] = p.N - tile * PK * PK;
+        d_x0[t] = 0;
+        d_base[t] = tile * PK * PK * G::S * G::S * row_bytes + chunk * 64;
+      }
     }
     d_wofs = chunk * 64;
     d_dst = smem + buf * BUF;
@@ -150,9 +175,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
       const int t = r / DM_HALO_ROUNDS, k = r % DM_HALO_ROUNDS;
       const int inst = wave + 8 * k;                                        // wave-uniform
       if (k + 1 < DM_HALO_ROUNDS || inst < DM_HALO_INST) {
-        const int dy = hcode[k] & 255, dx = (hcode[k] >> 8) & 255;
-        const bool ok = (hcode[k] >> 24) && d_tok[t] && (unsigned)(d_y0[t] + dy) < (unsigned)p.H &&
-                        (unsigned)(d_x0[t] + dx) < (unsigned)p.W;
+        bool ok;
+        if constexpr (PK == 1) {
+          const int dy = hcode[k] & 255, dx = (hcode[k] >> 8) & 255;
+          ok = (hcode[k] >> 24) && d_tok[t] && (unsigned)(d_y0[t] + dy) < (unsigned)p.H && (unsigned)(d_x0[t] + dx) < (unsigned)p.W;
+        } else {
+          ok = (hcode[k] >> 24) && d_tok[t] && (hcode[k] & 255) < d_y0[t];
+        }
         const unsigned off = ok ? (unsigned)(d_base[t] + hrel[k]) : DM_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_d*)(d_dst + t * DM_HALO_BYTES + inst * 1024), 16, (int)off, 0, 0, 0);
       }
@@ -185,7 +214,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   // ---- fragment addresses.  Halo fragment (row r, tap column kw): pixel q = Q0 + K with Q0 = 72 wm + frow (lane part)
   //      and K = 18 r + kw (compile time).  The swizzle bit (q >> 2) & 1 depends only on (Q0 + K) mod 8, so eight lane
   //      bases cover every K: the read is base[K & 7] + 64 K as an immediate offset -- no address arithmetic per read.
-  const int Q0 = wm * 4 * DM_HW + frow;
+  // packed tiles: + 2 halo rows per image block above this wave's rows (wave-uniform), + 2 columns per block left of the lane's
+  const int Q0 = PK == 1 ? wm * 4 * DM_HW + frow
+                         : (wm * 4 + 2 * ((wm * 4) / G::S)) * DM_HW + frow + 2 * (frow / G::S);
   int abase[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) abase[d] = Q0 * 64 + ((fg ^ ((((Q0 & 7) + d) >> 2 & 1) << 1)) << 4);
@@ -273,14 +304,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int tile = unit * NT + t;
-        const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
-        const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-        const int x = tx * 16 + frow;
+        int n, x, ybase;
+        if constexpr (PK == 1) {
+          const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+          const int ty = t1 % p.tiles_y;
+          n = t1 / p.tiles_y;
+          x = tx * 16 + frow;
+          ybase = ty * DM_TH + wm * 4;
+        } else {              // packed: tile row r = 4 wm + i, column frow -> image (r / S) PK + frow / S, pixel (r % S, frow % S)
+          n = tile * PK * PK + ((wm * 4) / G::S) * PK + frow / G::S;
+          x = frow % G::S;
+          ybase = (wm * 4) % G::S;
+        }
         unsigned offs[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int y = ty * DM_TH + wm * 4 + i;
-          const bool pok = tile < p.ntiles && y < p.H && x < p.W;
+          const int y = ybase + i;
+          const bool pok = tile < p.ntiles && y < p.H && x < p.W && n < p.N;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int co = cbase + j * 16 + fg * 4;
@@ -339,36 +379,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   }
 }
 
-template <bool HAS_RES, bool HAS_AUX, int NT>
+template <bool HAS_RES, bool HAS_AUX, int PK>
 static void launch_dma(const ConvDmaP& p, hipStream_t st) {
-  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX, NT>;
-  constexpr int LDS = 2 * dm_buf_bytes(NT);
+  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX, PK>;
+  constexpr int LDS = 2 * dm_buf_bytes<PK>();
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int nt = p.Cout / 64;
-  const int nunits = (p.ntiles + NT - 1) / NT;
+  const int nunits = p.ntiles;
   // persistent over work units: one workgroup per CU; grid.x a multiple of 8 so that the channel blocks of one pixel tile
   // (workgroup ids x, x + grid.x, ...) land on the SAME XCD and share its L2 copy of the halo
   int gx = 256 / nt;
   if (gx < 8) gx = 8;
   gx &= ~7;
   if (gx > nunits) gx = nunits;
-  static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>")
-                                           : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>");
+  static const char* const pname =
+      PK == 1 ? (HAS_RES ? (HAS_AUX ? "conv3x3_dma<res,aux>" : "conv3x3_dma<res>") : (HAS_AUX ? "conv3x3_dma<aux>" : "conv3x3_dma<>"))
+      : PK == 2 ? (HAS_RES ? (HAS_AUX ? "conv3x3_dma_pack2<res,aux>" : "conv3x3_dma_pack2<res>")
+                           : (HAS_AUX ? "conv3x3_dma_pack2<aux>" : "conv3x3_dma_pack2<>"))
+                : (HAS_RES ? (HAS_AUX ? "conv3x3_dma_pack4<res,aux>" : "conv3x3_dma_pack4<res>")
+                           : (HAS_AUX ? "conv3x3_dma_pack4<aux>" : "conv3x3_dma_pack4<>"));
   const double px = (double)p.N * p.H * p.W;
   TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
             px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(gx, nt), dim3(512),
             LDS, st, p);
 }
 
-template <int NT>
-static void launch_dma_nt(const ConvDmaP& p, bool res, bool aux, hipStream_t st) {
-  if (res && aux) launch_dma<true, true, NT>(p, st);
-  else if (res) launch_dma<true, false, NT>(p, st);
-  else if (aux) launch_dma<false, true, NT>(p, st);
-  else launch_dma<false, false, NT>(p, st);
+template <int PK>
+static void launch_dma_pk(const ConvDmaP& p, bool res, bool aux, hipStream_t st) {
+  if (res && aux) launch_dma<true, true, PK>(p, st);
+  else if (res) launch_dma<true, false, PK>(p, st);
+  else if (aux) launch_dma<false, true, PK>(p, st);
+  else launch_dma<false, false, PK>(p, st);
 }
 
 // Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
@@ -380,7 +424,10 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
   if (d->Cin % 32 != 0 || d->Cin < 64 || d->Cout % 64 != 0) return 0;
   if (d->act >= TG_ACT_TANH) return 0;
-  if (d->Hin <= 8 || d->Win <= 8) return 0;               // 8 x 8 and smaller: the packed tiles of conv3x3.hip
+  // images of exactly 8 x 8 / 4 x 4 pixels: packed tiles (4 / 16 whole images per 16 x 16 tile); other small sizes: conv3x3.hip
+  static const int min_wg_pack = getenv("TG_C3DMA_MIN_WG_PACK") ? atoi(getenv("TG_C3DMA_MIN_WG_PACK")) : 16;
+  const int pk = (d->Hin == 8 && d->Win == 8) ? 2 : ((d->Hin == 4 && d->Win == 4) ? 4 : 1);
+  if (pk == 1 && (d->Hin <= 8 || d->Win <= 8)) return 0;
   if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15)) return 0;
   const int64_t px = (int64_t)d->N * d->Hin * d->Win;
   const int64_t in_bytes = px * d->Cin * 2, out_bytes = px * d->Cout * 2, w_bytes = (int64_t)9 * d->Cout * d->Cin * 2;
@@ -393,11 +440,13 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   p.tiles_y = (p.H + DM_TH - 1) / DM_TH;
   p.tiles_x = (p.W + 15) / 16;
-  const int64_t ntiles = (int64_t)p.N * p.tiles_y * p.tiles_x;
+  const int64_t ntiles = pk == 1 ? (int64_t)p.N * p.tiles_y * p.tiles_x : ((int64_t)p.N + pk * pk - 1) / (pk * pk);
   // below ~a third of the chip's CUs the 8 x 64 tiles of conv3x3.hip (twice the workgroups) fill it better
-  if (ntiles * (p.Cout / 64) < min_wg || ntiles >= ((int64_t)1 << 30)) return 0;
+  if (ntiles * (p.Cout / 64) < (pk == 1 ? min_wg : min_wg_pack) || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-  launch_dma_nt<1>(p, res != nullptr, aux != nullptr, st);
+  if (pk == 2) launch_dma_pk<2>(p, res != nullptr, aux != nullptr, st);
+  else if (pk == 4) launch_dma_pk<4>(p, res != nullptr, aux != nullptr, st);
+  else launch_dma_pk<1>(p, res != nullptr, aux != nullptr, st);
   return 1;
 }

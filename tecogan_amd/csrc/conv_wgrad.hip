@@ -760,6 +760,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
   }
 }
 
+int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
+                       float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip
+
 static bool tg_wgrad_row3_applies(const tg_conv_desc* d, int ldx, int ldy) {
   static const bool enabled = getenv("TG_NO_WGRAD_ROW3") == nullptr;                               // A/B switch
   if (!enabled || d->KW != 3 || d->stride != 1 || d->pad_l != 1 || d->Win != d->Wout || d->Hin != d->Hout) return false;
@@ -806,9 +809,6 @@ static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, cons
   return tg_wgrad_row3_launch(d, 1, &x, ldx, &y, ldy, &dw, dbias ? &dbias : nullptr, st);
 }
 
-int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
-                       float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip
-
 extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
                                      const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
                                      void* stream) {
@@ -834,6 +834,8 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   static const bool enabled = getenv("TG_NO_WGRAD_BF16") == nullptr;
   if (!enabled || x_dtype != TG_BF16 || y_dtype != TG_BF16) return 0;
   if (ldx % 8 || ldy % 8 || (((uintptr_t)x | (uintptr_t)y) & 15)) return 0;
+  if (d->mode == 0 && ldx >= d->Cin && ldy >= d->Cout && tg_wgrad_tr_launch(d, 1, &x, ldx, &y, ldy, &dw, dbias ? &dbias : nullptr, st))
+    return 1;                           // 64-channel 3x3 layers on images whose width is a multiple of 32 (conv_wgrad_tr.hip)
   if (tg_wgrad_row3_try(d, x, ldx, y, ldy, dw, dbias, st)) return 1;
   WgradBP p;
   p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;

@@ -18,6 +18,10 @@
 //     tiles), and are added to dW with fp32 atomics once at the end; the bias gradient is one extra MFMA per fragment
 //     with an all-ones A operand in the waves of the first ci half.
 // Grouped like the row kernel: `groups` layers of identical geometry in one launch.
+// Images of any width that is a multiple of 32 (tiles of 8 x 32 pixels).  Second instantiation YC = 8 for the generator's
+// OUTPUT conv (64 -> 3 channels, gradient tensor channel-padded to 8: reference lib/frvsr.py:80 under tf.gradients): the four
+// waves split the 64 input channels, one 16-column MFMA tile holds the 3 (+5 zero, +8 don't-care) output channels; HBM-bound
+// on the 64-channel HR activation (159 MB per TecoGAN step): 215 us with the row kernel (0.8 TB/s, profiles/r03d_*).
 //
 // Round 3: validated on MI355X (tools/probe_tr.hip confirmed the lane map, profiles/r03a_probe_tr.txt; parity test in
 // tests/test_kernels_gpu.py) and default-on: the grouped trunk launch (32 layers x 76 images) 422.7 -> 353.1 us, 434 -> 520
@@ -33,9 +37,11 @@ struct WgradTrP {
   float* dws[TG_WTR_MAX_GROUPS];
   float* dbs[TG_WTR_MAX_GROUPS];
   int groups, nsplit;
-  int N, H;             // images, rows; W = 32, channels = 64 on both sides
-  int ntiles;           // N * H / 8
-  unsigned bytes;       // extent of every X / dY tensor
+  int N, H, W;          // images, rows, columns (W a multiple of 32, H of 8); X has 64 channels
+  int tiles_y, tiles_x;
+  int ntiles;           // N * tiles_y * tiles_x
+  int cout;             // real output channels (dW's innermost extent): 64, or <= 8 for the YC = 8 instantiation
+  unsigned xbytes, ybytes;
 };
 
 typedef short s16x4t __attribute__((ext_vector_type(4)));
@@ -43,37 +49,49 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) s16x4t lds_s16x4;
 
 namespace {
-constexpr int TR_W = 32, TR_TH = 8, TR_PIX = 128;                      // bytes per pixel (64 bf16 channels)
+constexpr int TR_W = 32, TR_TH = 8, TR_PIX = 128;                      // tile width; bytes per X pixel (64 bf16 channels)
 constexpr int TR_XSLOTS = (TR_TH + 2) * (TR_W + 2) * 8;               // 2720 16-byte slots of the X halo tile
 constexpr int TR_XINST = (TR_XSLOTS + 63) / 64;                       // 43 wave-wide DMA instructions
-constexpr int TR_YINST = TR_TH * TR_W * 8 / 64;                       // 32
 constexpr int TR_YOFF = TR_XINST * 1024;                              // 44032
-constexpr int TR_STAGE = (TR_XINST + TR_YINST) * 1024;                // 76800
-constexpr int TR_XROUNDS = (TR_XINST + 3) / 4, TR_YROUNDS = TR_YINST / 4;   // 11 + 8 DMA rounds of 4 waves
+constexpr int TR_XROUNDS = (TR_XINST + 3) / 4;                        // 11 DMA rounds of 4 waves
 constexpr unsigned TR_OOB = 0x80000000u;
+template <int YC> struct TrGeo {
+  static constexpr int YPIX = YC * 2;                                 // bytes per dY pixel
+  static constexpr int YROW_SLOTS = TR_W * YPIX / 16;                 // 16-byte slots per tile row: 256 / 32
+  static constexpr int YINST = TR_TH * YROW_SLOTS / 64;               // 32 / 4
+  static constexpr int YROUNDS = (YINST + 3) / 4;                     // 8 / 1
+  static constexpr int STAGE = (TR_XINST + YINST) * 1024;             // 76800 / 48128
+  static constexpr int ROUNDS = TR_XROUNDS + YROUNDS;                 // 19 / 12
+};
 }  // namespace
 
-// 8 consecutive K-values (pixels) of one channel for this lane: two transpose reads, 4 pixels apart
+// 8 consecutive K-values (pixels) of one channel for this lane: two transpose reads, 4 pixels (4 * pitch bytes) apart
+template <int PITCH>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
   const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * TR_PIX));
+  const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
   typedef short s16x8t __attribute__((ext_vector_type(8)));
   const s16x8t v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int YC>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x TR_STAGE
+  using G = TrGeo<YC>;
+  constexpr int YPIX = G::YPIX;
+  constexpr int NI = YC == 64 ? 2 : 1, NJ = YC == 64 ? 2 : 1;           // 16 x 16 accumulator tiles per wave (ci x co)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x STAGE (+ slack)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;                  // ci half / co half of the 64 x 64 block
+  // YC = 64: waves = (ci half, co half) of the 64 x 64 block; YC = 8: waves = the four 16-channel ci tiles, one co tile
+  const int ci0 = YC == 64 ? 32 * (wave >> 1) : 16 * wave;
+  const int co0 = YC == 64 ? 32 * (wave & 1) : 0;
   const int frow = lane & 15, fg = lane >> 4;
   const int grp = blockIdx.x / p.nsplit, split = blockIdx.x - grp * p.nsplit;
   const u16* __restrict__ gx = p.xs[grp];
   const u16* __restrict__ gy = p.ys[grp];
-  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.bytes, 0x00020000);
-  const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.bytes, 0x00020000);
-  const int tiles_y = p.H / TR_TH;
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.xbytes, 0x00020000);
+  const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.ybytes, 0x00020000);
 
   // ---- DMA slot descriptors.  X: slot S = (wave + 4k)*64 + lane -> halo pixel S / 8 = (dy, dx), 16-byte channel chunk S % 8
   int xrel[TR_XROUNDS], xcode[TR_XROUNDS];
@@ -82,54 +100,69 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
     const int S = (wave + 4 * k) * 64 + lane;
     const int q = S >> 3, c = S & 7;
     const int dy = q / (TR_W + 2), dx = q - (TR_W + 2) * dy;
-    xrel[k] = ((dy - 1) * TR_W + dx - 1) * TR_PIX + c * 16;
+    xrel[k] = ((dy - 1) * p.W + dx - 1) * TR_PIX + c * 16;
     xcode[k] = dy | (dx << 8) | (S < TR_XSLOTS ? (1 << 16) : 0);
   }
+  //      dY: slot S -> tile row S / YROW_SLOTS, 16-byte unit S % YROW_SLOTS of that row's 32 pixels
+  int yrel[G::YROUNDS];
+#pragma unroll
+  for (int k = 0; k < G::YROUNDS; ++k) {
+    const int S = (wave + 4 * k) * 64 + lane;
+    const int r = S / G::YROW_SLOTS, o = S - r * G::YROW_SLOTS;
+    yrel[k] = (wave + 4 * k) < G::YINST ? r * p.W * YPIX + o * 16 : -1;
+  }
   auto issue_dma = [&](int tile, int buf, int r0, int r1) {          // DMA rounds [r0, r1) of the stage (compile-time bounds)
-    const int n = tile / tiles_y, y0 = (tile - n * tiles_y) * TR_TH;
-    const int base = (n * p.H + y0) * TR_W * TR_PIX;                        // wave-uniform: byte offset of the tile's pixel (0,0)
-    unsigned char* dst = smem + buf * TR_STAGE;
+    const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
+    const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+    const int y0 = ty * TR_TH, x0 = tx * TR_W;
+    const int pix0 = (n * p.H + y0) * p.W + x0;                             // wave-uniform: the tile's pixel (0,0)
+    unsigned char* dst = smem + buf * G::STAGE;
 #pragma unroll
     for (int r = r0; r < r1; ++r) {
       if (r < TR_XROUNDS) {
         const int inst = wave + 4 * r;
         if (r + 1 < TR_XROUNDS || inst < TR_XINST) {
           const int dy = xcode[r] & 255, dx = (xcode[r] >> 8) & 255;
-          const bool ok = (xcode[r] >> 16) && (unsigned)(y0 + dy - 1) < (unsigned)p.H && (unsigned)(dx - 1) < (unsigned)TR_W;
-          const unsigned off = ok ? (unsigned)(base + xrel[r]) : TR_OOB;
+          const bool ok = (xcode[r] >> 16) && (unsigned)(y0 + dy - 1) < (unsigned)p.H && (unsigned)(x0 + dx - 1) < (unsigned)p.W;
+          const unsigned off = ok ? (unsigned)(pix0 * TR_PIX + xrel[r]) : TR_OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_t*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
         }
-      } else {                                                              // dY tile: 32 KB contiguous in memory
-        const int inst = wave + 4 * (r - TR_XROUNDS);
-        const unsigned off = (unsigned)(base + inst * 1024 + lane * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_void_t*)(dst + TR_YOFF + inst * 1024), 16, (int)off, 0, 0, 0);
+      } else if (r < G::ROUNDS) {
+        const int k = r - TR_XROUNDS;
+        const int inst = wave + 4 * k;
+        if (k + 1 < G::YROUNDS || inst < G::YINST) {
+          const unsigned off = yrel[k] >= 0 ? (unsigned)(pix0 * YPIX + yrel[k]) : TR_OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_void_t*)(dst + TR_YOFF + inst * 1024), 16, (int)off, 0, 0, 0);
+        }
       }
     }
   };
 
   int tile = split;
   if (tile >= p.ntiles) return;                             // (workgroup-uniform; its accumulators would be zero)
-  issue_dma(tile, 0, 0, TR_XROUNDS + TR_YROUNDS);
+  issue_dma(tile, 0, 0, G::ROUNDS);
 
   // ---- per-lane fragment bases: lane L = frow of group fg points at pixel 8 fg + L/4 (+4 for the second read), channels
-  //      c0 + 4 (L % 4); everything else (image row, tap shift, 16-channel tile) is a compile-time offset
+  //      c0 + 4 (L % 4); everything else (image row, tap shift, 16-channel tile) is a compile-time offset.  (YC = 8: the
+  //      lanes with L % 4 >= 2 point 16 / 24 bytes into the NEXT pixel -- they feed output columns 8..15, which are discarded.)
   const int lp = 8 * fg + (frow >> 2), lc = 4 * (frow & 3);
-  const int abase = lp * TR_PIX + (32 * wm + lc) * 2;       // halo (row 0, column lp) = image (y0 - 1, lp - 1): tap (0, 0) of row 0
-  const int bbase = TR_YOFF + lp * TR_PIX + (32 * wn + lc) * 2;
+  const int abase = lp * TR_PIX + (ci0 + lc) * 2;           // halo (row 0, column lp) = image (y0 - 1, x0 + lp - 1): tap (0, 0) of row 0
+  const int bbase = TR_YOFF + lp * YPIX + (co0 + lc) * 2;
 
-  f32x4 acc[9][2][2];
-  f32x4 accb[2];
+  f32x4 acc[9][NI][NJ];
+  f32x4 accb[NJ];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  accb[0] = accb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   typedef short s16x8o __attribute__((ext_vector_type(8)));
   const s16x8o ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
-  const bool do_bias = p.dbs[grp] != nullptr && wm == 0;    // wave-uniform
+  const bool do_bias = p.dbs[grp] != nullptr && ci0 == 0;   // wave-uniform
 
   int buf = 0;
   while (true) {
@@ -138,34 +171,34 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                           // everybody's; nobody still reads the other buffer
     const bool has_next = ntile < p.ntiles;
-    const unsigned char* sb = smem + buf * TR_STAGE;
+    const unsigned char* sb = smem + buf * G::STAGE;
 #pragma unroll
     for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
-      bf16x8 bq[2];
+      bf16x8 bq[NJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bq[j] = tr_frag(sb + bbase + yy * TR_W * TR_PIX + j * 32);
+      for (int j = 0; j < NJ; ++j) bq[j] = tr_frag<YPIX>(sb + bbase + yy * TR_W * YPIX + j * 32);
       if (do_bias) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
       }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          bf16x8 aq[2];
+          bf16x8 aq[NI];
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            aq[i] = tr_frag(sb + abase + ((yy + kh) * (TR_W + 2) + kw) * TR_PIX + i * 32);      // image (y0+yy+kh-1, lp+kw-1)
+          for (int i = 0; i < NI; ++i)
+            aq[i] = tr_frag<TR_PIX>(sb + abase + ((yy + kh) * (TR_W + 2) + kw) * TR_PIX + i * 32);   // image (y0+yy+kh-1, x0+lp+kw-1)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
               acc[kh * 3 + kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[j], acc[kh * 3 + kw][i][j], 0, 0, 0);
         }
-      // the next stage's 19 DMA rounds spread over the 8 rows (an LDS-DMA instruction costs 60-180 issue cycles)
+      // the next stage's DMA rounds spread over the 8 rows (an LDS-DMA instruction costs 60-180 issue cycles)
       if (has_next) {
         __builtin_amdgcn_sched_barrier(0);
-        if (yy < 7) issue_dma(ntile, buf ^ 1, yy * 3, yy * 3 + 3 < TR_XROUNDS + TR_YROUNDS ? yy * 3 + 3 : TR_XROUNDS + TR_YROUNDS);
+        if (yy < 7) issue_dma(ntile, buf ^ 1, yy * 3, yy * 3 + 3 < G::ROUNDS ? yy * 3 + 3 : G::ROUNDS);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -179,50 +212,65 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ci = 32 * wm + 16 * i + 4 * fg + r, co = 32 * wn + 16 * j + frow;
-          unsafeAtomicAdd(dw + (t * 64 + ci) * 64 + co, acc[t][i][j][r]);
+          const int ci = ci0 + 16 * i + 4 * fg + r, co = co0 + 16 * j + frow;
+          if (YC == 64 || co < p.cout) unsafeAtomicAdd(dw + (t * 64 + ci) * p.cout + co, acc[t][i][j][r]);
         }
   if (do_bias && fg == 0) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) unsafeAtomicAdd(p.dbs[grp] + 32 * wn + 16 * j + frow, accb[j][0]);
+    for (int j = 0; j < NJ; ++j) {
+      const int co = co0 + 16 * j + frow;
+      if (YC == 64 || co < p.cout) unsafeAtomicAdd(p.dbs[grp] + co, accb[j][0]);
+    }
   }
 }
 
-// returns 1 if launched (geometry of the generator trunk only), 0 otherwise
+template <int YC>
+static void wgrad_tr_go(const WgradTrP& p, double flops, double bytes, hipStream_t st) {
+  constexpr int LDS = 2 * TrGeo<YC>::STAGE + 64;            // + slack: the YC = 8 fragment reads reach 16 bytes past the last pixel
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel<YC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  TG_LAUNCH(YC == 64 ? "conv_wgrad_tr" : "conv_wgrad_tr_out", flops, bytes, conv_wgrad_tr_kernel<YC>,
+            dim3((unsigned)(p.groups * p.nsplit)), dim3(256), LDS, st, p);
+}
+
+// returns 1 if launched, 0 otherwise.  Geometries: 3x3 s1 SAME, 64 input channels (ldx = 64), images H % 8 == 0, W % 32 == 0;
+// 64 -> 64 (ldy = 64: the generator trunk, grouped) or 64 -> <= 8 with ldy = 8 (the generator's output conv).
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
                        float* const* dw, float* const* dbias, hipStream_t st) {
   static const bool enabled = getenv("TG_WGRAD_TR") == nullptr || atoi(getenv("TG_WGRAD_TR")) != 0;
   if (!enabled || groups < 1 || groups > TG_WTR_MAX_GROUPS) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->mode != 0) return 0;
-  if (d->Win != TR_W || d->Wout != TR_W || d->Hin != d->Hout || d->Hin % TR_TH != 0) return 0;
-  if (d->Cin != 64 || d->Cout != 64 || ldx != 64 || ldy != 64) return 0;
-  const int64_t bytes = (int64_t)d->N * d->Hin * TR_W * TR_PIX;
-  if (bytes >= ((int64_t)1 << 31)) return 0;
+  if (d->Win % TR_W != 0 || d->Wout != d->Win || d->Hin != d->Hout || d->Hin % TR_TH != 0) return 0;
+  const bool trunk = d->Cout == 64 && ldy == 64, outc = d->Cout <= 8 && ldy == 8;
+  if (d->Cin != 64 || ldx != 64 || !(trunk || outc)) return 0;
+  const int64_t px = (int64_t)d->N * d->Hin * d->Win;
+  if (px * TR_PIX >= ((int64_t)1 << 31)) return 0;
   WgradTrP p;
   for (int g = 0; g < TG_WTR_MAX_GROUPS; ++g) {
     const int k = g < groups ? g : 0;
     p.xs[g] = (const u16*)x[k]; p.ys[g] = (const u16*)y[k]; p.dws[g] = dw[k]; p.dbs[g] = dbias ? dbias[k] : nullptr;
   }
   p.groups = groups;
-  p.N = d->N; p.H = d->Hin;
-  p.ntiles = d->N * (d->Hin / TR_TH);
-  p.bytes = (unsigned)bytes;
-  int nsplit = 256 / groups;                                // one workgroup per CU (150 KB of LDS)
+  p.N = d->N; p.H = d->Hin; p.W = d->Win;
+  p.tiles_y = d->Hin / TR_TH; p.tiles_x = d->Win / TR_W;
+  p.ntiles = d->N * p.tiles_y * p.tiles_x;
+  p.cout = d->Cout;
+  p.xbytes = (unsigned)(px * TR_PIX);
+  p.ybytes = (unsigned)(px * ldy * 2);
+  int nsplit = 256 / groups;                                // one workgroup per CU (150 / 94 KB of LDS)
   if (nsplit < 1) nsplit = 1;
   if (nsplit > p.ntiles) nsplit = p.ntiles;
   p.nsplit = nsplit;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * TR_STAGE);
-  });
-  const double M = (double)d->N * d->Hin * TR_W;
-  TG_LAUNCH("conv_wgrad_tr", 2.0 * groups * M * 9.0 * 64 * 64, groups * (M * 2.0 * TR_PIX + 36.0 * 64 * 64), conv_wgrad_tr_kernel,
-            dim3((unsigned)(groups * nsplit)), dim3(256), 2 * TR_STAGE, st, p);
+  const double M = (double)px;
+  const double flops = 2.0 * groups * M * 9.0 * 64 * d->Cout, bytes = groups * (M * (TR_PIX + 2.0 * ldy) + 36.0 * 64 * d->Cout);
+  if (trunk) wgrad_tr_go<64>(p, flops, bytes, st);
+  else wgrad_tr_go<8>(p, flops, bytes, st);
   return 1;
 }

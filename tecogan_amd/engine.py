@@ -437,6 +437,8 @@ class TrainEngine:
         # [tc, T): late frames.  One cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at
         # 10 + 9 and 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the early chunk has the forward pass to hide in).
         tc = (min((T + 3) // 2, T - 1) if T > 1 else T) if self.use_vgg else T
+        if self.use_vgg and os.environ.get("TG_VGG_CUT"):                   # A/B: first late frame
+            tc = max(1, min(int(os.environ["TG_VGG_CUT"]), T - 1)) if T > 1 else T
         d_vgg = None
         if self.use_vgg:
             d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
@@ -525,6 +527,8 @@ class TrainEngine:
             with seg("wgrad", "S" if gw_side else "M", ["bwd_b"]):       # (bit 32: beside FNet's backward pass)
                 self.G.wgrad_sequence(0, T)
             self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
+            # (FNet's 14 weight gradients behind the generator's on the side stream, its input-gradient chain alone on the
+            #  main stream: measured no gain -- 12.69 vs 12.73 ms, profiles/r03j_ab.txt -- the pieces serialise on each other)
             with seg("fnet_bwd"):
                 self.Fn.backward(fsaved, d_flow)
             self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])

@@ -314,7 +314,7 @@ class FNet:
         return flow, ((saved, net, o1, flow) if keep else None)
 
     def backward(self, saved_all, d_flow, flags=0):
-        """Backward pass (input gradient chain + weight gradients accumulated into the flat gradient buffer)."""
+        """Backward pass: the input-gradient chain, and the weight gradients accumulated into the flat gradient buffer."""
         ps, p = self.ps, self.P
         saved, net_last, o1, flow = saved_all
         s = p + "output_stage/"

@@ -928,6 +928,11 @@ DMA_CASES = [
     (57, 16, 16, 512, 512, False, False, False, ACT_RELU),    # odd tile count: the last unit's second tile does not exist
     (57, 40, 27, 96, 128, False, True, False, ACT_LRELU),     # ragged edges + residual, pairs straddle image boundaries
     (20, 64, 64, 128, 128, True, False, True, ACT_NONE),      # input-gradient form with ReLU mask
+    # packed tiles (round 3): 4 whole 8 x 8 images / 16 whole 4 x 4 images per 16 x 16 tile, each with its own zero border
+    (76, 8, 8, 512, 512, False, False, False, ACT_RELU),      # VGG conv5_x at the full batch
+    (37, 8, 8, 128, 128, True, True, True, ACT_NONE),         # image count not a multiple of 4; input-gradient form, res + mask
+    (70, 4, 4, 256, 256, False, True, False, ACT_LRELU),      # FNet's innermost level; count not a multiple of 16
+    (65, 4, 4, 256, 256, True, False, True, ACT_NONE),
 ]
 
 
@@ -1040,3 +1045,30 @@ def test_wgrad_transpose_read_kernel_matches_autograd(case):
         O.conv2(xr, w, b, 1).backward(ys[g].float())
         close(got_w[g] - 0.5, w.grad, 3e-4, "transpose-read dW layer %d %s" % (g, case))
         close(got_b[g], b.grad, 3e-4, "transpose-read dbias layer %d %s" % (g, case))
+
+
+@pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") == "0", reason="TG_WGRAD_TR=0 switches the transpose-read kernel off")
+@pytest.mark.parametrize("case", [(2, 8, 64, 64), (3, 24, 96, 64), (5, 16, 128, 3), (2, 128, 128, 3), (1, 8, 32, 8)])
+def test_wgrad_transpose_read_kernel_wide_images_and_output_conv(case):
+    """Round 3: the transpose-read weight-gradient kernel on images of any width that is a multiple of 32 (tiles of 8 x 32
+    pixels, single-layer entry point) and its 64 -> (<= 8) instantiation for the generator's output conv (lib/frvsr.py:80):
+    gradient tensor channel-padded to 8, the padding channels hold GARBAGE here and must not reach dW."""
+    N, H, W, Co = case
+    ldy = 64 if Co == 64 else 8
+    x = rnd(N, H, W, 64, seed=3).bfloat16()
+    y = rnd(N, H, W, ldy, seed=4).bfloat16()
+    d = K.conv_desc(N, H, W, 64, H, W, Co, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16)
+    dw = torch.full((3, 3, 64, Co), 0.25, device=DEV)
+    db = torch.zeros(Co, device=DEV)
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_wgrad(d, x.to(DEV), y.to(DEV), dw, db, ldx=64, ldy=ldy)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"] == ("conv_wgrad_tr" if Co == 64 else "conv_wgrad_tr_out"), ents
+    xr = x.float().requires_grad_()
+    w = torch.zeros(3, 3, 64, Co, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    O.conv2(xr, w, b, 1).backward(y.float()[..., :Co])
+    close(dw - 0.25, w.grad, 3e-4, "transpose-read dW %s" % (case,))
+    close(db, b.grad, 3e-4, "transpose-read dbias %s" % (case,))

@@ -18,3 +18,14 @@ for G, N in ((32, 76), (20, 40)):
     t = graph_timeit(fn, chain=5)
     fl = 2.0 * G * N * 32 * 32 * 64 * 64 * 9
     print("wgrad grouped G=%d N=%d (TG_WGRAD_TR=%s): %.1f us  %.1f TFLOP/s" % (G, N, os.environ.get("TG_WGRAD_TR"), t, fl / t / 1e6))
+
+# the generator's output conv (64 -> 3, gradient tensor padded to 8 channels) over T*B = 76 / 40 HR frames
+for N in (76, 40):
+    d = K.conv_desc(N, 128, 128, 64, 128, 128, 3, 3, 3, 1, 1, 1, 0, 0, 0)
+    x = torch.randn(N, 128, 128, 64, device="cuda").bfloat16()
+    y = torch.randn(N, 128, 128, 8, device="cuda").bfloat16()
+    dw = torch.zeros(3, 3, 64, 3, device="cuda")
+    db = torch.zeros(3, device="cuda")
+    fn = lambda: K.conv_wgrad(d, x, y, dw, db, ldx=64, ldy=8)
+    t = graph_timeit(fn, chain=5)
+    print("wgrad out-conv N=%d (TG_WGRAD_TR=%s): %.1f us  %.2f TB/s" % (N, os.environ.get("TG_WGRAD_TR"), t, N * 16384 * 144 / t / 1e6))

@@ -85,6 +85,9 @@ def main():
         ("conv3x3 vgg  [76,16,16,512->512]", conv_case(76, 16, 16, 512, 512, dtype=dt)),
         ("conv3x3 vgg5 [76,8,8,512->512]", conv_case(76, 8, 8, 512, 512, dtype=dt)),
         ("conv3x3 fnet [72,8,8,128->128]", conv_case(72, 8, 8, 128, 128, dtype=dt)),
+        ("conv3x3 vgg5 [32,8,8,512->512]", conv_case(32, 8, 8, 512, 512, dtype=dt)),
+        ("conv3x3 vgg5 [44,8,8,512->512]", conv_case(44, 8, 8, 512, 512, dtype=dt)),
+        ("conv3x3 fnet [72,4,4,256->256]", conv_case(72, 4, 4, 256, 256, dtype=dt)),
         ("conv4x4s2 D  [24,128,128,64->64]", conv_case(24, 128, 128, 64, 64, 4, 2, 0, dt)),
         ("conv3x3 inf  [1,270,480,64->64]", conv_case(1, 270, 480, 64, 64, dtype=dt)),
         ("conv3x3 inf  [1,270,480,56->64]", conv_case(1, 270, 480, 56, 64, dtype=dt)),
