@@ -22,8 +22,13 @@
 //   * bicubic in the same epilogue: the 4 x 4 LR neighbourhood of a pixel is gathered by the four 16-lane groups of the
 //     wave (group g reads LR row g, four 8-byte loads), weighted, and summed across the groups with two xor-shuffles.
 //
-// Round-2 status: written after the round's GPU budget was spent; index logic checked on the CPU only.  Opt-in
-// (TG_HR_TAIL=1 in tecogan_amd/nets.py); its GPU test is gated behind TG_TEST_UNVALIDATED=1.
+// Round 3: validated on MI355X (tests/test_kernels_gpu.py::test_hr_tail_fused_matches_the_three_kernel_path, every frame of
+// tests/test_infer_gpu.py) and default-on (TG_HR_TAIL=0 is the A/B switch): 1080p frame 1.103 -> 1.068 ms same box
+// (profiles/r03a_ab.txt).  rocprofv3: 224 us per 1080p frame (profiles/r03l_infer1080p_bf16_kernel_stats.txt), i.e. ~6900
+// cycles per tile against ~4600 cycles of MFMA issue (270 v_mfma_16x16x32 per wave and tile at one wave per SIMD): it is
+// MFMA-ISSUE bound, and 126 of the 270 are the output conv with 3 of 16 operand rows in use.  Hoisting the bicubic skip's LR
+// loads ahead of the transposed-conv phase changed nothing (224.2 us).  Open: the output conv as ONE [pixel] x [tap, channel]
+// product (27 -> 32 columns, 4 MFMAs per 16 pixels instead of 18) followed by a shifted 9-tap sum of the partial products.
 #include "common.h"
 #include <mutex>
 #include <stdlib.h>
