@@ -4,7 +4,8 @@
   1  inference of ./LR/calendar (or --lr-dir) with a trained model        (reference runGan.py:67-90)
   3  TecoGAN training: G + spatio-temporal D + VGG + ping-pong            (reference runGan.py:107-244)
   4  FRVSR training: l2 content + l2 warp                                 (reference runGan.py:247-296)
-  0 / 2 (dataset download, offline metrics) are outside the MI355X hot path and only print a notice.
+  2  metrics of ./results/<scene> against ./HR/<scene> -> ./results/metric_log/   (reference runGan.py:91-105; metrics.py)
+  0  (dataset / model download) is outside the MI355X hot path and only prints a notice.
 
 Each case spawns `main.py` as a child process with the reference's flag list (same spellings and values).
 Extras of this implementation go after `--`:   python runGan.py 4 -- --synthetic --max_iter 200
@@ -65,10 +66,14 @@ def main():
         raise SystemExit(__doc__)
     case = int(argv[0])
     py = [sys.executable]
-    if case in (0, 2):
-        print("runGan.py %d (%s) is outside the MI355X hot path of this repository." %
-              (case, "dataset / model download" if case == 0 else "offline metrics"))
+    if case == 0:
+        print("runGan.py 0 (dataset / model download) is outside the MI355X hot path of this repository.")
         return 0
+    if case == 2:           # reference runGan.py:91-105
+        testpre, dirstr, tarstr = ["calendar"], "./results/", "./HR/"
+        cmd = py + [os.path.join(HERE, "metrics.py"), "--output", dirstr + "metric_log/",
+                    "--results", ",".join(dirstr + s_ for s_ in testpre), "--targets", ",".join(tarstr + s_ for s_ in testpre)] + extra
+        return subprocess.call(cmd)
     if case == 1:
         out = "./results/"
         os.makedirs(out, exist_ok=True)
