@@ -39,7 +39,7 @@ struct Conv3P {
   float nslope;       // none: 1, ReLU: 0, LeakyReLU: alpha  -> act(v) = max(v, v*nslope)
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope (ReLU 0, LeakyReLU alpha, none 1)
   int tiles_y, tiles_x, ntiles;
-  int direct_epi;     // A/B switch (TG_C3_DIRECT_EPI): per-lane stores instead of the LDS-staged rows
+  int direct_epi;     // per-lane stores instead of the LDS-staged rows
   int prio;           // A/B switch (TG_C3_PRIO): s_setprio for the small-tile (latency-bound chain) instantiations
   unsigned in_bytes, w_bytes;   // extents of `in` / `w` for the bounds-checked buffer loads (< 2^31)
 };
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_tile_kernel(Conv3P p) {
         // Phase 1: bias + activation in fp32 registers, bf16 tile into the (now idle) halo region of LDS.
         // Phase 2: every thread moves 16-byte rows: residual / mask operands arrive as vector loads and the
         // result leaves as one dwordx4 store per 8 channels (the per-lane 2-byte stores of the direct epilogue
-        // cost 10 of 27 us at [1,270,480,64->64]: store-issue bound, tools ablation TG_C3_ABL).
+        // cost 10 of 27 us at [1,270,480,64->64]: store-issue bound).
         __syncthreads();                   // all waves are done reading the halo tile
         u16* stage = reinterpret_cast<u16*>(As);
         constexpr int SP = 72;             // u16 per staged pixel row: 64 channels + 8 pad (144 B)
@@ -444,45 +444,12 @@ template <typename TIn, typename TOut>
 static void launch3_typed(const Conv3P& p, hipStream_t st, bool coexist) {
   const int64_t pix = (int64_t)p.N * p.H * p.W;
   const int nt64 = (p.Cout + 63) / 64;
-  static const char* force = getenv("TG_C3_FORCE");       // experiment switch: "TH,BN" e.g. "4,32"
-  if (force && p.Cout > 32) {
-    int th = 0, bn = 0;
-    if (sscanf(force, "%d,%d", &th, &bn) == 2) {
-      if (th == 2 && bn == 64) return launch3<TIn, TOut, 2, 64>(p, st);
-      if (th == 4 && bn == 64) return launch3<TIn, TOut, 4, 64>(p, st);
-      if (th == 8 && bn == 64) return launch3<TIn, TOut, 8, 64>(p, st);
-      if (th == 16 && bn == 64) {
-        static const int abl = getenv("TG_C3_ABL") ? atoi(getenv("TG_C3_ABL")) : 0;
-        if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
-          switch (abl) {
-            case 1: return launch3<TIn, TOut, 16, 64, 1>(p, st);
-            case 2: return launch3<TIn, TOut, 16, 64, 2>(p, st);
-            case 3: return launch3<TIn, TOut, 16, 64, 3>(p, st);
-            case 4: return launch3<TIn, TOut, 16, 64, 4>(p, st);
-            case 12: return launch3<TIn, TOut, 16, 64, 12>(p, st);
-            case 14: return launch3<TIn, TOut, 16, 64, 14>(p, st);
-            case 15: return launch3<TIn, TOut, 16, 64, 15>(p, st);
-            default: break;
-          }
-        }
-        return launch3<TIn, TOut, 16, 64>(p, st);
-      }
-      if (th == 4 && bn == 32) return launch3<TIn, TOut, 4, 32>(p, st);
-      if (th == 2 && bn == 32) return launch3<TIn, TOut, 2, 32>(p, st);
-      if (th == 4 && bn == 16) return launch3<TIn, TOut, 4, 16>(p, st);
-      if (th == 8 && bn == 16) return launch3<TIn, TOut, 8, 16>(p, st);
-      if (th == 8 && bn == 32) return launch3<TIn, TOut, 8, 32>(p, st);
-      if (th == 16 && bn == 32) return launch3<TIn, TOut, 16, 32>(p, st);
-    }
-  }
   if constexpr (sizeof(TIn) == 2 && sizeof(TOut) == 2) {
-    // narrow images: several per tile row (A/B switch TG_NO_C3_PACK=1)
-    static const bool no_pack = getenv("TG_NO_C3_PACK") != nullptr;
+    // narrow images: several per tile row
     // ... once the layer is big enough to fill the chip anyway (pixels x channel tiles >= 16k: VGG conv5, the 72-pair
     // FNet of the TecoGAN step); below that the packed tiling only cuts the workgroup count of a latency-bound launch
     // (FRVSR step 3.96 -> 4.06 ms with packing everywhere)
-    if (!no_pack && !p.direct_epi && p.W <= 8 && p.N >= 2 && (p.Cout & 7) == 0 && p.Cout >= 64 && !(force && p.Cout > 32) &&
-        pix * nt64 >= 16384) {
+    if (!p.direct_epi && p.W <= 8 && p.N >= 2 && (p.Cout & 7) == 0 && p.Cout >= 64 && pix * nt64 >= 16384) {
       if (p.W <= 4 && p.N >= 4) return launch3<TIn, TOut, 4, 64, 0, 4>(p, st);
       if (p.H <= 4) return launch3<TIn, TOut, 4, 64, 0, 2>(p, st);
       return launch3<TIn, TOut, 8, 64, 0, 2>(p, st);
@@ -498,10 +465,9 @@ static void launch3_typed(const Conv3P& p, hipStream_t st, bool coexist) {
     else launch3<TIn, TOut, 4, 32>(p, st);
   } else if (p.Cin * (int)sizeof(TIn) > 128) {
     // multi-chunk (Cin > one 128-B chunk): the weight panel is re-staged per (tile, chunk) -> largest pixel tile
-    // TG_C3_MAXTH=8 (A/B switch): <8,64> instead of <16,64> -- 109 KB LDS / ~300 registers instead of 130 KB / ~400, which
-    // leaves room on the CU for a co-resident workgroup of the latency-bound <4,16> chain kernel (36 KB / 120 registers)
-    static const int maxth_env = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
-    const int maxth = coexist ? 8 : maxth_env;             // TG_CONV_COEXIST: leave room for a chain workgroup
+    // TG_CONV_COEXIST: <8,64> instead of <16,64> -- 109 KB LDS / ~300 registers instead of 130 KB / ~400, which leaves room
+    // on the CU for a co-resident workgroup of the latency-bound <4,16> chain kernel (36 KB / 120 registers)
+    const int maxth = coexist ? 8 : 16;
     if (maxth >= 16 && pix * nt64 >= (int64_t)16 * 16 * 256) launch3<TIn, TOut, 16, 64>(p, st);
     else if (pix * nt64 >= (int64_t)8 * 16 * 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (pix * nt64 >= (int64_t)4 * 16 * 256) launch3<TIn, TOut, 4, 64>(p, st);
@@ -509,12 +475,11 @@ static void launch3_typed(const Conv3P& p, hipStream_t st, bool coexist) {
   } else {
     // single chunk, weights stationary: the largest tile that still gives every CU a workgroup.  Narrow
     // channel tiles (BN 32/16) shrink the weight panel each workgroup stages and were measured faster in situ
-    // for the small recurrent-chain shapes (FRVSR step 6.10 -> 5.61 ms with <4,16>, same-session A/B via TG_C3_FORCE).
+    // for the small recurrent-chain shapes (FRVSR step 6.10 -> 5.61 ms with <4,16>, same-session A/B in round 1).
     auto blocks = [&](int th, int bn) {
       return (int64_t)p.N * ((p.H + th - 1) / th) * ((p.W + 15) / 16) * ((p.Cout + bn - 1) / bn);
     };
-    static const int maxth_env = getenv("TG_C3_MAXTH") ? atoi(getenv("TG_C3_MAXTH")) : 16;
-    const int maxth = coexist ? 8 : maxth_env;
+    const int maxth = coexist ? 8 : 16;
     if (maxth >= 16 && blocks(16, 64) >= 256) launch3<TIn, TOut, 16, 64>(p, st);
     else if (maxth < 16 && blocks(8, 64) >= 256) launch3<TIn, TOut, 8, 64>(p, st);
     else if (blocks(16, 32) >= 256) launch3<TIn, TOut, 16, 32>(p, st);
@@ -650,7 +615,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(C8P p) {
 
 static int conv3x3_c8_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                           const void* aux, void* out, hipStream_t st) {
-  static const bool enabled = getenv("TG_NO_C8") == nullptr;           // A/B switch
+  const bool enabled = true;
   if (!enabled || d->Cin != 8 || d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
   if (d->act >= TG_ACT_TANH || (d->Cout != 32 && d->Cout % 64 != 0)) return 0;
   if ((((uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15)) return 0;
@@ -693,7 +658,7 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout;
   p.flip = d->mode == 1;
   p.act = d->act; p.act_alpha = d->act_alpha;
-  static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
+  const int direct = 0;
   p.direct_epi = direct;
   // default ON: with throughput kernels of the side stream on the same CU, the chain's waves at s_setprio 3 hide 75 % instead
   // of 48 % of a co-running VGG layer (tools/mb_forktax.py D: 5.14 vs 6.06 ms) and the TecoGAN step gains 2 %

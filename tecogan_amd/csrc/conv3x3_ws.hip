@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_ws_kernel(ConvWsP p) {
 // Returns 1 if handled (bf16, Cin <= 64, Cout % 64 == 0, k3 s2 pad 0 transposed, >= 256 input tiles), else 0.
 int tg_deconv3x3s2_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                           const void* aux, void* out, hipStream_t st) {
-  static const bool enabled = getenv("TG_NO_DECONV_WS") == nullptr;         // A/B switch
+  const bool enabled = true;
   if (!enabled || d->mode != 1 || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad_t != 0 || d->pad_l != 0) return 0;
   if (d->Hout != 2 * d->Hin || d->Wout != 2 * d->Win || res || aux) return 0;
   if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16 || d->act >= TG_ACT_TANH) return 0;
@@ -526,8 +526,8 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   // TG_CONV_COEXIST: ONE workgroup per CU (32 KB of unused LDS push the request past half the CU) -- two of them would
   // take 480 of the SIMD's 512 registers and lock the latency-bound chain kernel out of the CU
   // two workgroups per CU pay the weight prologue twice per CU: worth it from ~4 tiles per workgroup on
-  // (measured at 1020 tiles: 16.4 us with one, 17.8 us with two; at 9728 tiles: 97 vs 95 us); TG_C3WS_PERCU forces it
-  static const int per_cu_env = getenv("TG_C3WS_PERCU") ? atoi(getenv("TG_C3WS_PERCU")) : 0;      // A/B switch
+  // (measured at 1020 tiles: 16.4 us with one, 17.8 us with two; at 9728 tiles: 97 vs 95 us)
+  const int per_cu_env = 0;
   const int per_cu = coexist ? 1 : (per_cu_env ? (per_cu_env < 2 ? 1 : 2) : (p.ntiles >= 2048 ? 2 : 1));
   static const bool wlds = getenv("TG_C3WS_WLDS") == nullptr || atoi(getenv("TG_C3WS_WLDS")) != 0;   // A/B switch (=0: off)
   // ... from two tiles per workgroup on (the 1080p inference convs: 4); with a single tile per workgroup (FNet's 64-channel
@@ -553,7 +553,7 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
 int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                       const void* aux, void* out, hipStream_t st) {
   static const bool enabled = getenv("TG_NO_C3WS") == nullptr;            // A/B switch
-  static const int min_tiles = getenv("TG_C3WS_MIN_TILES") ? atoi(getenv("TG_C3WS_MIN_TILES")) : 256;
+  const int min_tiles = 256;
   if (!enabled) return 0;
   if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
   if (d->Cin % 8 != 0 || d->Cin > 64 || d->Cin < 16 || d->Cout % 64 != 0) return 0;

@@ -40,7 +40,7 @@ struct ConvP {
   float mask_alpha;
   int vec;  // Cin % (16B worth) == 0 -> 16-byte loads
   float nslope, mslope;  // act(v) = max(v, v*nslope); mask = aux > 0 ? 1 : mslope
-  int direct_epi;        // A/B switch TG_C3_DIRECT_EPI
+  int direct_epi;        // always 0 (the LDS-staged rows won; kept for the fp32 path)
   unsigned in_bytes, w_bytes;   // != 0: both operands < 2^31 bytes -> bounds-checked buffer loads (see load_vec)
   int sinv;                     // ceil(2^16 / stride)
 };
@@ -384,7 +384,7 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
                    (int64_t)d->N * d->Hin * d->Win < (1ll << 31),
                "tensor too large for 32-bit pixel indexing");
   hipStream_t st0 = static_cast<hipStream_t>(stream);
-  static const bool use_tile3 = getenv("TG_NO_CONV3X3") == nullptr;      // A/B switch for profiling
+  const bool use_tile3 = true;
   if (use_tile3 && tg_conv3x3_try(d, in, weight, bias, res, aux, out, st0)) TG_CHECK_LAUNCH();
   if (tg_deconv3x3s2_ws_try(d, in, weight, bias, res, aux, out, st0)) TG_CHECK_LAUNCH();
   ConvP p;
@@ -393,7 +393,7 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l; p.mode = d->mode;
   p.act = d->act; p.act_alpha = d->act_alpha; p.mask_act = d->mask_act; p.mask_alpha = d->mask_alpha;
-  static const int direct = getenv("TG_C3_DIRECT_EPI") ? 1 : 0;
+  const int direct = 0;
   p.direct_epi = direct;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
@@ -402,7 +402,7 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   {
     const int64_t esz = d->in_dtype == TG_F32 ? 4 : 2;
     const int64_t ib = (int64_t)d->N * d->Hin * d->Win * d->Cin * esz, wb = (int64_t)d->KH * d->KW * d->Cout * d->Cin * esz;
-    static const bool no_buf = getenv("TG_NO_BUFFER_LOADS") != nullptr;                // A/B switch
+    const bool no_buf = false;
     const bool fits = ib < ((int64_t)1 << 31) && wb < ((int64_t)1 << 31) && !no_buf;
     p.sinv = (65536 + d->stride - 1) / d->stride;
     p.in_bytes = fits ? (unsigned)ib : 0u;

@@ -306,7 +306,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // (the L2 atomic units retire ~0.5 T adds/s chip-wide).  steps = M/64/ksplit, atomics = outputs * ksplit:
 // the optimum is ksplit = sqrt(a * (M/64) / (b * outputs)), capped so that the grid stays within ~1024 workgroups.
 static int tg_wgrad_ksplit(int M, int64_t outputs, int base_blocks, int quantum) {
-  static const int target_env = getenv("TG_WGRAD_BLOCKS") ? atoi(getenv("TG_WGRAD_BLOCKS")) : 0;
+  const int target_env = 0;
   int ksplit;
   if (target_env) {
     ksplit = (target_env + base_blocks - 1) / base_blocks;
@@ -764,7 +764,7 @@ int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, 
                        float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip
 
 static bool tg_wgrad_row3_applies(const tg_conv_desc* d, int ldx, int ldy) {
-  static const bool enabled = getenv("TG_NO_WGRAD_ROW3") == nullptr;                               // A/B switch
+  const bool enabled = true;
   if (!enabled || d->KW != 3 || d->stride != 1 || d->pad_l != 1 || d->Win != d->Wout || d->Hin != d->Hout) return false;
   if ((d->Wout & 1) || d->KH > 11 || d->pad_t < 0 || d->pad_t >= d->KH) return false;
   const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
@@ -816,7 +816,7 @@ extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const vo
   for (int g = 0; g < groups; ++g) TG_CHECK_ARG(x[g] && y[g] && dw[g], "null group pointer");
   const int lx = ldx > 0 ? ldx : d->Cin, ly = ldy > 0 ? ldy : d->Cout;
   bool fast = d->mode == 0 && x_dtype == TG_BF16 && y_dtype == TG_BF16 && lx % 8 == 0 && ly % 8 == 0 && lx >= d->Cin &&
-              ly >= d->Cout && getenv("TG_NO_WGRAD_BF16") == nullptr;
+              ly >= d->Cout;
   for (int g = 0; g < groups && fast; ++g) fast = ((((uintptr_t)x[g] | (uintptr_t)y[g])) & 15) == 0;
   if (fast && tg_wgrad_tr_launch(d, groups, x, lx, y, ly, dw, dbias, static_cast<hipStream_t>(stream))) TG_CHECK_LAUNCH();
   if (fast && tg_wgrad_row3_launch(d, groups, x, lx, y, ly, dw, dbias, static_cast<hipStream_t>(stream)))
@@ -831,8 +831,7 @@ extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const vo
 // returns 1 if launched
 int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx, const void* y, int y_dtype, int ldy,
                       float* dw, float* dbias, hipStream_t st) {
-  static const bool enabled = getenv("TG_NO_WGRAD_BF16") == nullptr;
-  if (!enabled || x_dtype != TG_BF16 || y_dtype != TG_BF16) return 0;
+  if (x_dtype != TG_BF16 || y_dtype != TG_BF16) return 0;
   if (ldx % 8 || ldy % 8 || (((uintptr_t)x | (uintptr_t)y) & 15)) return 0;
   if (d->mode == 0 && ldx >= d->Cin && ldy >= d->Cout && tg_wgrad_tr_launch(d, 1, &x, ldx, &y, ldy, &dw, dbias ? &dbias : nullptr, st))
     return 1;                           // 64-channel 3x3 layers on images whose width is a multiple of 32 (conv_wgrad_tr.hip)
@@ -852,7 +851,7 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
   p.ytiles = (p.Cy + 63) / 64;
   p.xtiles = xtiles;
   const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
-  static const int pf_env = getenv("TG_WGRAD_PF") ? atoi(getenv("TG_WGRAD_PF")) : 2;               // A/B switch
+  const int pf_env = 2;
   const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);        // 2: best or within noise at every swept shape
   const int quantum = 64 * pf;
   int ksplit = tg_wgrad_ksplit(p.M, (int64_t)base_blocks * 4096, base_blocks, quantum);

@@ -811,7 +811,7 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
   dim3 grid(grid_1d((int64_t)B * h * w * 16, 256));
   const double by = (double)B * h * w * (16.0 * 12.0 * (1 + (out != nullptr) + (state != nullptr)) +
                                          3.0 * (in_dtype == TG_F32 ? 4.0 : 2.0));   // conv_out in, frame / state out, LR in
-  static const bool no_quad = getenv("TG_NO_BICUBIC_QUAD") != nullptr;                 // A/B switch
+  const bool no_quad = false;
   if (!no_quad && ((((uintptr_t)conv_out | (uintptr_t)out | (uintptr_t)state)) & 15) == 0 &&
       (int64_t)B * h * w * 4 < ((int64_t)1 << 31)) {
     dim3 gq(grid_1d((int64_t)B * h * w * 4, 256, 1 << 20));
@@ -823,7 +823,7 @@ extern "C" int tg_bicubic_add_preprocess(const float* conv_out, const void* gen_
     else TG_CHECK_ARG(false, "bad dtype");
     TG_CHECK_LAUNCH();
   }
-  TG_CHECK_ARG(out != nullptr && state == nullptr, "the per-pixel fallback (TG_NO_BICUBIC_QUAD) writes `out` only");
+  TG_CHECK_ARG(out != nullptr && state == nullptr, "the per-pixel fallback writes `out` only");
   if (in_dtype == TG_F32) TG_LAUNCH("bicubic_add<f32>", 0, by, (bicubic_add_kernel<float>), grid, dim3(256), 0, ST(stream), conv_out, (const float*)gen_in, Cpad, out, B, h, w);
   else if (in_dtype == TG_BF16) TG_LAUNCH("bicubic_add<bf16>", 0, by, (bicubic_add_kernel<u16>), grid, dim3(256), 0, ST(stream), conv_out, (const u16*)gen_in, Cpad, out, B, h, w);
   else TG_CHECK_ARG(false, "bad dtype");

@@ -251,7 +251,7 @@ extern "C" int tg_warp_s2d_forward(const float* pre, const float* flow_lr, const
   const double by = px * ((pre ? 16.0 * 12.0 : 0.0) + (pre ? (double)hf * wf / ((double)h * w) * 8.0 : 0.0) + 12.0 +
                           Cpad * (out_dtype == TG_F32 ? 4.0 : 2.0));
   const int esz = out_dtype == TG_F32 ? 4 : 2;
-  static const bool no_vec = getenv("TG_NO_WARP_VEC") != nullptr;           // A/B switch
+  const bool no_vec = false;
   const bool vec = !no_vec && (Cpad * esz) % 16 == 0 && Cpad * esz <= 256 && ((uintptr_t)out & 15) == 0;
   const unsigned lds = 16u * Cpad * esz;
   if (out_dtype == TG_F32 && vec)

@@ -173,7 +173,7 @@ class TrainEngine:
         # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
         # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
         # and each such node would wait for a CU to drain (~50 us, 27 + 19 nodes per step)
-        if uses_side and os.environ.get("TG_CHAIN_COEXIST", "1") != "0":
+        if uses_side:
             self.G.chain_flags = K.CONV_COEXIST
 
     # ------------------------------------------------------------------------------------------
@@ -439,8 +439,6 @@ class TrainEngine:
         # [tc, T): late frames.  One cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at
         # 10 + 9 and 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the early chunk has the forward pass to hide in).
         tc = (min((T + 3) // 2, T - 1) if T > 1 else T) if self.use_vgg else T
-        if self.use_vgg and os.environ.get("TG_VGG_CUT"):                   # A/B: first late frame
-            tc = max(1, min(int(os.environ["TG_VGG_CUT"]), T - 1)) if T > 1 else T
         d_vgg = None
         if self.use_vgg:
             d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
