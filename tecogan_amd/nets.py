@@ -142,6 +142,9 @@ class Generator:
         assert not keep, "training uses begin_sequence/forward_t"
         ps, p = self.ps, self.P
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU)
+        # (one launch per residual block -- r kept in LDS, both convs on MFMA -- was built and measured in round 3: parity
+        #  green, 35.2 us per block against 35.3 us for these two launches: bound by 2-way-conflicted LDS fragment reads under
+        #  the gfx950 ds_read_b128 lane grouping; numbers and cycle stamps in profiles/r03p_resblock_ws.txt, kernel deleted)
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU)

@@ -1072,3 +1072,4 @@ def test_wgrad_transpose_read_kernel_wide_images_and_output_conv(case):
     O.conv2(xr, w, b, 1).backward(y.float()[..., :Co])
     close(dw - 0.25, w.grad, 3e-4, "transpose-read dW %s" % (case,))
     close(db, b.grad, 3e-4, "transpose-read dbias %s" % (case,))
+
