@@ -9,20 +9,25 @@ def tg_name(k):
     if m:
         base = "conv3x3_tile<%s,%s,%s,%s" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4))
         return base + (",pack%s>" % m.group(5) if m.group(5) and m.group(5) != "1" else ">")
-    m = re.search(r"conv3x3_ws_kernel<(true|false), (true|false)>", k)
+    m = re.search(r"conv3x3_ws_kernel<(true|false), (true|false)(?:, (?:true|false))?>", k)
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
         return "conv3x3_ws<%s>" % ",".join(tags)
     m = re.search(r"conv3x3_dma_kernel<(true|false), (true|false)(?:, (\d+))?>", k)
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
-        return "conv3x3_dma%s<%s>" % ("2" if m.group(3) == "2" else "", ",".join(tags))
+        return "conv3x3_dma%s<%s>" % ({"2": "_pack2", "4": "_pack4"}.get(m.group(3), ""), ",".join(tags))
     m = re.search(r"conv3x3_c8_kernel<(\d+)>", k)
     if m:
         return "conv3x3_c8<%s>" % m.group(1)
     m = re.search(r"conv_igemm_kernel<([a-z ]+), ([a-z ]+), (\d+), (\d+), (\d+), (\d+), (true|false)>", k)
     if m:
         return "conv_igemm<%s,%s,%s,%s,%s,%s>" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4), m.group(5), m.group(6))
+    if "hr_tail_kernel" in k:
+        return "hr_tail"
+    m = re.search(r"conv_wgrad_tr_kernel<(\d+)>", k)
+    if m:
+        return "conv_wgrad_tr" if m.group(1) == "64" else "conv_wgrad_tr_out"
     if "deconv3x3s2_ws_kernel" in k:
         return "deconv3x3s2_ws"
     if "conv_wgrad_row3_bf16_kernel" in k:
