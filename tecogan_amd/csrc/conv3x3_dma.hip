@@ -81,8 +81,10 @@ extern "C" int tg_debug_dma_trace(unsigned long long* out) {
 #define DM_STAMP(i) do { } while (0)
 #endif
 
-// (A two-tiles-per-stage variant -- one weight panel for two halos, 39 instead of 57 KB per 256 output pixels -- lost to tile
-// quantisation, 1044 vs 1143 TFLOP/s at [76,32,32,256], profiles/r02t_microbench.txt, and was removed in round 3.)
+// (A two-tiles-per-stage variant -- one weight panel for two halos, 39 instead of 57 KB per 256 output pixels -- lost twice:
+// alone to tile quantisation (1044 vs 1143 TFLOP/s at [76,32,32,256], profiles/r02t_microbench.txt), and in round 3 also as
+// "whole rounds of pairs + a second launch of single tiles for the remainder" (78.8 -> 81.8 us, profiles/r03q_microbench.txt):
+// a pair stage costs ~1.65 x a single one, not the 1.35 x its byte count suggests -- the stage is not purely stream-bound.)
 template <bool HAS_RES, bool HAS_AUX, int PK>
 __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   using G = DmGeo<PK>;
