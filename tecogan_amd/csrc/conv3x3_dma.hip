@@ -421,7 +421,11 @@ static void launch_dma_pk(const ConvDmaP& p, bool res, bool aux, hipStream_t st)
 int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                        const void* aux, void* out, hipStream_t st) {
   static const bool enabled = getenv("TG_NO_C3DMA") == nullptr;            // A/B switch
-  static const int min_wg = getenv("TG_C3DMA_MIN_WG") ? atoi(getenv("TG_C3DMA_MIN_WG")) : 96;
+  // selection threshold in workgroup-units (tiles x channel blocks).  Round 2 set 96 ("below a third of the chip the 8 x 64
+  // tiles fill it better"); re-measured in round 3, alternating runs on one box (profiles/r03s_ab.txt): the 1080p inference frame
+  // 1.070 -> 1.042 ms with 24 (FNet's 33 x 60 / 66 x 120 levels: the tile kernel's K loop is the longer serial chain there),
+  // the training steps unchanged (TecoGAN 12.09-12.15 ms with either)
+  static const int min_wg = getenv("TG_C3DMA_MIN_WG") ? atoi(getenv("TG_C3DMA_MIN_WG")) : 24;
   if (!enabled) return 0;
   if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
   if (d->Cin % 32 != 0 || d->Cin < 64 || d->Cout % 64 != 0) return 0;
@@ -443,7 +447,6 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   p.tiles_y = (p.H + DM_TH - 1) / DM_TH;
   p.tiles_x = (p.W + 15) / 16;
   const int64_t ntiles = pk == 1 ? (int64_t)p.N * p.tiles_y * p.tiles_x : ((int64_t)p.N + pk * pk - 1) / (pk * pk);
-  // below ~a third of the chip's CUs the 8 x 64 tiles of conv3x3.hip (twice the workgroups) fill it better
   if (ntiles * (p.Cout / 64) < (pk == 1 ? min_wg : min_wg_pack) || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;

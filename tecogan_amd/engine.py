@@ -328,8 +328,10 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
-        if self.gan and self._mode == "eager":
-            self.D.set_scratch(None)            # the BN scratch pool is valid inside a step only (sticky cursor)
+        if self.gan and self._mode in ("eager", "capture", "flat"):
+            # the BN scratch pool is valid inside a step's program only (captured graphs hold the pool's addresses, not this
+            # attribute): D.forward / D.backward on eng.D outside a step get self-zeroed tensors again (sticky cursor)
+            self.D.set_scratch(None)
         if self._skip_update:
             return
         after = ["down", "wgrad"]
