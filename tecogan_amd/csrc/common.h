@@ -12,6 +12,16 @@ typedef unsigned short u16;
 
 void tg_set_error(const char* fmt, ...);
 
+// TG_DETERMINISTIC=1 (read once): ordered-reduction PARITY mode.  Every kernel that accumulates with floating-point atomics is
+// launched so that the order of its additions is fixed: reductions (losses, batch-norm sums, column sums) as ONE workgroup (their
+// in-block reduction order is fixed by the code, a single atomic per output remains), weight gradients without split-K (one
+// workgroup owns an output block over ALL pixels: each dW element receives exactly one add per launch), scatter kernels (the
+// three warp / D-input backward passes) as ONE wavefront.  Slow (the fp32 parity step: seconds instead of 60 ms) and only meant
+// for the parity tests: a regression is then distinguishable from summation-order noise (tools/c3_repeat.py).
+bool tg_det();
+#define TG_DET_GRID(g) (tg_det() ? dim3(1) : dim3(g))
+#define TG_DET_WAVE(b) (tg_det() ? dim3(64) : dim3(b))
+
 #define TG_CHECK_ARG(cond, msg)                                   \
   do {                                                            \
     if (!(cond)) {                                                \

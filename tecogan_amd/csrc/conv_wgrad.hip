@@ -181,7 +181,7 @@ extern "C" int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, 
   int ksplit = (2048 + base_blocks - 1) / base_blocks;
   const int max_split = (p.M + 63) / 64;
   if (ksplit > max_split) ksplit = max_split;
-  if (ksplit < 1) ksplit = 1;
+  if (ksplit < 1 || tg_det()) ksplit = 1;                  // parity mode: no split-K (one add per dW element and launch)
   p.chunk = (((p.M + ksplit - 1) / ksplit) + 31) / 32 * 32;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
   dim3 grid(d->KH * d->KW, xtiles * p.ytiles, ksplit);
@@ -273,7 +273,7 @@ extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* o
     const int RP = 256 / (C / 8);
     int gx = (int)cdiv64(rows, (int64_t)RP * 8);
     if (gx > 256) gx = 256;              // every workgroup ends with C atomics on the same C addresses
-    hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3(gx), dim3(256), 0, static_cast<hipStream_t>(stream), (const u16*)x, rows,
+    hipLaunchKernelGGL(colsum_bf16x8_kernel, TG_DET_GRID(gx), dim3(256), 0, static_cast<hipStream_t>(stream), (const u16*)x, rows,
                        C, out);
     TG_CHECK_LAUNCH();
   }
@@ -282,7 +282,7 @@ extern "C" int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* o
   int gx = (int)cdiv64(rows, (int64_t)lpc * 64);
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
-  dim3 grid(gx, (C + Cb - 1) / Cb);
+  dim3 grid(tg_det() ? 1 : gx, (C + Cb - 1) / Cb);          // (parity mode: one workgroup per channel block)
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == TG_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, C, out);
   else hipLaunchKernelGGL((colsum_kernel<u16>), grid, dim3(256), 0, st, (const u16*)x, rows, C, out);
@@ -318,7 +318,7 @@ static int tg_wgrad_ksplit(int M, int64_t outputs, int base_blocks, int quantum)
   }
   const int max_split = (M + 2 * quantum - 1) / (2 * quantum);
   if (ksplit > max_split) ksplit = max_split;
-  if (ksplit < 1) ksplit = 1;
+  if (ksplit < 1 || tg_det()) ksplit = 1;                  // parity mode: no split-K
   return ksplit;
 }
 

@@ -245,7 +245,7 @@ static void wgrad_tr_go(const WgradTrP& p, double flops, double bytes, hipStream
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
                        float* const* dw, float* const* dbias, hipStream_t st) {
   static const bool enabled = getenv("TG_WGRAD_TR") == nullptr || atoi(getenv("TG_WGRAD_TR")) != 0;
-  if (!enabled || groups < 1 || groups > TG_WTR_MAX_GROUPS) return 0;
+  if (!enabled || tg_det() || groups < 1 || groups > TG_WTR_MAX_GROUPS) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->mode != 0) return 0;
   if (d->Win % TR_W != 0 || d->Wout != d->Win || d->Hin != d->Hout || d->Hin % TR_TH != 0) return 0;
   const bool trunk = d->Cout == 64 && ldy == 64, outc = d->Cout <= 8 && ldy == 8;

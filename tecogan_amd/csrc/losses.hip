@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void pingpong_kernel(const float* __restrict__
 extern "C" int tg_pingpong(const float* gen, float* d_gen, int T, int npair, int64_t frame_elems, float loss_scale,
                            float grad_scale, float* loss, void* stream) {
   TG_CHECK_ARG(gen && d_gen && loss && T > 1 && npair > 0 && 2 * npair < T + 1 && frame_elems > 0, "bad argument");
-  hipLaunchKernelGGL(pingpong_kernel, dim3(grid_1d((int64_t)npair * frame_elems, 256 * 4, 1024)), dim3(256), 0,
+  hipLaunchKernelGGL(pingpong_kernel, TG_DET_GRID(grid_1d((int64_t)npair * frame_elems, 256 * 4, 1024)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), gen, d_gen, T, npair, frame_elems, loss_scale, grad_scale, loss);
   TG_CHECK_LAUNCH();
 }
@@ -172,7 +172,7 @@ extern "C" int tg_cosine_loss(const void* g, const void* t, int dtype, int64_t n
     // <= 1024 workgroups: every workgroup ends with ONE atomic on the same address and same-address atomics serialise at
     // the memory side (~10 ns each): 8192 of them cost ~100 us, more than the streaming itself
     dim3 gx(grid_1d(npix, 4 * (64 / lp), 1024));
-#define TG_COS(LP_) hipLaunchKernelGGL((cosine_loss_x8_kernel<LP_>), gx, dim3(256), 0, sx, (const u16*)g, (const u16*)t, npix, cos_scale, grad_scale, cos_sum, (u16*)d_g)
+#define TG_COS(LP_) hipLaunchKernelGGL((cosine_loss_x8_kernel<LP_>), TG_DET_GRID(gx), dim3(256), 0, sx, (const u16*)g, (const u16*)t, npix, cos_scale, grad_scale, cos_sum, (u16*)d_g)
     if (lp == 8) TG_COS(8);
     else if (lp == 16) TG_COS(16);
     else if (lp == 32) TG_COS(32);
@@ -182,8 +182,8 @@ extern "C" int tg_cosine_loss(const void* g, const void* t, int dtype, int64_t n
   }
   dim3 grid(grid_1d(npix, 4, 1024));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == TG_F32) hipLaunchKernelGGL((cosine_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)g, (const float*)t, npix, C, cos_scale, grad_scale, cos_sum, (float*)d_g);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((cosine_loss_kernel<u16>), grid, dim3(256), 0, st, (const u16*)g, (const u16*)t, npix, C, cos_scale, grad_scale, cos_sum, (u16*)d_g);
+  if (dtype == TG_F32) hipLaunchKernelGGL((cosine_loss_kernel<float>), TG_DET_GRID(grid), dim3(256), 0, st, (const float*)g, (const float*)t, npix, C, cos_scale, grad_scale, cos_sum, (float*)d_g);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((cosine_loss_kernel<u16>), TG_DET_GRID(grid), dim3(256), 0, st, (const u16*)g, (const u16*)t, npix, C, cos_scale, grad_scale, cos_sum, (u16*)d_g);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -209,8 +209,8 @@ extern "C" int tg_l1_loss(const void* r, const void* f, int dtype, int64_t n, fl
   TG_CHECK_ARG(r && f && loss && n > 0, "bad argument");
   dim3 grid(grid_1d(n, 256 * 4, 1024));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == TG_F32) hipLaunchKernelGGL((l1_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)r, (const float*)f, n, loss_scale, grad_scale, grad_scale_dev, loss, (float*)d_f);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((l1_loss_kernel<u16>), grid, dim3(256), 0, st, (const u16*)r, (const u16*)f, n, loss_scale, grad_scale, grad_scale_dev, loss, (u16*)d_f);
+  if (dtype == TG_F32) hipLaunchKernelGGL((l1_loss_kernel<float>), TG_DET_GRID(grid), dim3(256), 0, st, (const float*)r, (const float*)f, n, loss_scale, grad_scale, grad_scale_dev, loss, (float*)d_f);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((l1_loss_kernel<u16>), TG_DET_GRID(grid), dim3(256), 0, st, (const u16*)r, (const u16*)f, n, loss_scale, grad_scale, grad_scale_dev, loss, (u16*)d_f);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -485,8 +485,8 @@ extern "C" int tg_pack_d_input_backward(const void* d_out, int dtype, const floa
                          off, merge, Cpad) == 0, "bad argument");
   dim3 grid(grid_1d((int64_t)nt * B * h * w * 16, 256));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == TG_F32) hipLaunchKernelGGL((pack_d_bwd_kernel<float>), grid, dim3(256), 0, st, p, d_frames);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((pack_d_bwd_kernel<u16>), grid, dim3(256), 0, st, p, d_frames);
+  if (dtype == TG_F32) hipLaunchKernelGGL((pack_d_bwd_kernel<float>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, p, d_frames);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((pack_d_bwd_kernel<u16>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, p, d_frames);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }

@@ -932,8 +932,8 @@ extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t ro
   if (bn_x8_ok(dtype, C, x, y, nullptr, nullptr)) {
     const int OC = C / 8, RP = 256 / OC;
     const dim3 rg8(grid_1d(rows, RP * 16, 256)), eg8(grid_1d(rows * OC, 256, 2048));
-    hipLaunchKernelGGL((bn_stats_x8_kernel<0>), rg8, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
-    hipLaunchKernelGGL((bn_stats_x8_kernel<1>), rg8, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
+    hipLaunchKernelGGL((bn_stats_x8_kernel<0>), TG_DET_GRID(rg8), dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
+    hipLaunchKernelGGL((bn_stats_x8_kernel<1>), TG_DET_GRID(rg8), dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
     hipLaunchKernelGGL(bn_lrelu_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (u16*)y, rows, C, beta, stats,
                        eps, alpha, moving);
     TG_CHECK_LAUNCH();
@@ -941,12 +941,12 @@ extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t ro
   const dim3 rg = reduce_grid(rows, C);
   const dim3 eg(grid_1d(rows * C, 256));
   if (dtype == TG_F32) {
-    hipLaunchKernelGGL((bn_stats_kernel<float>), rg, dim3(256), 0, ST(stream), (const float*)x, rows, C, stats, 0);
-    hipLaunchKernelGGL((bn_stats_kernel<float>), rg, dim3(256), 0, ST(stream), (const float*)x, rows, C, stats, 1);
+    hipLaunchKernelGGL((bn_stats_kernel<float>), TG_DET_GRID(rg), dim3(256), 0, ST(stream), (const float*)x, rows, C, stats, 0);
+    hipLaunchKernelGGL((bn_stats_kernel<float>), TG_DET_GRID(rg), dim3(256), 0, ST(stream), (const float*)x, rows, C, stats, 1);
     hipLaunchKernelGGL((bn_lrelu_apply_kernel<float>), eg, dim3(256), 0, ST(stream), (const float*)x, (float*)y, rows, C, beta, stats, eps, alpha, moving);
   } else {
-    hipLaunchKernelGGL((bn_stats_kernel<u16>), rg, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats, 0);
-    hipLaunchKernelGGL((bn_stats_kernel<u16>), rg, dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats, 1);
+    hipLaunchKernelGGL((bn_stats_kernel<u16>), TG_DET_GRID(rg), dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats, 0);
+    hipLaunchKernelGGL((bn_stats_kernel<u16>), TG_DET_GRID(rg), dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats, 1);
     hipLaunchKernelGGL((bn_lrelu_apply_kernel<u16>), eg, dim3(256), 0, ST(stream), (const u16*)x, (u16*)y, rows, C, beta, stats, eps, alpha, moving);
   }
   TG_CHECK_LAUNCH();
@@ -964,7 +964,7 @@ extern "C" int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_
   if (bn_x8_ok(dtype, C, x, y, d_y, d_x)) {
     const int OC = C / 8, RP = 256 / OC;
     const dim3 rg8(grid_1d(rows, RP * 16, 256)), eg8(grid_1d(rows * OC, 256, 2048));
-    hipLaunchKernelGGL(bn_bwd_sums_x8_kernel, rg8, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows,
+    hipLaunchKernelGGL(bn_bwd_sums_x8_kernel, TG_DET_GRID(rg8), dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows,
                        C, stats, eps, alpha, ws);
     hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y,
                        (u16*)d_x, rows, C, stats, eps, alpha, ws, d_beta);
@@ -973,10 +973,10 @@ extern "C" int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_
   const dim3 rg = reduce_grid(rows, C);
   const dim3 eg(grid_1d(rows * C, 256));
   if (dtype == TG_F32) {
-    hipLaunchKernelGGL((bn_bwd_sums_kernel<float>), rg, dim3(256), 0, ST(stream), (const float*)x, (const float*)y, (const float*)d_y, rows, C, stats, eps, alpha, ws);
+    hipLaunchKernelGGL((bn_bwd_sums_kernel<float>), TG_DET_GRID(rg), dim3(256), 0, ST(stream), (const float*)x, (const float*)y, (const float*)d_y, rows, C, stats, eps, alpha, ws);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), eg, dim3(256), 0, ST(stream), (const float*)x, (const float*)y, (const float*)d_y, (float*)d_x, rows, C, stats, eps, alpha, ws, d_beta);
   } else {
-    hipLaunchKernelGGL((bn_bwd_sums_kernel<u16>), rg, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows, C, stats, eps, alpha, ws);
+    hipLaunchKernelGGL((bn_bwd_sums_kernel<u16>), TG_DET_GRID(rg), dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows, C, stats, eps, alpha, ws);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<u16>), eg, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, (u16*)d_x, rows, C, stats, eps, alpha, ws, d_beta);
   }
   TG_CHECK_LAUNCH();
@@ -1004,8 +1004,8 @@ extern "C" int tg_sum_sq_diff(const void* a, const void* b, int dtype, int64_t n
                               void* stream) {
   TG_CHECK_ARG(a && b && out && n > 0, "bad argument");
   dim3 grid(grid_1d(n, 256 * 8, 1024));
-  if (dtype == TG_F32) hipLaunchKernelGGL((sum_diff_kernel<float, 0>), grid, dim3(256), 0, ST(stream), (const float*)a, (const float*)b, n, scale, out);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((sum_diff_kernel<u16, 0>), grid, dim3(256), 0, ST(stream), (const u16*)a, (const u16*)b, n, scale, out);
+  if (dtype == TG_F32) hipLaunchKernelGGL((sum_diff_kernel<float, 0>), TG_DET_GRID(grid), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, n, scale, out);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((sum_diff_kernel<u16, 0>), TG_DET_GRID(grid), dim3(256), 0, ST(stream), (const u16*)a, (const u16*)b, n, scale, out);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }
@@ -1014,8 +1014,8 @@ extern "C" int tg_sum_abs_diff(const void* a, const void* b, int dtype, int64_t 
                                void* stream) {
   TG_CHECK_ARG(a && b && out && n > 0, "bad argument");
   dim3 grid(grid_1d(n, 256 * 8, 1024));
-  if (dtype == TG_F32) hipLaunchKernelGGL((sum_diff_kernel<float, 1>), grid, dim3(256), 0, ST(stream), (const float*)a, (const float*)b, n, scale, out);
-  else if (dtype == TG_BF16) hipLaunchKernelGGL((sum_diff_kernel<u16, 1>), grid, dim3(256), 0, ST(stream), (const u16*)a, (const u16*)b, n, scale, out);
+  if (dtype == TG_F32) hipLaunchKernelGGL((sum_diff_kernel<float, 1>), TG_DET_GRID(grid), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, n, scale, out);
+  else if (dtype == TG_BF16) hipLaunchKernelGGL((sum_diff_kernel<u16, 1>), TG_DET_GRID(grid), dim3(256), 0, ST(stream), (const u16*)a, (const u16*)b, n, scale, out);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -30,6 +31,11 @@ std::mutex g_mu;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;       // recycled events
 }  // namespace
+
+bool tg_det() {
+  static const bool on = getenv("TG_DETERMINISTIC") != nullptr && atoi(getenv("TG_DETERMINISTIC")) != 0;
+  return on;
+}
 
 bool tg_prof_slot(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
   if (!g_on.load(std::memory_order_relaxed)) return false;

@@ -280,10 +280,10 @@ extern "C" int tg_warp_s2d_backward(const void* d_out, int dtype, const float* p
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double by = (double)B * h * w * (Cpad * (dtype == TG_F32 ? 4.0 : 2.0) + 16.0 * 12.0 * 3.0 + 16.0);
   if (dtype == TG_F32)
-    TG_LAUNCH("warp_s2d_bwd<f32>", 0, by, (warp_s2d_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)d_out, pre,
+    TG_LAUNCH("warp_s2d_bwd<f32>", 0, by, (warp_s2d_bwd_kernel<float>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, (const float*)d_out, pre,
               flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale);
   else if (dtype == TG_BF16)
-    TG_LAUNCH("warp_s2d_bwd<bf16>", 0, by, (warp_s2d_bwd_kernel<u16>), dim3(grid), dim3(256), 0, st, (const u16*)d_out, pre,
+    TG_LAUNCH("warp_s2d_bwd<bf16>", 0, by, (warp_s2d_bwd_kernel<u16>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, (const u16*)d_out, pre,
               flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale);
   else
     TG_CHECK_ARG(false, "bad dtype");
@@ -355,7 +355,7 @@ extern "C" int tg_warp_backward(const float* d_out, const float* img, const floa
                                 int B, int H, int W, int C, void* stream) {
   TG_CHECK_ARG(d_out && img && flow && B > 0 && H > 1 && W > 1 && C > 0, "bad argument");
   const int grid = grid_1d((int64_t)B * H * W, 256);
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_out, img, flow,
+  hipLaunchKernelGGL(warp_bwd_kernel, TG_DET_GRID(grid), TG_DET_WAVE(256), 0, static_cast<hipStream_t>(stream), d_out, img, flow,
                      d_img, d_flow, B, H, W, C);
   TG_CHECK_LAUNCH();
 }

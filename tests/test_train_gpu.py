@@ -381,3 +381,18 @@ def test_captured_exchange_segments_carry_nodes_standin_world2():
     for name, w in a.ps.state_dict().items():
         d = (b.ps.view(name).cpu() - w).abs().max().item()
         assert d <= 1e-3 * w.abs().max().item() + 6.0 * F.learning_rate, (name, d)
+
+
+def test_deterministic_parity_mode_is_bit_reproducible():
+    """TG_DETERMINISTIC=1 (csrc/common.h): every accumulation with floating-point atomics runs in a fixed order -- reductions as
+    one workgroup, weight gradients without split-K, the scatter kernels as one wavefront -- so that three fresh engines produce
+    bit-identical frames, loss slots, gradients and post-Adam weights (the switch is read once per process: subprocess), while
+    the default mode is allowed to differ.  A regression is then distinguishable from summation-order noise."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "c3_repeat.py")
+    env = dict(os.environ, TG_DETERMINISTIC="1")
+    for cfg, runs in (("small", "3"), ("c3", "2")):            # c3 = BASELINE configs[2]: B=4 x 19 frames, D + VGG
+        r = subprocess.run([sys.executable, tool, "--config", cfg, "--runs", runs], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert r.stdout.strip().splitlines()[-1] == "IDENTICAL", (cfg, r.stdout[-1500:])
