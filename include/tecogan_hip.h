@@ -121,6 +121,14 @@ int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* 
                           const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
                           void* stream);
 
+/* Weight gradients of `groups` layers of DIFFERENT geometry in one call (descs[g], ldx[g], ldy[g] per layer; ld* = 0 means the
+ * channel count): the 14 convolutions of fnet, reference lib/frvsr.py:4-41 under tf.gradients (lib/Teco.py:441-449).  bf16 3x3
+ * stride-1 SAME layers leave as ONE launch; any other mix falls back to one tg_conv_wgrad per layer.  Same accumulation
+ * semantics as tg_conv_wgrad. */
+int tg_conv_wgrad_multi(const tg_conv_desc* descs, int groups, const void* const* x, int x_dtype, const int* ldx,
+                        const void* const* y, int y_dtype, const int* ldy, float* const* dw, float* const* dbias /*nullable*/,
+                        void* stream);
+
 /* out[c] += sum over rows of x[rows][C]  (bias gradient helper) */
 int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* stream);
 

@@ -595,15 +595,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
 // (launch, prologue, first loads) and after the last (atomics drain); one launch for all layers pays that once, and
 // with groups x more workgroups per launch the split-K degree per layer (= atomics) drops.
 #define TG_WGRAD_MAX_GROUPS 40
+#define TG_WGRAD_MAX_GEOS 16
+// geometry of a group (layer): the grouped launch may mix layers of DIFFERENT geometry (round 3: FNet's 14 weight gradients
+// in one launch); groups sharing a geometry (the generator trunk) share a table entry
+struct WgradGeo {
+  int N, H, W, Cx, Cy, KH, pt;
+  int M, chunk, nchunk, xtiles, ytiles, ldx, ldy;
+  unsigned xbytes, ybytes;
+};
 struct WgradRP {
   const u16* xs[TG_WGRAD_MAX_GROUPS];
   const u16* ys[TG_WGRAD_MAX_GROUPS];
   float* dws[TG_WGRAD_MAX_GROUPS];
   float* dbs[TG_WGRAD_MAX_GROUPS];
-  int groups, nchunk;
-  int N, H, W, Cx, Cy, KH, pt;
-  int M, chunk, xtiles, ytiles, ldx, ldy;
-  unsigned xbytes, ybytes;
+  int wstart[TG_WGRAD_MAX_GROUPS + 1];     // first work item of every group (prefix sums of KH * xtiles * ytiles * nchunk)
+  unsigned char gidx[TG_WGRAD_MAX_GROUPS];  // geometry table entry of every group
+  WgradGeo geo[TG_WGRAD_MAX_GEOS];
+  int groups;
 };
 
 __device__ __forceinline__ void tg_interleave_store(const u32x4& a, const u32x4& b, unsigned char* dst) {
@@ -627,60 +635,63 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
   const int nwg = gridDim.x, L = blockIdx.x;
   const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
   const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int per_chunk = p.KH * p.xtiles * p.ytiles;
-  const int per_group = per_chunk * p.nchunk;
-  const int grp = work / per_group, wrem = work - grp * per_group;
+  int grp = 0;                                        // workgroup-uniform scan of the (<= 40 entry) prefix table
+  for (int g1 = 1; g1 < p.groups; ++g1) grp = work >= p.wstart[g1] ? g1 : grp;
+  if (work >= p.wstart[p.groups]) return;
+  const WgradGeo g = p.geo[p.gidx[grp]];
+  const int wrem = work - p.wstart[grp];
+  const int per_chunk = g.KH * g.xtiles * g.ytiles;
   const int zc = wrem / per_chunk, rem = wrem - zc * per_chunk;
   const u16* __restrict__ gx = p.xs[grp];             // workgroup-uniform: scalar loads from the kernarg tables
   const u16* __restrict__ gy = p.ys[grp];
   float* __restrict__ gdw = p.dws[grp];
   float* __restrict__ gdb = p.dbs[grp];
-  const int tile = rem / p.KH, kh = rem - tile * p.KH;
-  const int xt = tile / p.ytiles, yt = tile - xt * p.ytiles;
+  const int tile = rem / g.KH, kh = rem - tile * g.KH;
+  const int xt = tile / g.ytiles, yt = tile - xt * g.ytiles;
   const int cx0 = xt * 64, cy0 = yt * 64;
-  const int mbeg = zc * p.chunk, mend = min(mbeg + p.chunk, p.M);
+  const int mbeg = zc * g.chunk, mend = min(mbeg + g.chunk, g.M);
   const bool do_bias = gdb != nullptr && kh == 0 && xt == 0;
 
-  const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.xbytes, 0x00020000);
-  const auto rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.ybytes, 0x00020000);
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)g.xbytes, 0x00020000);
+  const auto rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)g.ybytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
 
   // staging item of this thread: pixel pair pp (pixels 2pp, 2pp+1 of the 64-pixel step) x channel octet oct, for X and Y
   const int pp = tid & 31, oct = tid >> 5;
-  const bool cxok = cx0 + oct * 8 < p.ldx, cyok = cy0 + oct * 8 < p.ldy;
+  const bool cxok = cx0 + oct * 8 < g.ldx, cyok = cy0 + oct * 8 < g.ldy;
   int m = mbeg + 2 * pp;                                    // output pixel of the pair (even; W is even)
   int ox, iy;                                               // output column, input row of this kernel row
   {
-    const int t = m / p.W;
-    ox = m - t * p.W;
-    iy = t % p.H + kh - p.pt;
+    const int t = m / g.W;
+    ox = m - t * g.W;
+    iy = t % g.H + kh - g.pt;
   }
   // stride 1, equal extents: the input pixel of (output pixel m, tap kh, kw) is m + (kh-pt)*W + (kw-1), linear in m
-  unsigned offx = (unsigned)(((m + (kh - p.pt) * p.W) * p.ldx + cx0 + oct * 8) * 2);
-  unsigned offy = (unsigned)((m * p.ldy + cy0 + oct * 8) * 2);
-  const unsigned pixb = (unsigned)(p.ldx * 2), stepx = 64u * pixb, stepy = (unsigned)(64 * p.ldy * 2);
-  const int q64 = 64 / p.W, r64 = 64 - q64 * p.W, rH = q64 % p.H;
-  const int iyLim = p.H + kh - p.pt;
+  unsigned offx = (unsigned)(((m + (kh - g.pt) * g.W) * g.ldx + cx0 + oct * 8) * 2);
+  unsigned offy = (unsigned)((m * g.ldy + cy0 + oct * 8) * 2);
+  const unsigned pixb = (unsigned)(g.ldx * 2), stepx = 64u * pixb, stepy = (unsigned)(64 * g.ldy * 2);
+  const int q64 = 64 / g.W, r64 = 64 - q64 * g.W, rH = q64 % g.H;
+  const int iyLim = g.H + kh - g.pt;
 
   u32x4 rx[4], ry[2];
   auto load_step = [&]() {             // 6 loads for the current state, then advance the state by 64 pixels
-    const bool rowok = cxok & ((unsigned)iy < (unsigned)p.H);
+    const bool rowok = cxok & ((unsigned)iy < (unsigned)g.H);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool ok = rowok & ((unsigned)(ox - 1 + j) < (unsigned)p.W);
+      const bool ok = rowok & ((unsigned)(ox - 1 + j) < (unsigned)g.W);
       rx[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(ok ? offx + (unsigned)(j - 1) * pixb : OOB), 0, 0);
     }
     // pixels past the chunk contribute nothing because their Y is zero (X stays finite: in-image data or zeros)
     ry[0] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (int)((cyok & (m < mend)) ? offy : OOB), 0, 0);
-    ry[1] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (int)((cyok & (m + 1 < mend)) ? offy + (unsigned)(p.ldy * 2) : OOB), 0, 0);
+    ry[1] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (int)((cyok & (m + 1 < mend)) ? offy + (unsigned)(g.ldy * 2) : OOB), 0, 0);
     m += 64;
     offx += stepx;
     offy += stepy;
     ox += r64;
-    const bool c = ox >= p.W;
-    ox -= c ? p.W : 0;
+    const bool c = ox >= g.W;
+    ox -= c ? g.W : 0;
     iy += rH + (c ? 1 : 0);
-    iy -= iy >= iyLim ? p.H : 0;
+    iy -= iy >= iyLim ? g.H : 0;
   };
 
   f32x4 acc[3][2][2];
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
   }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    float* __restrict__ dw = gdw + (int64_t)(kh * 3 + t) * p.Cx * p.Cy;
+    float* __restrict__ dw = gdw + (int64_t)(kh * 3 + t) * g.Cx * g.Cy;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
         for (int r = 0; r < 4; ++r) {
           const int cx = cx0 + wm * 32 + i * 16 + fg * 4 + r;
           const int cy = cy0 + wn * 32 + j * 16 + frow;
-          if (cx < p.Cx && cy < p.Cy) unsafeAtomicAdd(dw + (int64_t)cx * p.Cy + cy, acc[t][i][j][r]);
+          if (cx < g.Cx && cy < g.Cy) unsafeAtomicAdd(dw + (int64_t)cx * g.Cy + cy, acc[t][i][j][r]);
         }
   }
   if (do_bias) {                       // 32 lanes (pixel pairs) share an octet: xor-reduce, one 64-wide atomic instruction
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
       if (pp == 0) red[oct * 8 + k] = bsum[k];
     }
     __syncthreads();
-    if (tid < 64 && cy0 + tid < p.Cy) unsafeAtomicAdd(gdb + cy0 + tid, red[tid]);
+    if (tid < 64 && cy0 + tid < g.Cy) unsafeAtomicAdd(gdb + cy0 + tid, red[tid]);
   }
 }
 
@@ -771,37 +782,91 @@ static bool tg_wgrad_row3_applies(const tg_conv_desc* d, int ldx, int ldy) {
   return M64 * ldx < ((int64_t)1 << 29) && M64 * ldy < ((int64_t)1 << 29);                       // 32-bit byte offsets
 }
 
-// groups >= 1 layers of identical geometry; pointer arrays live on the host and are copied into the kernel arguments
-static int tg_wgrad_row3_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
-                                float* const* dw, float* const* dbias, hipStream_t st) {
-  if (groups < 1 || groups > TG_WGRAD_MAX_GROUPS || !tg_wgrad_row3_applies(d, ldx, ldy)) return 0;
-  const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
+// groups >= 1 layers, each with its own descriptor / channel strides (identical descriptors share a geometry entry); pointer
+// arrays live on the host and are copied into the kernel arguments.  Returns 1 if launched, 0 if some layer does not fit.
+static int tg_wgrad_row3_launch_multi(const tg_conv_desc* const* ds, int groups, const void* const* x, const int* ldxs,
+                                      const void* const* y, const int* ldys, float* const* dw, float* const* dbias, hipStream_t st) {
+  if (groups < 1 || groups > TG_WGRAD_MAX_GROUPS) return 0;
   WgradRP p;
-  for (int g = 0; g < TG_WGRAD_MAX_GROUPS; ++g) {
-    const int k = g < groups ? g : 0;
-    p.xs[g] = (const u16*)x[k]; p.ys[g] = (const u16*)y[k]; p.dws[g] = dw[k]; p.dbs[g] = dbias ? dbias[k] : nullptr;
+  int ngeo = 0;
+  double total_work = 0.0, flops = 0.0, bytes = 0.0;
+  int base_blocks[TG_WGRAD_MAX_GEOS];
+  double work_of[TG_WGRAD_MAX_GEOS];
+  int members[TG_WGRAD_MAX_GEOS];
+  for (int g = 0; g < groups; ++g) {
+    const tg_conv_desc* d = ds[g];
+    if (!tg_wgrad_row3_applies(d, ldxs[g], ldys[g])) return 0;
+    const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
+    int e = -1;
+    for (int k = 0; k < ngeo && e < 0; ++k) {
+      const WgradGeo& q = p.geo[k];
+      if (q.N == d->N && q.H == d->Hout && q.W == d->Wout && q.Cx == d->Cin && q.Cy == d->Cout && q.KH == d->KH && q.pt == d->pad_t &&
+          q.ldx == ldxs[g] && q.ldy == ldys[g])
+        e = k;
+    }
+    if (e < 0) {
+      if (ngeo == TG_WGRAD_MAX_GEOS) return 0;
+      e = ngeo++;
+      WgradGeo& q = p.geo[e];
+      q.N = d->N; q.H = d->Hout; q.W = d->Wout; q.Cx = d->Cin; q.Cy = d->Cout; q.KH = d->KH; q.pt = d->pad_t;
+      q.M = (int)M64; q.ldx = ldxs[g]; q.ldy = ldys[g];
+      q.xbytes = (unsigned)(M64 * ldxs[g] * 2);
+      q.ybytes = (unsigned)(M64 * ldys[g] * 2);
+      q.xtiles = (q.Cx + 63) / 64;
+      q.ytiles = (q.Cy + 63) / 64;
+      base_blocks[e] = d->KH * q.xtiles * q.ytiles;
+      work_of[e] = (double)M64 * base_blocks[e];
+      members[e] = 0;
+    }
+    members[e]++;
+    p.gidx[g] = (unsigned char)e;
+    total_work += work_of[e];
+    flops += 2.0 * (double)M64 * 3.0 * d->KH * d->Cin * d->Cout;
+    bytes += (double)M64 * (ldxs[g] + ldys[g]) * 2.0 + 12.0 * d->KH * d->Cin * d->Cout;
+    p.xs[g] = (const u16*)x[g]; p.ys[g] = (const u16*)y[g]; p.dws[g] = dw[g]; p.dbs[g] = dbias ? dbias[g] : nullptr;
   }
+  for (int g = groups; g < TG_WGRAD_MAX_GROUPS; ++g) {
+    p.xs[g] = p.xs[0]; p.ys[g] = p.ys[0]; p.dws[g] = p.dws[0]; p.dbs[g] = p.dbs[0]; p.gidx[g] = 0;
+  }
+  // split-K degree per geometry.  One geometry (the old grouped form): the launch-wide model of tg_wgrad_ksplit.  Several:
+  // every layer gets the share of ~768 workgroups its pixel x tile volume has in the launch (at least one per base block).
+  for (int e = 0; e < ngeo; ++e) {
+    WgradGeo& q = p.geo[e];
+    int ksplit;
+    if (ngeo == 1) {
+      ksplit = tg_wgrad_ksplit(q.M, (int64_t)members[e] * q.KH * 3 * q.xtiles * q.ytiles * 4096, members[e] * base_blocks[e], 64);
+    } else {
+      ksplit = (int)(768.0 * work_of[e] / total_work / base_blocks[e] + 0.5);
+      const int max_split = (q.M + 127) / 128;
+      if (ksplit > max_split) ksplit = max_split;
+      if (ksplit < 1 || tg_det()) ksplit = 1;
+    }
+    q.chunk = (((q.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
+    q.nchunk = (q.M + q.chunk - 1) / q.chunk;
+  }
+  int w = 0;
+  for (int g = 0; g < groups; ++g) {
+    p.wstart[g] = w;
+    w += base_blocks[p.gidx[g]] * p.geo[p.gidx[g]].nchunk;
+  }
+  for (int g = groups; g <= TG_WGRAD_MAX_GROUPS; ++g) p.wstart[g] = w;
   p.groups = groups;
-  p.N = d->N; p.H = d->Hout; p.W = d->Wout; p.Cx = d->Cin; p.Cy = d->Cout; p.KH = d->KH; p.pt = d->pad_t;
-  p.M = (int)M64; p.ldx = ldx; p.ldy = ldy;
-  p.xbytes = (unsigned)(M64 * ldx * 2);
-  p.ybytes = (unsigned)(M64 * ldy * 2);
-  p.xtiles = (p.Cx + 63) / 64;
-  p.ytiles = (p.Cy + 63) / 64;
-  const int base_blocks = d->KH * p.xtiles * p.ytiles;
-  // the atomics of all groups share the chip's atomic units and the workgroups of all groups share its CUs: the model of
-  // tg_wgrad_ksplit applied to the whole launch
-  int ksplit = tg_wgrad_ksplit(p.M, (int64_t)groups * d->KH * 3 * p.xtiles * p.ytiles * 4096, groups * base_blocks, 64);
-  p.chunk = (((p.M + ksplit - 1) / ksplit) + 63) / 64 * 64;
-  ksplit = (p.M + p.chunk - 1) / p.chunk;
-  p.nchunk = ksplit;
   // TG_CONV_COEXIST: 24 KB of unused dynamic LDS cap the residency at 2 workgroups per CU (instead of 4), so that a
   // workgroup of the latency-bound chain still finds registers on every CU while this launch runs beside it
-  const unsigned pad_lds = (d->flags & TG_CONV_COEXIST) ? 24576u : 0u;
-  TG_LAUNCH("conv_wgrad_row3_bf16", 2.0 * groups * (double)M64 * 9.0 * d->Cin * d->Cout,
-            groups * ((double)M64 * (ldx + ldy) * 2.0 + 36.0 * d->Cin * d->Cout), conv_wgrad_row3_bf16_kernel,
-            dim3((unsigned)(groups * base_blocks * ksplit)), dim3(256), pad_lds, st, p);
+  const unsigned pad_lds = (ds[0]->flags & TG_CONV_COEXIST) ? 24576u : 0u;
+  TG_LAUNCH(ngeo == 1 ? "conv_wgrad_row3_bf16" : "conv_wgrad_row3_bf16_multi", flops, bytes, conv_wgrad_row3_bf16_kernel,
+            dim3((unsigned)w), dim3(256), pad_lds, st, p);
   return 1;
+}
+
+// groups >= 1 layers of identical geometry
+static int tg_wgrad_row3_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
+                                float* const* dw, float* const* dbias, hipStream_t st) {
+  if (groups < 1 || groups > TG_WGRAD_MAX_GROUPS) return 0;
+  const tg_conv_desc* ds[TG_WGRAD_MAX_GROUPS];
+  int lx[TG_WGRAD_MAX_GROUPS], ly[TG_WGRAD_MAX_GROUPS];
+  for (int g = 0; g < groups; ++g) { ds[g] = d; lx[g] = ldx; ly[g] = ldy; }
+  return tg_wgrad_row3_launch_multi(ds, groups, x, lx, y, ly, dw, dbias, st);
 }
 
 static int tg_wgrad_row3_try(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
@@ -823,6 +888,48 @@ extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const vo
     TG_CHECK_LAUNCH();
   for (int g = 0; g < groups; ++g) {                        // any other geometry / dtype: one ordinary launch per layer
     const int rc = tg_conv_wgrad(d, x[g], x_dtype, ldx, y[g], y_dtype, ldy, dw[g], dbias ? dbias[g] : nullptr, stream);
+    if (rc != TG_OK) return rc;
+  }
+  return TG_OK;
+}
+
+// Weight gradients of `groups` layers of DIFFERENT geometry in one call: descs[g] / ldx[g] / ldy[g] per layer.  bf16 3x3 stride-1
+// SAME layers (FNet's 14 convs, reference lib/frvsr.py:4-41 under tf.gradients) go out as ONE launch; anything else falls
+// back to one tg_conv_wgrad per layer.
+extern "C" int tg_conv_wgrad_multi(const tg_conv_desc* descs, int groups, const void* const* x, int x_dtype, const int* ldx,
+                                   const void* const* y, int y_dtype, const int* ldy, float* const* dw, float* const* dbias,
+                                   void* stream) {
+  TG_CHECK_ARG(descs && x && y && dw && ldx && ldy && groups >= 1, "null pointer / no groups");
+  // layers the row kernel takes go out together; every other one (dtype, stride, odd width, unpadded channel strides ...) alone
+  const tg_conv_desc* ds[TG_WGRAD_MAX_GROUPS];
+  const void *xe[TG_WGRAD_MAX_GROUPS], *ye[TG_WGRAD_MAX_GROUPS];
+  float *we[TG_WGRAD_MAX_GROUPS], *be[TG_WGRAD_MAX_GROUPS];
+  int lx[TG_WGRAD_MAX_GROUPS], ly[TG_WGRAD_MAX_GROUPS], ne = 0;
+  bool taken[TG_WGRAD_MAX_GROUPS] = {false};
+  for (int g = 0; g < groups; ++g) {
+    TG_CHECK_ARG(x[g] && y[g] && dw[g], "null group pointer");
+    if (x_dtype != TG_BF16 || y_dtype != TG_BF16 || groups > TG_WGRAD_MAX_GROUPS) continue;
+    const tg_conv_desc* d = descs + g;
+    const int a = ldx[g] > 0 ? ldx[g] : d->Cin, b = ldy[g] > 0 ? ldy[g] : d->Cout;
+    if (d->mode == 0 && a % 8 == 0 && b % 8 == 0 && a >= d->Cin && b >= d->Cout && ((((uintptr_t)x[g] | (uintptr_t)y[g])) & 15) == 0 &&
+        tg_wgrad_row3_applies(d, a, b)) {
+      ds[ne] = d; xe[ne] = x[g]; ye[ne] = y[g]; we[ne] = dw[g]; be[ne] = dbias ? dbias[g] : nullptr; lx[ne] = a; ly[ne] = b;
+      taken[g] = true;
+      ++ne;
+    }
+  }
+  if (ne >= 2) {
+    bool any_bias = false;
+    for (int k = 0; k < ne; ++k) any_bias = any_bias || be[k] != nullptr;
+    if (!tg_wgrad_row3_launch_multi(ds, ne, xe, lx, ye, ly, we, any_bias ? be : nullptr, static_cast<hipStream_t>(stream)))
+      for (int g = 0; g < groups; ++g) taken[g] = false;
+    else if (hipGetLastError() != hipSuccess) { tg_set_error("%s: launch failed", __func__); return TG_ELAUNCH; }
+  } else {
+    for (int g = 0; g < groups; ++g) taken[g] = false;
+  }
+  for (int g = 0; g < groups; ++g) {
+    if (g < TG_WGRAD_MAX_GROUPS && taken[g]) continue;
+    const int rc = tg_conv_wgrad(descs + g, x[g], x_dtype, ldx[g], y[g], y_dtype, ldy[g], dw[g], dbias ? dbias[g] : nullptr, stream);
     if (rc != TG_OK) return rc;
   }
   return TG_OK;

@@ -110,7 +110,8 @@ class TrainEngine:
         if gan:
             specs["tdiscriminator"] = discriminator_spec(self.d_cin)
         self.ps = ParamStore(specs, self.dev, act_dtype,
-                             bpad=("generator/generator_unit/output_stage/conv/Conv/weights",))
+                             bpad=("generator/generator_unit/output_stage/conv/Conv/weights",
+                                   "fnet/autoencode_unit/output_stage/conv2/Conv/weights"))
         vals = OrderedDict()
         vals.update(init_values(specs["generator"], seed))
         vals.update(init_values(specs["fnet"], seed + 1))

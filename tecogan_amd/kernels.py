@@ -66,6 +66,19 @@ def conv_wgrad_grouped(desc, xs, ys, dws, dbiases, ldx=0, ldy=0):
           "tg_conv_wgrad_grouped")
 
 
+def conv_wgrad_multi(descs, xs, ys, dws, dbiases, ldxs, ldys):
+    """Weight gradients of len(xs) layers of DIFFERENT geometry in one call (one launch for bf16 3x3 stride-1 layers)."""
+    G = len(xs)
+    assert G >= 1 and len(descs) == G and len(ys) == G and len(dws) == G and len(dbiases) == G
+    arr = (ConvDesc * G)(*descs)
+
+    def table(ts):
+        return (C.c_void_p * G)(*[_p(t) if t is not None else None for t in ts])
+    lx, ly = (C.c_int * G)(*ldxs), (C.c_int * G)(*ldys)
+    check(lib().tg_conv_wgrad_multi(arr, G, table(xs), dt(xs[0]), lx, table(ys), dt(ys[0]), ly, table(dws), table(dbiases),
+                                    _stream()), "tg_conv_wgrad_multi")
+
+
 def colsum(x, rows, Cn, out):
     check(lib().tg_colsum(_p(x), dt(x), rows, Cn, _p(out), _stream()), "tg_colsum")
 

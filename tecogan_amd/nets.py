@@ -71,6 +71,18 @@ def conv_wgrad(ps, wname, bname, x, dy, stride=1, flags=0):
     K.conv_wgrad(d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, ldx=Cp, ldy=Co)
 
 
+def conv_wgrad_args(ps, wname, bname, x, dy, stride=1, flags=0):
+    """The arguments conv_wgrad would launch with, for K.conv_wgrad_multi: (desc, x, dy, dW view, dbias view, ldx, ldy)."""
+    e = ps.entries[wname]
+    N, H, W, Cp = x.shape
+    _, Ho, Wo, Co = dy.shape
+    k = e["k"]
+    _, pt = K.same_pad(H, k, stride)
+    _, pl = K.same_pad(W, k, stride)
+    d = K.conv_desc(N, H, W, e["A"], Ho, Wo, e["B"], k, k, stride, pt, pl, 0, 0, 0, flags=flags)
+    return d, x, dy, ps.gview(wname), ps.gview(bname) if bname else None, Cp, Co
+
+
 def deconv_fwd(ps, wname, bname, x, act=ACT_NONE, alpha=0.0, out=None, flags=0):
     """slim.conv2d_transpose k3 s2 SAME (reference lib/ops.py:35-44, [TF1] A.2): transposed mode, pad 0."""
     e = ps.entries[wname]                      # TF layout [kh,kw,Cout,Cin] -> A = Cout, B = Cin
@@ -294,6 +306,7 @@ class FNet:
 
     def __init__(self, ps):
         self.ps = ps
+        self.wgrad_multi = os.environ.get("TG_FNET_WGRAD_MULTI", "1") == "1"      # A/B switch
 
     def forward(self, x, keep=True):
         """x [N,h,w,8] (prev LR | cur LR | 0-pad) -> flow [N,h',w',2] fp32 (h' = h - h%8)."""
@@ -317,15 +330,32 @@ class FNet:
         return flow, ((saved, net, o1, flow) if keep else None)
 
     def backward(self, saved_all, d_flow, flags=0):
-        """Backward pass: the input-gradient chain, and the weight gradients accumulated into the flat gradient buffer."""
+        """Backward pass: the input-gradient chain first, then the 14 weight gradients as ONE multi-geometry launch
+        (tg_conv_wgrad_multi; TG_FNET_WGRAD_MULTI=0: one launch per layer, interleaved with the chain as in round 2): as
+        separate launches they are 14 x 17-35 us of launch, prologue and atomics tails for 37 GFLOP of work."""
         ps, p = self.ps, self.P
         saved, net_last, o1, flow = saved_all
+        todo = [] if self.wgrad_multi else None
+
+        def wg(wname, bname, x, dy):
+            if todo is None:
+                conv_wgrad(ps, wname, bname, x, dy, flags=flags)
+            else:
+                todo.append(conv_wgrad_args(ps, wname, bname, x, dy, flags=flags))
+
         s = p + "output_stage/"
-        g = K.act_backward(d_flow, flow, _empty(flow.shape, ps.act_dtype, flow), ACT_TANH, 24.0)
-        conv_wgrad(ps, s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, g, flags=flags)
+        if ps.entries[s + "conv2/Conv/weights"]["Bpad"] == 8:
+            # the 2-channel flow gradient zero-padded to 8 channels (16-byte pixels), as the generator's 3-channel output
+            # gradient is: its weight gradient then runs on the MFMA row kernel (83 -> ~20 us at 72 pairs, it used to fall to
+            # the generic kernel) and its input gradient on the 8-channel conv kernel
+            g2 = K.act_backward(d_flow, flow, torch.empty_like(flow), ACT_TANH, 24.0)
+            g = K.concat2_pad(g2, None, _empty(flow.shape[:3] + (8,), ps.act_dtype, flow))
+        else:
+            g = K.act_backward(d_flow, flow, _empty(flow.shape, ps.act_dtype, flow), ACT_TANH, 24.0)
+        wg(s + "conv2/Conv/weights", s + "conv2/Conv/biases", o1, g)
         g = conv_bwd_data(ps, s + "conv2/Conv/weights", g, o1.shape[1:3], 1, aux=o1, mask_act=ACT_LRELU, mask_alpha=0.2,
                           flags=flags)
-        conv_wgrad(ps, s + "conv1/Conv/weights", s + "conv1/Conv/biases", net_last, g, flags=flags)
+        wg(s + "conv1/Conv/weights", s + "conv1/Conv/biases", net_last, g)
         g = conv_bwd_data(ps, s + "conv1/Conv/weights", g, net_last.shape[1:3], 1, flags=flags)          # d (resampled map)
         for bi in range(len(FNET_BLOCKS) - 1, -1, -1):
             name = FNET_BLOCKS[bi][0]
@@ -335,12 +365,15 @@ class FNet:
                 g = K.maxpool2_backward(c2, g, torch.empty_like(c2), ACT_LRELU, 0.2)
             else:
                 g = K.upsample2_backward(g, torch.empty_like(c2), c2, ACT_LRELU, 0.2)
-            conv_wgrad(ps, sc + "/conv_2/Conv/weights", sc + "/conv_2/Conv/biases", c1, g, flags=flags)
+            wg(sc + "/conv_2/Conv/weights", sc + "/conv_2/Conv/biases", c1, g)
             g = conv_bwd_data(ps, sc + "/conv_2/Conv/weights", g, c1.shape[1:3], 1, aux=c1, mask_act=ACT_LRELU,
                               mask_alpha=0.2, flags=flags)
-            conv_wgrad(ps, sc + "/conv_1/Conv/weights", sc + "/conv_1/Conv/biases", x_in, g, flags=flags)
+            wg(sc + "/conv_1/Conv/weights", sc + "/conv_1/Conv/biases", x_in, g)
             if bi > 0:
                 g = conv_bwd_data(ps, sc + "/conv_1/Conv/weights", g, x_in.shape[1:3], 1, flags=flags)
+        if todo:
+            ds, xs, dys, dws, dbs, lxs, lys = zip(*todo)
+            K.conv_wgrad_multi(list(ds), list(xs), list(dys), list(dws), list(dbs), list(lxs), list(lys))
         return None
 
 

@@ -1073,3 +1073,41 @@ def test_wgrad_transpose_read_kernel_wide_images_and_output_conv(case):
     close(dw - 0.25, w.grad, 3e-4, "transpose-read dW %s" % (case,))
     close(db, b.grad, 3e-4, "transpose-read dbias %s" % (case,))
 
+
+
+def test_wgrad_multi_geometry_grouped_launch_matches_autograd():
+    """tg_conv_wgrad_multi: weight / bias gradients of layers of DIFFERENT geometry in one launch (FNet's 14 convs,
+    lib/frvsr.py:4-41 under tf.gradients): image sizes 32 / 16 / 8 / 4, channel counts 8(6) .. 256, padded channel strides,
+    two layers sharing one geometry -- each against torch autograd on the bf16-rounded operands."""
+    cases = [(5, 32, 32, 6, 8, 32), (5, 32, 32, 32, 32, 32), (5, 16, 16, 32, 32, 64), (5, 16, 16, 64, 64, 64), (5, 8, 8, 64, 64, 128),
+             (5, 4, 4, 128, 128, 256), (5, 4, 4, 256, 256, 256), (5, 4, 4, 256, 256, 256), (5, 32, 32, 32, 32, 2)]
+    descs, xs, ys, dws, dbs, lxs, lys, refs = [], [], [], [], [], [], [], []
+    for i, (N, H, W, Ci, Cp, Co) in enumerate(cases):
+        x = torch.zeros(N, H, W, Cp)
+        x[..., :Ci] = rnd(N, H, W, Ci, seed=10 + i)
+        x = x.bfloat16()
+        Cop = (Co + 7) // 8 * 8
+        y = torch.zeros(N, H, W, Cop)
+        y[..., :Co] = rnd(N, H, W, Co, seed=40 + i)
+        y = y.bfloat16()
+        descs.append(K.conv_desc(N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16))
+        xs.append(x.to(DEV))
+        ys.append(y.to(DEV))
+        dws.append(torch.full((3, 3, Ci, Co), 0.5, device=DEV))
+        dbs.append(torch.zeros(Co, device=DEV))
+        lxs.append(Cp)
+        lys.append(Cop)
+        xr = x.float()[..., :Ci].requires_grad_()
+        w = torch.zeros(3, 3, Ci, Co, requires_grad=True)
+        b = torch.zeros(Co, requires_grad=True)
+        O.conv2(xr, w, b, 1).backward(y.float()[..., :Co])
+        refs.append((w.grad, b.grad))
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_wgrad_multi(descs, xs, ys, dws, dbs, lxs, lys)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert len(ents) == 1 and ents[0]["name"] == "conv_wgrad_row3_bf16_multi" and ents[0]["calls"] == 1, ents
+    for i, (gw, gb) in enumerate(refs):
+        close(dws[i] - 0.5, gw, 3e-4, "multi-geometry dW layer %d %s" % (i, cases[i]))
+        close(dbs[i], gb, 3e-4, "multi-geometry dbias layer %d %s" % (i, cases[i]))

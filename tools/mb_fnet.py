@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""FNet forward + backward alone (graph-replayed), per launch type: where do the 0.8 ms of the backward pass go?"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from collections import OrderedDict
+from tecogan_amd import kernels as K
+from tecogan_amd.nets import FNET_CPAD, FNet
+from tecogan_amd.params import ParamStore, fnet_spec, init_values
+from tools.microbench import timeit
+
+N = int(os.environ.get("MB_N", "72"))
+ps = ParamStore(OrderedDict(fnet=fnet_spec()), torch.device("cuda"), torch.bfloat16,
+                bpad=("fnet/autoencode_unit/output_stage/conv2/Conv/weights",))       # as TrainEngine builds it
+ps.load(init_values(fnet_spec(), 1))
+fn = FNet(ps)
+x = torch.rand(N, 32, 32, FNET_CPAD, device="cuda").bfloat16()
+flow, saved = fn.forward(x)
+dflow = torch.randn_like(flow)
+for _ in range(3):
+    fn.backward(saved, dflow)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    fn.backward(saved, dflow)
+t = timeit(g.replay, 50, 5)
+K.prof_collect(); K.prof_enable(True); fn.backward(saved, dflow); torch.cuda.synchronize(); K.prof_enable(False)
+ents = K.prof_collect()
+print("FNet backward N=%d multi=%s target=%s: %.1f us per pass; instrumented launches: %s" % (
+    N, os.environ.get("TG_FNET_WGRAD_MULTI", "1"), "-", t,
+    ", ".join("%s x%d %.0f us" % (e["name"], e["calls"], e["total_us"]) for e in ents[:6])))
