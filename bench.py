@@ -303,14 +303,57 @@ def sub_main_py(steps=400, display=100):
     return out
 
 
-def first_step_frames(config, dtype, device):
-    """HR frames of the first training step from damped xavier weights (params.damp_values: the well-conditioned regime
-    the BASELINE-size parity tests use) on the seeded synthetic batch."""
+def first_step(config, dtype, device):
+    """HR frames and the flat gradient buffer of the first training step from damped xavier weights (params.damp_values: the
+    well-conditioned regime the BASELINE-size parity tests use) on the seeded synthetic batch."""
     e = new_engine(config, dtype, device, use_graph=False)
     x, y = synthetic_batch(e.F, 1234, device)
     e.step(x, y)
     torch.cuda.synchronize()
-    return e.gen.clone()
+    return e.gen.clone(), {sc: e.ps.scope_slice(sc, e.ps.grad).clone() for sc in e.ps.scope_range}
+
+
+def grad_err(ga, gb):
+    """Per optimiser scope: relative L2 error of the whole gradient, and the worst per-tensor-free max-norm error."""
+    out = {}
+    for sc in ga:
+        a, b = ga[sc].double(), gb[sc].double()
+        if float(b.norm()) == 0.0:
+            continue                                  # the discriminator's slice on a gated-off step
+        out[sc] = {"rel_l2": round(float((a - b).norm() / b.norm()), 6),
+                   "max_norm_rel": round(float((a - b).abs().max() / b.abs().max()), 6)}
+    return out
+
+
+def loss_trajectory(config, device, steps=200, every=20):
+    """`steps` optimiser steps of the bf16 mode and of the fp32 mode from the same damped weights over the same seeded
+    sequence of batches (a fresh batch every step): the losses the reference prints, sampled every `every` steps, and the
+    relative drift of the bf16 trajectory from the fp32 one."""
+    traj = {}
+    for dtype in ("bf16", "f32"):
+        e = new_engine(config, dtype, device)
+        rows = []
+        for it in range(steps):
+            x, y = synthetic_batch(e.F, 5000 + it, device)
+            e.step(x, y)
+            if (it + 1) % every == 0:
+                torch.cuda.synchronize()
+                L = e.losses()
+                rows.append([L.get("l2_content_loss", L.get("content_loss")), L.get("l2_warp_loss", L.get("warp_loss")),
+                             L.get("t_discrim_loss"), L.get("t_balance")])
+        traj[dtype] = rows
+        del e
+        torch.cuda.empty_cache()
+    names = ["content_loss", "warp_loss", "t_discrim_loss", "t_balance"]
+    out = {"steps": steps, "sampled_every": every, "columns": names}
+    for j, n in enumerate(names):
+        a = [r[j] for r in traj["bf16"]]
+        b = [r[j] for r in traj["f32"]]
+        if a[0] is None:
+            continue
+        out[n] = {"bf16": [round(v, 5) for v in a], "f32": [round(v, 5) for v in b],
+                  "max_rel_dev": round(max(abs(u - v) / max(abs(v), 1e-12) for u, v in zip(a, b)), 5)}
+    return out
 
 
 def sub_records(device, fence):
@@ -333,11 +376,18 @@ def sub_records(device, fence):
                                "note": "fp32 activations + exact-fp32 MFMA: the mode the 1e-3 parity tests run in"}
     del e
     # error of the timed bf16 mode against the fp32 mode at the full BASELINE sizes
+    fb, gb = first_step("tecogan", "bf16", device)
+    ff, gf = first_step("tecogan", "f32", device)
+    rb, rgb = first_step("frvsr", "bf16", device)
+    rf, rgf = first_step("frvsr", "f32", device)
     out["bf16_vs_fp32"] = {
-        "C3_tecogan_gen_outputs": err_stats(first_step_frames("tecogan", "bf16", device), first_step_frames("tecogan", "f32", device)),
-        "C2_frvsr_gen_outputs": err_stats(first_step_frames("frvsr", "bf16", device), first_step_frames("frvsr", "f32", device)),
-        "note": "HR frames (all 19 / 10 recurrent frames) of the bf16 mode against the fp32 mode after one step from identical "
-                "damped-xavier weights and batch; per_pixel_rel = |a-b| / max(|b|, 1e-3 max|b|)"}
+        "C3_tecogan_gen_outputs": err_stats(fb, ff), "C2_frvsr_gen_outputs": err_stats(rb, rf),
+        "C3_tecogan_gradients": grad_err(gb, gf), "C2_frvsr_gradients": grad_err(rgb, rgf),
+        "C3_tecogan_loss_trajectory": loss_trajectory("tecogan", device),
+        "note": "HR frames (all 19 / 10 recurrent frames) and the flat gradient of each optimiser scope, bf16 mode against the "
+                "fp32 mode after one step from identical damped-xavier weights and batch; per_pixel_rel = |a-b| / "
+                "max(|b|, 1e-3 max|b|); loss_trajectory: 200 Adam steps of both modes over the same batch sequence"}
+    del fb, ff, rb, rf, gb, gf, rgb, rgf
     out["inference_fps"] = sub_inference(device)
     torch.cuda.empty_cache()
     out["main_py_image_per_sec"] = sub_main_py()

@@ -138,6 +138,9 @@ int tg_colsum(const void* x, int dtype, int64_t rows, int C, float* out, void* s
  * (channel padding of the first layers: 51->56, 6->8, 27->32, 3->8). */
 int tg_pack_weights(const float* src_base, void* dst_base, int dst_dtype, const int64_t* tab,
                     int count, int transpose, void* stream);
+/* The same for BOTH layouts in one launch (dst_t = [tap][out][in], dst_n = [tap][in][out]): the per-step refresh of the MFMA
+ * weight copies after the three Adam updates. */
+int tg_pack_weights_both(const float* src_base, void* dst_t, void* dst_n, int dst_dtype, const int64_t* tab, int count, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Fused recurrent input builder:

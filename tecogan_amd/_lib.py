@@ -35,6 +35,7 @@ SIGNATURES = {
     "tg_conv_wgrad_multi": [_D, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P],
     "tg_colsum": [_P, _I, _L, _I, _P, _P],
     "tg_pack_weights": [_P, _P, _I, _P, _I, _I, _P],
+    "tg_pack_weights_both": [_P, _P, _P, _I, _P, _I, _P],
     "tg_warp_s2d_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "tg_warp_s2d_backward": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "tg_warp_forward": [_P, _P, _P, _I, _I, _I, _I, _P],

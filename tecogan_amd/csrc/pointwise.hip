@@ -695,28 +695,34 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
 // weight re-layout: dst[tap][b][a] = src[tap][a][b] (or plain converting copy); table-driven so one
 // launch re-packs every weight of the flat parameter buffer.
 template <typename TD>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src, TD* __restrict__ dst,
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src, TD* __restrict__ dstT, TD* __restrict__ dstN,
                                                            const int64_t* __restrict__ tab, int transpose) {
+  // blockIdx.z selects the layout when BOTH compute copies are refreshed in one launch (transpose < 0): z = 0 the transposed
+  // copy into dstT, z = 1 the natural copy into dstN; otherwise `transpose` says which and dstT is the destination
+  const bool tr = transpose < 0 ? blockIdx.z == 0 : transpose != 0;
+  TD* __restrict__ dst = (transpose < 0 && blockIdx.z == 1) ? dstN : dstT;
   const int64_t* t = tab + (int64_t)blockIdx.y * 7;
-  const int64_t so = t[0], dof = t[1], taps = t[2];
-  const int A = (int)t[3], Bs = (int)t[4], Ap = (int)t[5];   // src [tap][A][B]; A zero-padded to Ap in dst
-  const int Bd = transpose ? Bs : (int)t[6];                   // natural copy: B zero-padded to Bp as well
-  const int64_t n = taps * Ap * Bd;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    int a, b;
-    int64_t tap;
-    if (transpose) {  // e indexes dst [tap][b][a_pad]
-      a = (int)(e % Ap);
-      const int64_t r = e / Ap;
-      b = (int)(r % Bd);
+  const int64_t so = t[0], dof = t[1];
+  const unsigned taps = (unsigned)t[2];
+  const unsigned A = (unsigned)t[3], Bs = (unsigned)t[4], Ap = (unsigned)t[5];   // src [tap][A][B]; A zero-padded to Ap in dst
+  const unsigned Bd = tr ? Bs : (unsigned)t[6];                                  // natural copy: B zero-padded to Bp as well
+  const unsigned n = taps * Ap * Bd;                          // (a weight tensor has far fewer than 2^32 elements: 32-bit index math)
+  const float* __restrict__ s0 = src + so;
+  TD* __restrict__ d0 = dst + dof;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    unsigned a, b, tap;
+    if (tr) {         // e indexes dst [tap][b][a_pad]
+      const unsigned r = e / Ap;
+      a = e - r * Ap;
       tap = r / Bd;
+      b = r - tap * Bd;
     } else {          // e indexes dst [tap][a_pad][b]
-      b = (int)(e % Bd);
-      const int64_t r = e / Bd;
-      a = (int)(r % Ap);
+      const unsigned r = e / Bd;
+      b = e - r * Bd;
       tap = r / Ap;
+      a = r - tap * Ap;
     }
-    Elem<TD>::st(dst + dof + e, (a < A && b < Bs) ? src[so + (tap * A + a) * Bs + b] : 0.f);
+    Elem<TD>::st(d0 + e, (a < A && b < Bs) ? s0[(tap * A + a) * Bs + b] : 0.f);
   }
 }
 
@@ -994,8 +1000,19 @@ extern "C" int tg_pack_weights(const float* src_base, void* dst_base, int dst_dt
                                int transpose, void* stream) {
   TG_CHECK_ARG(src_base && dst_base && tab && count > 0, "bad argument");
   dim3 grid(64, count);
-  if (dst_dtype == TG_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, ST(stream), src_base, (float*)dst_base, tab, transpose);
-  else if (dst_dtype == TG_BF16) hipLaunchKernelGGL((pack_weights_kernel<u16>), grid, dim3(256), 0, ST(stream), src_base, (u16*)dst_base, tab, transpose);
+  if (dst_dtype == TG_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, ST(stream), src_base, (float*)dst_base, (float*)nullptr, tab, transpose ? 1 : 0);
+  else if (dst_dtype == TG_BF16) hipLaunchKernelGGL((pack_weights_kernel<u16>), grid, dim3(256), 0, ST(stream), src_base, (u16*)dst_base, (u16*)nullptr, tab, transpose ? 1 : 0);
+  else TG_CHECK_ARG(false, "bad dtype");
+  TG_CHECK_LAUNCH();
+}
+
+// both compute copies ([tap][out][in] and [tap][in][out]) of every weight of the flat parameter buffer in ONE launch
+extern "C" int tg_pack_weights_both(const float* src_base, void* dst_t, void* dst_n, int dst_dtype, const int64_t* tab, int count,
+                                    void* stream) {
+  TG_CHECK_ARG(src_base && dst_t && dst_n && tab && count > 0, "bad argument");
+  dim3 grid(64, count, 2);
+  if (dst_dtype == TG_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), grid, dim3(256), 0, ST(stream), src_base, (float*)dst_t, (float*)dst_n, tab, -1);
+  else if (dst_dtype == TG_BF16) hipLaunchKernelGGL((pack_weights_kernel<u16>), grid, dim3(256), 0, ST(stream), src_base, (u16*)dst_t, (u16*)dst_n, tab, -1);
   else TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();
 }

@@ -88,6 +88,10 @@ def pack_weights(src_base, dst_base, tab, count, transpose):
           "tg_pack_weights")
 
 
+def pack_weights_both(src_base, dst_t, dst_n, tab, count):
+    check(lib().tg_pack_weights_both(_p(src_base), _p(dst_t), _p(dst_n), dt(dst_t), _p(tab), count, _stream()), "tg_pack_weights_both")
+
+
 def warp_s2d_forward(pre, flow_lr, lr, out, scale, shift, warped=None):
     B, h, w, _ = lr.shape
     hf, wf = (flow_lr.shape[1], flow_lr.shape[2]) if flow_lr is not None else (h, w)

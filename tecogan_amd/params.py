@@ -203,10 +203,9 @@ class ParamStore:
         return OrderedDict((n, self.view(n).detach().cpu().clone()) for n in self.entries)
 
     def repack(self):
-        """Refresh both compute copies from the fp32 master (two launches for the whole store)."""
+        """Refresh both compute copies from the fp32 master (one launch for the whole store)."""
         if self.ntab:
-            K.pack_weights(self.flat, self.wT, self.table, self.ntab, True)
-            K.pack_weights(self.flat, self.wN, self.table, self.ntab, False)
+            K.pack_weights_both(self.flat, self.wT, self.wN, self.table, self.ntab)
 
     def zero_grad(self):
         self.grad.zero_()

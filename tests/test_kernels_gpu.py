@@ -466,6 +466,19 @@ def test_pack_weights():
         assert torch.equal(dst[:9 * 8 * 16], ref0) and torch.equal(dst[9 * 8 * 16:], ref1)
         K.pack_weights(flat, dst, tab, 2, False)
         assert torch.equal(dst, flat.to(dtype))
+        # both layouts in one launch (the per-step refresh), with padded extents: 5 -> 8 reduction channels, 3 -> 8 outputs
+        tabp = torch.tensor([[0, 0, 9, 8, 16, 8, 16], [9 * 8 * 16, 9 * 8 * 16, 4, 5, 3, 8, 8]], dtype=torch.int64, device=DEV)
+        dT = torch.full((9 * 8 * 16 + 4 * 8 * 8,), 7.0, device=DEV, dtype=dtype)
+        dN = torch.full_like(dT, 7.0)
+        K.pack_weights_both(flat, dT, dN, tabp, 2)
+        assert torch.equal(dT[:9 * 8 * 16], ref0) and torch.equal(dN[:9 * 8 * 16], flat[:9 * 8 * 16].to(dtype))
+        w = flat[9 * 8 * 16:9 * 8 * 16 + 60].reshape(4, 5, 3)
+        refT = torch.zeros(4, 3, 8, device=DEV)
+        refT[:, :, :5] = w.permute(0, 2, 1)
+        refN = torch.zeros(4, 8, 8, device=DEV)
+        refN[:, :5, :3] = w
+        assert torch.equal(dT[9 * 8 * 16:9 * 8 * 16 + 96], refT.reshape(-1).to(dtype))
+        assert torch.equal(dN[9 * 8 * 16:], refN.reshape(-1).to(dtype))
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 3, 1), (1, 9, 11, 32, 128, 4, 2), (3, 7, 5, 128, 64, 3, 1),
