@@ -325,6 +325,14 @@ def grad_err(ga, gb):
     return out
 
 
+def _guarded(fn, *args):
+    """A sub-record must never cost the headline line: a failure is reported in its place."""
+    try:
+        return fn(*args)
+    except Exception as e:                                       # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
 def loss_trajectory(config, device, steps=200, every=20):
     """`steps` optimiser steps of the bf16 mode and of the fp32 mode from the same damped weights over the same seeded
     sequence of batches (a fresh batch every step): the losses the reference prints, sampled every `every` steps, and the
@@ -383,7 +391,7 @@ def sub_records(device, fence):
     out["bf16_vs_fp32"] = {
         "C3_tecogan_gen_outputs": err_stats(fb, ff), "C2_frvsr_gen_outputs": err_stats(rb, rf),
         "C3_tecogan_gradients": grad_err(gb, gf), "C2_frvsr_gradients": grad_err(rgb, rgf),
-        "C3_tecogan_loss_trajectory": loss_trajectory("tecogan", device),
+        "C3_tecogan_loss_trajectory": _guarded(loss_trajectory, "tecogan", device),
         "note": "HR frames (all 19 / 10 recurrent frames) and the flat gradient of each optimiser scope, bf16 mode against the "
                 "fp32 mode after one step from identical damped-xavier weights and batch; per_pixel_rel = |a-b| / "
                 "max(|b|, 1e-3 max|b|); loss_trajectory: 200 Adam steps of both modes over the same batch sequence"}
