@@ -29,3 +29,6 @@ ents = K.prof_collect()
 print("FNet backward N=%d multi=%s target=%s: %.1f us per pass; instrumented launches: %s" % (
     N, os.environ.get("TG_FNET_WGRAD_MULTI", "1"), "-", t,
     ", ".join("%s x%d %.0f us" % (e["name"], e["calls"], e["total_us"]) for e in ents[:6])))
+for e in ents:
+    if e["name"].startswith("conv_wgrad"):
+        print("   %-32s x%d %.0f us  %.1f MFLOP  %.2f MB" % (e["name"], e["calls"], e["total_us"], e["flops"] / 1e6, e["bytes"] / 1e6))
