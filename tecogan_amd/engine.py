@@ -442,6 +442,10 @@ class TrainEngine:
         # [tc, T): late frames.  One cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at
         # 10 + 9 and 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the early chunk has the forward pass to hide in).
         tc = (min((T + 3) // 2, T - 1) if T > 1 else T) if self.use_vgg else T
+        # (SEVERAL early chunks -- cuts at 6/12/15, 5/10/15, 7/13/16, 6/11/14/17 frames, each chunk's VGG pass beside the next
+        #  forward segment and only 4 / 3 / 2 frames left exposed -- measured 11.94-12.75 ms against 11.70-11.80 for the one
+        #  cut, profiles/r03x_ab.txt: a VGG pass costs ~0.35 ms + 41 us per image alone and 1.3 ms beside the chain whatever
+        #  its size from 12 to 24 images, so every extra chunk costs more than the exposure it removes.)
         d_vgg = None
         if self.use_vgg:
             d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
