@@ -107,13 +107,17 @@ __global__ __launch_bounds__(256) void warp_s2d_fwd_scalar_kernel(const float* _
 }
 
 
-// Vectorised form (the scalar kernel above is the fallback for odd channel paddings).  Same 16-lanes-per-LR-pixel map,
-// but (a) the 2x2 bilinear footprint of a lane is two 24-byte row segments (tl|tr, bl|br: 6 consecutive floats each)
-// fetched as dwordx4 + dwordx2 instead of 12 scalar loads, and (b) the generator-input row of an LR pixel (Cpad
-// channels: LR frame | 48 space-to-depth channels | zero padding) is assembled in LDS and leaves as 16-byte vectors --
-// 448 contiguous bytes per wave (bf16, Cpad 56) -- instead of three 2-byte stores per lane (measured at 1080p:
-// 49 us = 0.85 TB/s for the scalar kernel, store-issue bound).  Each wave owns its four LDS rows, and the LDS executes
-// one wave's operations in order, so the hand-off needs no workgroup barrier (the loop trip count differs per wave).
+// Row-band form (the scalar kernel above is the fallback for odd channel paddings).  One wave owns 16 consecutive LR pixels of
+// one LR row = a 4 x 64 band of HR pixels; a workgroup = 4 vertically adjacent bands (17 HR rows of the previous frame for 16
+// produced).  Lane l is HR column 64*jt + l, so (a) the 2x2 bilinear footprints of a wave -- two 24-byte row segments per
+// lane (tl|tr, bl|br: 6 consecutive floats, dwordx4 + dwordx2) -- cover one ~780-byte stretch per HR row instead of four
+// 60-byte ones, (b) the four HR rows of the band are independent: their flows come from ONE set of four LR corner loads per
+// lane and all eight footprint loads are in flight together (the 16-lanes-per-LR-pixel form this replaces made four dependent
+// round trips per wave at 1080p: 15.2 us = 2.76 TB/s, latency-bound), and (c) the generator-input rows of the 16 LR pixels
+// (Cpad channels each: LR frame | 48 space-to-depth channels | zero padding) are assembled in LDS and leave as ONE contiguous
+// run of 16-byte vectors (1792 bytes per wave at bf16, Cpad 56).  The LDS executes one wave's operations in order, so the
+// hand-off needs no workgroup barrier.  Workgroups are renumbered so that each XCD (workgroup id mod 8) owns a contiguous
+// range of bands and shared footprint rows meet in one L2.
 struct __attribute__((packed, aligned(4))) F6 { float v[6]; };
 
 template <typename TOut>
@@ -122,90 +126,159 @@ __global__ __launch_bounds__(256) void warp_s2d_fwd_kernel(const float* __restri
                                                            const float* __restrict__ lr, TOut* __restrict__ out,
                                                            int B, int h, int w, int hf, int wf, int Cpad, float scale,
                                                            float shift, float* __restrict__ warped) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 16 rows of Cpad elements
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 4 waves x 16 rows of Cpad elements
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 15, pl = lane >> 4;
-  constexpr int EPV = 16 / (int)sizeof(TOut);
-  const int vpp = Cpad / EPV;                                               // 16-byte vectors per row
-  TOut* __restrict__ row = reinterpret_cast<TOut*>(smem) + (wave * 4 + pl) * Cpad;
-  const int64_t npix = (int64_t)B * h * w;
-  const int64_t nquad = (npix + 3) >> 2;
-  const int H = 4 * h, W = 4 * w;
-  for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nquad; q += (int64_t)gridDim.x * 4) {     // wave-uniform
-    const int64_t lp = min(q * 4 + pl, npix - 1);           // lanes past the end redo the last pixel (never stored)
-    const int j = (int)(lp % w);
-    const int i = (int)((lp / w) % h);
-    const int b = (int)(lp / ((int64_t)w * h));
-    if (sub < 3) Elem<TOut>::st(row + sub, lr[lp * 3 + sub]);
-    if (51 + sub < Cpad) Elem<TOut>::st(row + 51 + sub, 0.f);
-    float v[3] = {0.f, 0.f, 0.f};
-    if (pre) {
-      float wts[4];
-      const float2 f = flow_hr_at(flow_lr, b, i, j, sub, h, w, hf, wf, wts);
-      const int Y = 4 * i + (sub >> 2), X = 4 * j + (sub & 3);
-      const BilinearTap t = make_tap((float)Y - f.x, (float)X - f.y, H, W);
-      const float* __restrict__ p0 = pre + ((int64_t)(b * H + t.fy) * W + t.fx) * 3;
-      const F6 top6 = *reinterpret_cast<const F6*>(p0);
-      const F6 bot6 = *reinterpret_cast<const F6*>(p0 + (int64_t)W * 3);
+  const int jl = lane >> 2, xs = lane & 3;
+  const int tw = (w + 15) >> 4, th = (h + 3) >> 2;
+  // XCD-contiguous renumbering (a bijection for any grid size)
+  const int nb = (int)gridDim.x, xcd = (int)blockIdx.x & 7;
+  int bid = xcd * (nb >> 3) + min(xcd, nb & 7) + ((int)blockIdx.x >> 3);
+  const int jt = bid % tw;
+  bid /= tw;
+  const int i = (bid % th) * 4 + wave, b = bid / th;
+  if (i >= h) return;                                        // wave-uniform; the kernel has no workgroup barrier
+  const int j0 = jt * 16;
+  const int nv = min(16, w - j0);                            // LR pixels of this band that exist
+  const int j = min(j0 + jl, w - 1);                         // lanes past the row end redo its last pixel (never stored)
+  const bool live = j0 + jl < w;
+  const int64_t lp0 = ((int64_t)b * h + i) * w + j0;
+  TOut* __restrict__ rows = reinterpret_cast<TOut*>(smem) + wave * 16 * Cpad;
+  const float lrv = lr[lp0 * 3 + min(lane, nv * 3 - 1)];     // unconditional: issued here, first used after the footprint loads
+  float v[4][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float tl = top6.v[c], tr = top6.v[3 + c], bl = bot6.v[c], br = bot6.v[3 + c];
-        const float top = t.ax * (tr - tl) + tl;
-        const float bot = t.ax * (br - bl) + bl;
-        const float wv = t.ay * (bot - top) + top;
-        if (warped && q * 4 + pl < npix) warped[((int64_t)(b * H + Y) * W + X) * 3 + c] = wv;
-        v[c] = wv * scale + shift;
-      }
+  for (int r = 0; r < 4; ++r) v[r][0] = v[r][1] = v[r][2] = 0.f;
+  if (pre) {
+    const int H = 4 * h, W = 4 * w;
+    const int i1 = min(i + 1, h - 1), j1 = min(j + 1, w - 1);
+    float2 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ci = mirror((k & 2) ? i1 : i, hf), cj = mirror((k & 1) ? j1 : j, wf);
+      c[k] = *reinterpret_cast<const float2*>(flow_lr + ((int64_t)(b * hf + ci) * wf + cj) * 2);
+    }
+    const int X = 4 * j + xs;
+    BilinearTap t[4];
+    F6 top6[4], bot6[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // gen_flow = upscale_four(gen_flow_lr * 4.0): scale first, then blend (lib/Teco.py:113) -- the arithmetic of flow_hr_at
+      const float wy = 0.25f * r, wx = 0.25f * xs;
+      const float w0 = (1.f - wy) * (1.f - wx), w1 = (1.f - wy) * wx, w2 = wy * (1.f - wx), w3 = wy * wx;
+      const float fy = (c[0].x * 4.f) * w0 + (c[1].x * 4.f) * w1 + (c[2].x * 4.f) * w2 + (c[3].x * 4.f) * w3;
+      const float fx = (c[0].y * 4.f) * w0 + (c[1].y * 4.f) * w1 + (c[2].y * 4.f) * w2 + (c[3].y * 4.f) * w3;
+      t[r] = make_tap((float)(4 * i + r) - fy, (float)X - fx, H, W);
+      const float* __restrict__ p0 = pre + ((int64_t)(b * H + t[r].fy) * W + t[r].fx) * 3;
+      top6[r] = *reinterpret_cast<const F6*>(p0);
+      bot6[r] = *reinterpret_cast<const F6*>(p0 + (int64_t)W * 3);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Elem<TOut>::st(row + 3 + sub * 3 + c, v[c]);
-    __builtin_amdgcn_wave_barrier();                         // same-wave LDS ops are ordered; keep the compiler from mixing them
-    if (lane < 4 * vpp) {
-      const int pv = lane / vpp, vec = lane - pv * vpp;
-      const int64_t lpo = q * 4 + pv;
-      if (lpo < npix) {
-        const uint4 d = *reinterpret_cast<const uint4*>(smem + ((wave * 4 + pv) * Cpad) * sizeof(TOut) + vec * 16);
-        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(out) + lpo * Cpad * (int64_t)sizeof(TOut) + vec * 16) = d;
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float tl = top6[r].v[ch], tr = top6[r].v[3 + ch], bl = bot6[r].v[ch], br = bot6[r].v[3 + ch];
+        const float top = t[r].ax * (tr - tl) + tl;
+        const float bot = t[r].ax * (br - bl) + bl;
+        const float wv = t[r].ay * (bot - top) + top;
+        if (warped && live) warped[((int64_t)(b * H + 4 * i + r) * W + X) * 3 + ch] = wv;
+        v[r][ch] = wv * scale + shift;
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) Elem<TOut>::st(rows + jl * Cpad + 3 + (r * 4 + xs) * 3 + ch, v[r][ch]);
+  if (lane < nv * 3) Elem<TOut>::st(rows + (lane / 3) * Cpad + lane % 3, lrv);
+  for (int k = 51 + xs; k < Cpad; k += 4) Elem<TOut>::st(rows + jl * Cpad + k, 0.f);          // zero padding of row jl
+  __builtin_amdgcn_wave_barrier();                           // same-wave LDS ops are ordered; keep the compiler from mixing them
+  const int nvec = nv * Cpad * (int)sizeof(TOut) / 16;
+  const unsigned char* __restrict__ src = smem + (size_t)wave * 16 * Cpad * sizeof(TOut);
+  unsigned char* __restrict__ dst = reinterpret_cast<unsigned char*>(out) + lp0 * Cpad * (int64_t)sizeof(TOut);
+  for (int e = lane; e < nvec; e += 64)
+    *reinterpret_cast<uint4*>(dst + e * 16) = *reinterpret_cast<const uint4*>(src + e * 16);
 }
 
+// Backward of the fused warp: gather of d_out, scatter into d_pre (the previous HR frame's gradient) and into the LR flow.
+// The scatter is the cost (12 fp32 atomics per HR pixel: 16.5 us per [4,128,128] frame, one launch per BPTT frame on the
+// critical path).  MERGE: where the flow is smooth the footprints of neighbouring HR pixels tile the frame -- the right tap of
+// pixel X IS the left tap of pixel X+1, the lower taps of row Y the upper taps of row Y+1.  Lanes therefore hand their
+// tr / br contributions to the lane on their right and their (merged) bl / br to the lane below whenever the ADDRESSES say
+// so (o00_left + 3 == o00_right, o00_up + 3W == o00_down: the test is on addresses only, so it is exact for any flow), and a
+// contribution that has been handed on (or is zero) issues no atomic: 3 instead of 12 atomics per pixel in smooth regions,
+// the old count where neighbouring footprints do not line up.  Lane pairs: left/right along the HR row incl. the step into the
+// next LR pixel of the wave (lane +-1 / +-13), up/down inside the 4x4 block of an LR pixel (lane +-4).
 template <typename TG>
 __global__ __launch_bounds__(256) void warp_s2d_bwd_kernel(const TG* __restrict__ d_out, const float* __restrict__ pre,
                                                            const float* __restrict__ flow_lr,
                                                            float* __restrict__ d_pre, float* __restrict__ d_flow_lr,
-                                                           int B, int h, int w, int Cpad, float scale) {
-  const int64_t npix = (int64_t)B * h * w;
-  const int H = 4 * h, W = 4 * w;
-  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; (gid >> 4) < npix;
-       gid += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t lp = gid >> 4;
-    const int sub = (int)(gid & 15);
+                                                           int B, int h, int w, int Cpad, float scale, int merge) {
+  const int64_t npix = (int64_t)B * h * w, nlane = npix * 16;
+  const int H = 4 * h, W = 4 * w, W3 = W * 3;
+  const int lane = threadIdx.x & 63, sub = lane & 15, dy = sub >> 2, dx = sub & 3;
+  const int lsrc = dx > 0 ? lane - 1 : lane - 13, rdst = dx < 3 ? lane + 1 : lane + 13;
+  const bool has_l = lsrc >= 0, has_r = rdst < 64, has_u = dy > 0, has_d = dy < 3;
+  const int lfrom = has_l ? lsrc : lane, rfrom = has_r ? rdst : lane, ufrom = has_u ? lane - 4 : lane, dfrom = has_d ? lane + 4 : lane;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < nlane;
+       base += (int64_t)gridDim.x * blockDim.x) {                                                   // wave-uniform trip count
+    const int64_t gid = base + lane;
+    const bool active = gid < nlane;                         // whole 16-lane groups past the end idle (zero contributions)
+    const int64_t lp = active ? (gid >> 4) : npix - 1;
     const int j = (int)(lp % w);
     const int i = (int)((lp / w) % h);
     const int b = (int)(lp / ((int64_t)w * h));
     float wts[4];
     const float2 f = flow_hr_at(flow_lr, b, i, j, sub, h, w, h, w, wts);
-    const int Y = 4 * i + (sub >> 2), X = 4 * j + (sub & 3);
+    const int Y = 4 * i + dy, X = 4 * j + dx;
     const BilinearTap t = make_tap((float)Y - f.x, (float)X - f.y, H, W);
     const int64_t o00 = ((int64_t)(b * H + t.fy) * W + t.fx) * 3;
-    const int64_t o10 = o00 + (int64_t)W * 3;
+    const int64_t o10 = o00 + W3;
     float d_ax = 0.f, d_ay = 0.f;
+    float ctl[3], ctr[3], cbl[3], cbr[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float g = Elem<TG>::ld(d_out + lp * Cpad + 3 + sub * 3 + c) * scale;
+      const float g = active ? Elem<TG>::ld(d_out + lp * Cpad + 3 + sub * 3 + c) * scale : 0.f;
       const float tl = pre[o00 + c], tr = pre[o00 + 3 + c], bl = pre[o10 + c], br = pre[o10 + 3 + c];
       const float top = t.ax * (tr - tl) + tl;
       const float bot = t.ax * (br - bl) + bl;
       d_ay += g * (bot - top);
       d_ax += g * ((1.f - t.ay) * (tr - tl) + t.ay * (br - bl));
-      if (d_pre) {
-        unsafeAtomicAdd(d_pre + o00 + c, g * (1.f - t.ay) * (1.f - t.ax));
-        unsafeAtomicAdd(d_pre + o00 + 3 + c, g * (1.f - t.ay) * t.ax);
-        unsafeAtomicAdd(d_pre + o10 + c, g * t.ay * (1.f - t.ax));
-        unsafeAtomicAdd(d_pre + o10 + 3 + c, g * t.ay * t.ax);
+      ctl[c] = g * (1.f - t.ay) * (1.f - t.ax);
+      ctr[c] = g * (1.f - t.ay) * t.ax;
+      cbl[c] = g * t.ay * (1.f - t.ax);
+      cbr[c] = g * t.ay * t.ax;
+    }
+    if (d_pre) {
+      if (merge) {                                           // kernel argument: uniform
+        const int o = active ? (int)o00 : -8;                // (the launcher checks that the frame has < 2^31 elements)
+        const int oL = __shfl(o, lfrom), oR = __shfl(o, rfrom);
+        const bool recv_l = has_l && oL + 3 == o, send_r = has_r && o + 3 == oR;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float a = __shfl(ctr[c], lfrom), q = __shfl(cbr[c], lfrom);
+          if (recv_l) { ctl[c] += a; cbl[c] += q; }
+        }
+        if (send_r) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) ctr[c] = cbr[c] = 0.f;
+        }
+        const int oU = __shfl(o, ufrom), oD = __shfl(o, dfrom);
+        const bool recv_u = has_u && oU + W3 == o, send_d = has_d && o + W3 == oD;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float a = __shfl(cbl[c], ufrom), q = __shfl(cbr[c], ufrom);
+          if (recv_u) { ctl[c] += a; ctr[c] += q; }
+        }
+        if (send_d) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) cbl[c] = cbr[c] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (ctl[c] != 0.f) unsafeAtomicAdd(d_pre + o00 + c, ctl[c]);
+        if (ctr[c] != 0.f) unsafeAtomicAdd(d_pre + o00 + 3 + c, ctr[c]);
+        if (cbl[c] != 0.f) unsafeAtomicAdd(d_pre + o10 + c, cbl[c]);
+        if (cbr[c] != 0.f) unsafeAtomicAdd(d_pre + o10 + 3 + c, cbr[c]);
       }
     }
     if (d_flow_lr) {
@@ -222,7 +295,7 @@ __global__ __launch_bounds__(256) void warp_s2d_bwd_kernel(const TG* __restrict_
           cx[k] += __shfl_xor(cx[k], o, 16);
         }
       }
-      if (sub == 0) {
+      if (sub == 0 && active) {
         const int i1 = min(i + 1, h - 1), j1 = min(j + 1, w - 1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -244,16 +317,17 @@ extern "C" int tg_warp_s2d_forward(const float* pre, const float* flow_lr, const
   TG_CHECK_ARG(B > 0 && h > 0 && w > 0 && Cpad >= 51 && Cpad <= 67, "bad shape (51 <= Cpad <= 67)");
   TG_CHECK_ARG(hf > 0 && wf > 0 && hf <= h && wf <= w && 2 * hf >= h && 2 * wf >= w, "bad flow extent");
   const int64_t work = (int64_t)B * h * w * 16;
-  const int grid = grid_1d(work, 256);
+  int grid = grid_1d(work, 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   // algorithmic bytes: previous HR frame + LR flow + LR frame read once, generator input written once
   const double px = (double)B * h * w;
   const double by = px * ((pre ? 16.0 * 12.0 : 0.0) + (pre ? (double)hf * wf / ((double)h * w) * 8.0 : 0.0) + 12.0 +
                           Cpad * (out_dtype == TG_F32 ? 4.0 : 2.0));
   const int esz = out_dtype == TG_F32 ? 4 : 2;
-  const bool no_vec = false;
-  const bool vec = !no_vec && (Cpad * esz) % 16 == 0 && Cpad * esz <= 256 && ((uintptr_t)out & 15) == 0;
-  const unsigned lds = 16u * Cpad * esz;
+  const int64_t bands = (int64_t)B * ((h + 3) / 4) * ((w + 15) / 16);       // one workgroup per 4 LR rows x 16 LR pixels
+  const bool vec = (Cpad * esz) % 16 == 0 && Cpad * esz <= 256 && ((uintptr_t)out & 15) == 0 && bands < ((int64_t)1 << 31);
+  const unsigned lds = 64u * Cpad * esz;
+  if (vec) grid = (int)bands;
   if (out_dtype == TG_F32 && vec)
     TG_LAUNCH("warp_s2d_fwd<f32>", 0, by, (warp_s2d_fwd_kernel<float>), dim3(grid), dim3(256), lds, st, pre, flow_lr, lr,
               (float*)out, B, h, w, hf, wf, Cpad, scale, shift, warped);
@@ -276,15 +350,17 @@ extern "C" int tg_warp_s2d_backward(const void* d_out, int dtype, const float* p
   TG_CHECK_ARG(d_out && pre && flow_lr, "null pointer");
   TG_CHECK_ARG(B > 0 && h > 0 && w > 0 && Cpad >= 51, "bad shape");
   const int64_t work = (int64_t)B * h * w * 16;
-  const int grid = grid_1d(work, 256);
+  int grid = grid_1d(work, 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double by = (double)B * h * w * (Cpad * (dtype == TG_F32 ? 4.0 : 2.0) + 16.0 * 12.0 * 3.0 + 16.0);
+  static const bool merge_env = getenv("TG_WARP_BWD_MERGE") == nullptr || atoi(getenv("TG_WARP_BWD_MERGE")) != 0;   // A/B switch
+  const int merge = merge_env && (int64_t)B * h * w * 48 + (int64_t)w * 12 + 16 < ((int64_t)1 << 31);   // 32-bit tap offsets
   if (dtype == TG_F32)
     TG_LAUNCH("warp_s2d_bwd<f32>", 0, by, (warp_s2d_bwd_kernel<float>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, (const float*)d_out, pre,
-              flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale);
+              flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale, merge);
   else if (dtype == TG_BF16)
     TG_LAUNCH("warp_s2d_bwd<bf16>", 0, by, (warp_s2d_bwd_kernel<u16>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, (const u16*)d_out, pre,
-              flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale);
+              flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale, merge);
   else
     TG_CHECK_ARG(false, "bad dtype");
   TG_CHECK_LAUNCH();

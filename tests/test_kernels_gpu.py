@@ -238,6 +238,36 @@ def test_warp_s2d_forward_backward(B, h, w):
     close(d_flow, flow.grad, 5e-4, "warp_s2d d_flow")
 
 
+@pytest.mark.parametrize("B,h,w,kind", [(2, 8, 8, "const"), (1, 5, 9, "ramp"), (4, 32, 32, "ramp"), (1, 7, 18, "tiny"),
+                                        (2, 6, 10, "steps")])
+def test_warp_s2d_backward_merged_scatter_smooth_flows(B, h, w, kind):
+    """The scatter of warp_s2d_backward hands tap contributions to neighbouring lanes wherever the footprints line up (smooth
+    flows: 3 instead of 12 atomics per HR pixel).  Constant / slowly varying / tiny / piecewise-constant flows exercise the
+    hand-over in both directions, across LR-pixel and wave boundaries, and next to places where it must NOT happen."""
+    pre = rnd(B, 4 * h, 4 * w, 3, seed=1).requires_grad_()
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    if kind == "const":
+        fl = torch.stack((torch.full((h, w), 0.3275), torch.full((h, w), -0.6125)), -1)
+    elif kind == "ramp":
+        fl = torch.stack((0.21 + 0.013 * yy - 0.007 * xx, -0.4 + 0.011 * xx + 0.005 * yy), -1)
+    elif kind == "steps":
+        fl = torch.stack((torch.where(xx < w // 2, 0.2625, -0.7375), torch.where(yy < h // 2, 0.5125, 1.2625)), -1)
+    else:                       # (exactly integer displacements would put every query ON a cell border, where one ulp of the
+        fl = torch.full((h, w, 2), 0.0125)      # blended flow decides the cell: not a property of the scatter under test)
+    flow = fl.expand(B, h, w, 2).clone().requires_grad_()
+    lr = rnd(B, h, w, 3, seed=3)
+    ref = oracle_gen_input(pre, flow, lr, 0.5, 0.5, 56)
+    g = rnd(B, h, w, 56, seed=4)
+    ref.backward(g)
+    for gd in (g, g.bfloat16()):
+        d_pre = torch.zeros(B, 4 * h, 4 * w, 3, device=DEV)
+        d_flow = torch.zeros(B, h, w, 2, device=DEV)
+        K.warp_s2d_backward(gd.to(DEV), pre.detach().to(DEV), flow.detach().to(DEV), d_pre, d_flow, 0.5)
+        tol = 1e-4 if gd.dtype == torch.float32 else 8e-3
+        close(d_pre, pre.grad, tol, "warp_s2d d_pre (%s)" % kind)
+        close(d_flow, flow.grad, 5 * tol, "warp_s2d d_flow (%s)" % kind)
+
+
 def test_warp_s2d_zero_flow_is_exact_shuffle():
     """Bit-exact: zero flow -> the s2d channels are exactly the reshuffled input."""
     B, h, w = 2, 8, 8
