@@ -867,29 +867,34 @@ extern "C" int tg_concat2_pad(const float* a, int Ca, const float* b, int Cb, vo
 // Frame-major gather of a batch-major sequence: dst[t][b][:] = src[b][idx[t]][:] -- the ping-pong extension
 // tf.concat(r, r[:, -2::-1]) of reference lib/Teco.py:80-85 plus the [B,T] -> [T,B] re-layout of this path's sequences.
 struct SeqIdx { int v[64]; };
-__global__ __launch_bounds__(256) void seq_gather_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int B, int T0,
-                                                         int T, int E4, SeqIdx idx) {
-  const int n = T * B * E4;                                   // < 2^31 (checked by the host)
+template <typename V>      // float4 when a frame is a whole number of 16-byte vectors, float otherwise (odd crop sizes)
+__global__ __launch_bounds__(256) void seq_gather_kernel(const V* __restrict__ src, V* __restrict__ dst, int B, int T0,
+                                                         int T, int E, SeqIdx idx) {
+  const int n = T * B * E;                                    // < 2^31 (checked by the host)
   for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const int k = e % E4, tb = e / E4;
+    const int k = e % E, tb = e / E;
     const int b = tb % B, t = tb / B;
-    dst[e] = src[((int64_t)b * T0 + idx.v[t]) * E4 + k];
+    dst[e] = src[((int64_t)b * T0 + idx.v[t]) * E + k];
   }
 }
 
 extern "C" int tg_seq_gather(const float* src, float* dst, int B, int T0, int T, int64_t frame_elems, const int* idx,
                              void* stream) {
   TG_CHECK_ARG(src && dst && idx && B > 0 && T0 > 0 && T > 0 && T <= 64 && frame_elems > 0, "bad argument");
-  TG_CHECK_ARG(frame_elems % 4 == 0 && ((((uintptr_t)src | (uintptr_t)dst)) & 15) == 0, "frame size must be a multiple of 4 floats");
-  TG_CHECK_ARG((int64_t)T * B * (frame_elems / 4) < ((int64_t)1 << 31), "sequence too large");
+  const bool vec = frame_elems % 4 == 0 && ((((uintptr_t)src | (uintptr_t)dst)) & 15) == 0;
+  const int64_t E64 = vec ? frame_elems / 4 : frame_elems;
+  TG_CHECK_ARG((int64_t)T * B * E64 < ((int64_t)1 << 31), "sequence too large");
   SeqIdx s;
   for (int t = 0; t < T; ++t) {
     TG_CHECK_ARG(idx[t] >= 0 && idx[t] < T0, "frame index out of range");
     s.v[t] = idx[t];
   }
-  const int E4 = (int)(frame_elems / 4);
-  hipLaunchKernelGGL(seq_gather_kernel, dim3(grid_1d((int64_t)T * B * E4, 256, 8192)), dim3(256), 0, ST(stream),
-                     (const float4*)src, (float4*)dst, B, T0, T, E4, s);
+  const int E = (int)E64;
+  const dim3 grid(grid_1d((int64_t)T * B * E, 256, 8192));
+  if (vec)
+    hipLaunchKernelGGL(seq_gather_kernel<float4>, grid, dim3(256), 0, ST(stream), (const float4*)src, (float4*)dst, B, T0, T, E, s);
+  else
+    hipLaunchKernelGGL(seq_gather_kernel<float>, grid, dim3(256), 0, ST(stream), src, dst, B, T0, T, E, s);
   TG_CHECK_LAUNCH();
 }
 

@@ -376,3 +376,22 @@ def test_engine_replay_executes_the_plan_with_streams_and_events(monkeypatch):
             assert log[i + 1] == ("record", n, k)
         if not lazy:
             assert not [e for e in log if e[0] == "host_wait"]
+
+
+def test_discriminator_bn_scratch_pool_falls_back_when_exhausted():
+    """nets.Discriminator._ws: slices of the caller's pre-zeroed pool while it lasts, a fresh (self-zeroed) tensor after that --
+    a pool sized for another schedule must not kill a step."""
+    from tecogan_amd.nets import Discriminator
+    D = Discriminator.__new__(Discriminator)
+    D.scratch, D._cursor = None, 0
+    like = torch.zeros(1)
+    buf, pooled = D._ws(4, like)
+    assert not pooled and buf.shape == (2, 4)
+    D.set_scratch(torch.zeros(20))
+    a, pa = D._ws(4, like)
+    b, pb = D._ws(4, like)
+    c, pc = D._ws(4, like)            # 24 > 20: exhausted
+    assert pa and pb and not pc and c.shape == (2, 4)
+    assert a.data_ptr() == D.scratch.data_ptr() and b.data_ptr() == D.scratch[8:].data_ptr()
+    d, pd = D._ws(2, like)            # the remaining 4 floats still serve a smaller request
+    assert pd and d.data_ptr() == D.scratch[16:].data_ptr()

@@ -778,6 +778,12 @@ def test_concat2_pad_lincomb_affine_seq_gather():
     dst = torch.empty(7, 3, 6, 6, 3, device=DEV)
     K.seq_gather(src.to(DEV), dst, idx)
     assert torch.equal(dst.cpu(), src.transpose(0, 1)[idx].contiguous())
+    # odd crop size: a frame of 5*5*3 = 75 floats is not a whole number of 16-byte vectors (scalar form)
+    src = rnd(2, 3, 5, 5, 3, seed=64)
+    idx = [0, 1, 2, 1, 0]
+    dst = torch.empty(5, 2, 5, 5, 3, device=DEV)
+    K.seq_gather(src.to(DEV), dst, idx)
+    assert torch.equal(dst.cpu(), src.transpose(0, 1)[idx].contiguous())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
