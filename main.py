@@ -4,7 +4,8 @@ through the hipGraph recurrent step, `--mode train` runs the FRVSR / TecoGAN tra
 
 Kept from the reference: every flag spelling (tecogan_amd/flags.py), the stdout lines
 "total time ... frame number ..." (main.py:270) and "progress ... image/sec ..." (main.py:409), the logfile
-tee, checkpoints `<output_dir>/model-<step>` written initially, every save_freq steps and on Ctrl+C.
+tee, checkpoints `<output_dir>/model-<step>` written initially, every save_freq steps and on Ctrl+C, each followed by
+the reference's inference try-out of the new checkpoint in a child process (testWhileTrain).
 Different by design: no TF session/graph; checkpoints are torch files keyed by the TF variable names
 (SURVEY.md Appendix B); `--checkpoint random` runs with seeded random weights (no trained model offline);
 multi-GPU training = launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`.
@@ -50,6 +51,28 @@ def save_checkpoint(eng, output_dir, step, avg=None):
     steps = {scope: int(eng.sched[8 + 2 * k].item()) for k, scope in enumerate(eng.opt_scopes)}
     save_bundle(path, eng.ps, step, beta1=eng.F.beta, adam_steps=steps, tb_ema=float(eng.sched[1].item()))
     return path
+
+
+def testWhileTrain(FLAGS, testno=0, lr_dir="./LR/calendar/"):
+    """reference main.py:151-174: whenever a checkpoint has been saved, try it in `--mode inference` in a child process --
+    the first 10 frames of the calendar clip, written as `<output_dir>/train/<step>_*.png`.  The reference hard-codes the
+    clip folder and the interpreter; here the child runs under the same interpreter and is skipped (with a note) when the
+    clip folder does not exist.  The child is its own process group so that Ctrl+C in the trainer does not reach it.
+    Returns the Popen object (None when skipped)."""
+    import subprocess
+    desstr = os.path.join(FLAGS.output_dir, 'train/')
+    cmd1 = [sys.executable, os.path.join(ROOT, "main.py"),
+            "--output_dir", desstr, "--summary_dir", desstr, "--mode", "inference",
+            "--num_resblock", "%d" % FLAGS.num_resblock,
+            "--checkpoint", os.path.join(FLAGS.output_dir, 'model-%d' % testno),
+            "--cudaID", FLAGS.cudaID,
+            "--input_dir_LR", lr_dir, "--output_pre", "", "--output_name", "%09d" % testno, "--input_dir_len", "10"]
+    print('[testWhileTrain] step %d:' % testno)
+    if not os.path.isdir(lr_dir):
+        print('[testWhileTrain] %s not found, inference test skipped' % lr_dir)
+        return None
+    print(' '.join(cmd1))
+    return subprocess.Popen(cmd1, preexec_fn=os.setpgrp)
 
 
 def restore_training(eng, FLAGS):
@@ -224,10 +247,14 @@ def run_training(FLAGS):
             if rank == 0 and (run_step % FLAGS.save_freq) == 0:
                 print('Save the checkpoint')
                 save_checkpoint(eng, FLAGS.output_dir, run_step, (avg_raw, n_avg))
+                testWhileTrain(FLAGS, run_step)
     except KeyboardInterrupt:
         if step > 1 and rank == 0:
             print('main.py: KeyboardInterrupt->saving the checkpoint')
             save_checkpoint(eng, FLAGS.output_dir, run_step, (avg_raw, n_avg))
+            child = testWhileTrain(FLAGS, run_step)
+            if child is not None:
+                child.communicate()
         print('main.py: quit')
         sys.exit(0)
     torch.cuda.synchronize()

@@ -395,3 +395,33 @@ def test_discriminator_bn_scratch_pool_falls_back_when_exhausted():
     assert a.data_ptr() == D.scratch.data_ptr() and b.data_ptr() == D.scratch[8:].data_ptr()
     d, pd = D._ws(2, like)            # the remaining 4 floats still serve a smaller request
     assert pd and d.data_ptr() == D.scratch[16:].data_ptr()
+
+
+def test_test_while_train_spawns_the_reference_inference_command(tmp_path, monkeypatch):
+    """main.testWhileTrain (reference main.py:151-174): after a checkpoint save, `--mode inference` on 10 frames of the calendar
+    clip in a child process of its own process group; skipped with a note when the clip folder is absent."""
+    import importlib
+    import main as M
+    importlib.reload(M)
+    from tecogan_amd import flags as FL
+    F = FL.parse(["--output_dir", str(tmp_path / "out"), "--mode", "train", "--num_resblock", "16", "--cudaID", "0"])
+    monkeypatch.chdir(tmp_path)
+    assert M.testWhileTrain(F, 500) is None                      # no ./LR/calendar/ here
+    (tmp_path / "LR" / "calendar").mkdir(parents=True)
+    seen = {}
+
+    class FakePopen:
+        def __init__(self, cmd, preexec_fn=None):
+            seen["cmd"], seen["preexec"] = cmd, preexec_fn
+
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    child = M.testWhileTrain(F, 500)
+    cmd = seen["cmd"]
+    assert isinstance(child, FakePopen) and seen["preexec"] is os.setpgrp
+    assert cmd[0] == sys.executable and cmd[1].endswith("main.py")
+    opts = dict(zip(cmd[2::2], cmd[3::2]))
+    assert opts["--mode"] == "inference" and opts["--num_resblock"] == "16" and opts["--input_dir_len"] == "10"
+    assert opts["--checkpoint"] == os.path.join(str(tmp_path / "out"), "model-500")
+    assert opts["--output_dir"] == opts["--summary_dir"] == os.path.join(str(tmp_path / "out"), "train/")
+    assert opts["--input_dir_LR"] == "./LR/calendar/" and opts["--output_pre"] == "" and opts["--output_name"] == "000000500"
+    FL.parse(cmd[2:])                                            # the child's command line parses with the same flag table
