@@ -205,7 +205,9 @@ class Tee(object):
         self.log.flush()
 
 
-def main(argv=None):
+def main(argv=None, flow=None):
+    """flow: optical-flow provider for tOF (an object with grey(img) and __call__(prev, next)); default: OpenCV's Farneback
+    flow when cv2 imports -- tests pass a stand-in to exercise the tOF bookkeeping without OpenCV."""
     import pandas as pd
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--output", required=True, help="the path of output directory")
@@ -218,7 +220,7 @@ def main(argv=None):
     os.makedirs(a.output, exist_ok=True)
     sys.stdout = Tee(os.path.join(a.output, "metricsfile.txt"))
     keys = [k for k in a.keys.split(",") if k in ALL_KEYS]
-    lpips = flow = None
+    lpips = None
     if "LPIPS" in keys or "tLP100" in keys:
         if a.lpips_alexnet and a.lpips_lin and os.path.exists(a.lpips_alexnet) and os.path.exists(a.lpips_lin):
             import torch
@@ -227,7 +229,7 @@ def main(argv=None):
             print("[metrics] LPIPS / tLP100 skipped: pass --lpips_alexnet (torchvision's AlexNet ImageNet state_dict, which the "
                   "reference downloads) and --lpips_lin (LPIPSmodels/v0.1/alex.pth of the reference)")
             keys = [k for k in keys if k not in ("LPIPS", "tLP100")]
-    if "tOF" in keys:
+    if "tOF" in keys and flow is None:
         try:
             flow = FarnebackFlow()
         except ImportError:

@@ -106,3 +106,61 @@ def test_folder_protocol_and_csv(tmp_path):
     assert 30 < vals["PSNR"][0] < 45
     csv = (out / "metrics.csv").read_text()
     assert "PSNR_00" in csv and "Avg_PSNR" in csv and "FolderAvg_SSIM" in csv and "FrameAvg_PSNR" in csv
+
+
+def test_lpips_restatement_matches_the_reference_module_on_seeded_backbone():
+    """metrics.Lpips against the reference's own LPIPSmodels.networks_basic.PNetLin('alex', v0.1): the distances in
+    tests/golden/lpips_reference.npz were produced by that module (oracle/make_golden_lpips.py, imported unmodified from the
+    reference) with the reference's trained linear heads and a SEEDED random AlexNet backbone (the ImageNet weights are a
+    torchvision download); the same backbone state and the stored heads must give the same numbers here."""
+    import torch
+    from oracle.make_golden_lpips import seeded_alexnet_state, seeded_images
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_reference.npz"))
+    lin = {k: torch.from_numpy(gold["lin/" + k]) for k in gold["lin_keys"]}
+    net = M.Lpips(seeded_alexnet_state(), lin)
+    for case, (h, w, d_ref, d_same) in enumerate(gold["cases"]):
+        a, b = seeded_images(100 + case, int(h), int(w))
+        d = net(M.im2tensor(a), M.im2tensor(b))
+        assert abs(d - d_ref) <= 1e-5 * max(abs(d_ref), 1e-3), (case, d, d_ref)
+        assert net(M.im2tensor(a), M.im2tensor(a)) == d_same == 0.0
+
+
+def test_metrics_cli_reproduces_the_reference_script_csv(tmp_path):
+    """tests/golden/metrics_reference.csv is the metrics.csv the REFERENCE's own metrics.py wrote for the seeded folders of
+    oracle/make_golden_metrics.py (run unmodified, on stand-ins for absl / cv2 / skimage / torchvision -- see that script).
+    This repository's metrics.py, given the same folders, the same seeded LPIPS backbone, the reference's linear heads and
+    the same stand-in flow, must write the same tables: listing and ordering, frame cut, crop of oversized results,
+    crop_8x8, PSNR, SSIM call convention, LPIPS, tLP100, tOF bookkeeping, per-folder / Avg / FolderAvg / FrameAvg rows."""
+    import torch
+    from oracle import make_golden_metrics as G
+    from oracle.make_golden_lpips import seeded_alexnet_state
+    res, tar = G.write_folders(str(tmp_path))
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_reference.npz"))
+    torch.save(seeded_alexnet_state(), str(tmp_path / "alexnet.pth"))
+    torch.save({str(k): torch.from_numpy(gold["lin/" + str(k)]) for k in gold["lin_keys"]}, str(tmp_path / "lin.pth"))
+
+    class Flow:
+        grey = staticmethod(G.grey)
+
+        def __call__(self, a, b):
+            return G.standin_flow(a, b)
+
+    stdout = sys.stdout
+    try:
+        M.main(["--output", str(tmp_path / "out"), "--results", ",".join(res), "--targets", ",".join(tar),
+                "--lpips_alexnet", str(tmp_path / "alexnet.pth"), "--lpips_lin", str(tmp_path / "lin.pth")], flow=Flow())
+    finally:
+        sys.stdout = stdout
+    mine = open(str(tmp_path / "out" / "metrics.csv")).read().strip().splitlines()
+    ref = open(os.path.join(os.path.dirname(__file__), "golden", "metrics_reference.csv")).read().strip().splitlines()
+    assert len(mine) == len(ref), (len(mine), len(ref))
+    for lm, lr in zip(mine, ref):
+        cm, cr = lm.split(","), lr.split(",")
+        assert len(cm) == len(cr), (lm, lr)
+        for a, b in zip(cm, cr):
+            try:
+                fb = float(b)
+            except ValueError:
+                assert a == b, (lm, lr)                       # header cells and empty cells
+                continue
+            assert abs(float(a) - fb) <= 2e-5 * max(abs(fb), 1e-3), (lm, lr)
