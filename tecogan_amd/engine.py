@@ -164,6 +164,10 @@ class TrainEngine:
         # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass, 64 the VGG pass
         # of the late frames beside D's generator-side backward pass (before the BPTT)
         self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
+        # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
+        # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Off by
+        # default until it has been measured on hardware (prepared in round 3 after the GPU budget was spent).
+        self.vggt_dedup = os.environ.get("TG_VGGT_DEDUP", "0") == "1" and bool(F.pingpang) and self.T0 > 1
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
@@ -425,9 +429,17 @@ class TrainEngine:
         if self.use_vgg:
             sk, cx = part(1)
             with seg("vggt", sk, ["head"]):
-                xt = K.vgg_preprocess_forward(hr_seq.view(T * B, H, H, 3),
-                                              torch.empty(T * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+                Tu = self.T0 if self.vggt_dedup else T                  # frames whose features are actually computed
+                xt = K.vgg_preprocess_forward(hr_seq[:Tu].view(Tu * B, H, H, 3),
+                                              torch.empty(Tu * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
                 taps_t, _ = self.V.forward(xt, keep=False, flags=cx)
+                if self.vggt_dedup:
+                    taps_u, taps_t = taps_t, {}
+                    for key, u in taps_u.items():                       # frame-major [Tu*B,...] -> [T*B,...] in sequence order
+                        full = torch.empty((T * B,) + tuple(u.shape[1:]), device=self.dev, dtype=u.dtype)
+                        K.seq_gather(u.view(1, Tu, -1).view(torch.float32), full.view(T, 1, -1).view(torch.float32), self.seq_idx)
+                        taps_t[key] = full
+                    hold.append(taps_u)
             hold += [xt, taps_t]
         if self.gan:
             sk, cx = part(2)

@@ -221,6 +221,23 @@ def test_engine_program_dry_run_with_mocked_kernels(monkeypatch):
         assert len(counts["1"]) >= len(counts["0"])
         segs = list(eng._done)                                    # (serial run: one flat program)
         assert segs[0] == "head" and segs[-1] == "update"
+    # ping-pong targets repeat: with TG_VGGT_DEDUP=1 the VGG target pass runs on the T0 distinct frames only (3 of 5 here)
+    # and the mirrored frames' features are gathered; everything downstream sees tensors of the same shapes
+    F = tecogan_flags(**small)
+    vol = {}
+    for dd in ("0", "1"):
+        monkeypatch.setenv("TG_VGGT_DEDUP", dd)
+        calls.clear()
+        work.clear()
+        eng = TrainEngine(F, "cpu", gan=True, act_dtype=torch.bfloat16, use_graph=False)
+        assert eng.vggt_dedup == (dd == "1")
+        eng.step(torch.rand(1, F.RNN_N, 16, 16, 3), torch.rand(1, F.RNN_N, 64, 64, 3))
+        vol[dd] = dict(work)
+        vol[dd]["n_seq_gather"] = calls.count("seq_gather")
+    monkeypatch.delenv("TG_VGGT_DEDUP")
+    assert vol["1"]["n_seq_gather"] == vol["0"]["n_seq_gather"] + 4                    # one gather per VGG tap
+    assert vol["1"]["vgg_preprocess_forward"] == vol["0"]["vgg_preprocess_forward"] - 2 * 64 * 64 * 3     # two frames fewer
+    assert vol["1"]["cosine_loss"] == vol["0"]["cosine_loss"] and vol["1"]["conv_forward"] < vol["0"]["conv_forward"]
 
 
 def test_scene_loader_moving_first_frame_augmentation(tmp_path):

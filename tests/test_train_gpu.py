@@ -119,6 +119,20 @@ def test_tecogan_step_fp32_parity():
     assert R["with_D"] is True
 
 
+def test_tecogan_step_with_deduplicated_vgg_target_pass(monkeypatch):
+    """TG_VGGT_DEDUP=1: the VGG features of the ping-pong TARGET frames computed for the RNN_N distinct frames only and
+    gathered into sequence order (the mirrored half repeats them) -- same parity against the oracle as the default path, in
+    the eager program and in the captured one."""
+    monkeypatch.setenv("TG_VGGT_DEDUP", "1")
+    F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=2)
+    for use_graph in (False, True):
+        S, eng, Rs = run_pair(F, gan=True, use_graph=use_graph)
+        assert eng.vggt_dedup
+        check_step(S, eng, Rs[-1], 1e-3)
+        L = eng.losses()
+        assert abs(L["All_loss_Gen"] - float(Rs[-1]["gen_loss"])) < 1e-3 * max(1.0, abs(float(Rs[-1]["gen_loss"])))
+
+
 def test_tecogan_three_steps_graph_and_gate():
     """hipGraph replay of the GAN step for 3 steps; the device-side D-gate follows the oracle's decisions."""
     F = OT.default_flags(batch_size=1, RNN_N=4, crop_size=16, num_resblock=1, Dbalance=1e-9)
