@@ -163,7 +163,7 @@ class TrainEngine:
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
         # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass, 64 the VGG pass
         # of the late frames beside D's generator-side backward pass (before the BPTT)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 239) if self.overlap else 0
         # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Off by
         # default until it has been measured on hardware (prepared in round 3 after the GPU budget was spent).
@@ -478,9 +478,20 @@ class TrainEngine:
             sk, cx = part(4)
             with seg("vgg_early", sk, ["fwd_a", "vggt"]):
                 self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx if early_on_side else 0, zero=True)
-        with seg("fwd_b", "M", ["dreal", "vggt"]):
-            if early_on_side:
-                forward_frames(tc, T)
+        # ---- side: VGG pass of the LATE frames [tc, T) as ONE full-tile piece on the side stream, beside D's generator-side
+        #      backward pass on the main stream (throughput work beside throughput work); the BPTT starts when both are done and
+        #      D's own-gradient passes run beside it.  Measured (same box, profiles/r03e_ab.txt): 12.87 -> 12.68 ms against the
+        #      late pass on the main stream.  Frame-DESCENDING pieces of 1 / 2 / 4 frames beside the BPTT of the frames above
+        #      them were slower (16.3 / 13.8 / 12.85 ms, profiles/r03c_ab.txt: a 2-frame VGG pass takes 0.95 ms beside the chain
+        #      against 0.36 ms pro rata), and so were FNet's backward pass / the generator's weight gradients of the late frames
+        #      beside the BPTT of the early ones (neutral: their launches are latency-bound, two half-batch passes cost twice).
+        late_on_side = self.use_vgg and bool(self.ov_parts & 64) and split and T > tc
+        # bit 128 (prepared for round 4, off by default): the main-stream segment ends with the last recurrent frame, so the
+        # late VGG pass starts beside the loss / D-fake-pass work (segment "fwd_c") instead of after it -- the main stream
+        # idles ~1.1 ms waiting for that pass (profiles/r03w_seg_timeline.txt)
+        late_first = late_on_side and early_on_side and bool(self.ov_parts & 128)
+
+        def losses_and_fake_pass():
             # ---- generator losses seeded into d_gen -------------------------------------------------------
             nhr = float(T * B * H * H)
             K.sum_sq_diff(gen, hr_seq, 1.0 / nhr, self.loss[LI["l2_content_loss"]:LI["l2_content_loss"] + 1])
@@ -492,23 +503,30 @@ class TrainEngine:
                                                     gd["merge"])
                 gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
                 self._gan_losses(gd)
-        hold.append(d_gen)
-        # ---- side: VGG pass of the LATE frames [tc, T) as ONE full-tile piece on the side stream, beside D's generator-side
-        #      backward pass on the main stream (throughput work beside throughput work); the BPTT starts when both are done and
-        #      D's own-gradient passes run beside it.  Measured (same box, profiles/r03e_ab.txt): 12.87 -> 12.68 ms against the
-        #      late pass on the main stream.  Frame-DESCENDING pieces of 1 / 2 / 4 frames beside the BPTT of the frames above
-        #      them were slower (16.3 / 13.8 / 12.85 ms, profiles/r03c_ab.txt: a 2-frame VGG pass takes 0.95 ms beside the chain
-        #      against 0.36 ms pro rata), and so were FNet's backward pass / the generator's weight gradients of the late frames
-        #      beside the BPTT of the early ones (neutral: their launches are latency-bound, two half-batch passes cost twice).
-        late_on_side = self.use_vgg and bool(self.ov_parts & 64) and split and T > tc
-        if late_on_side:
+            return d_gen
+
+        def late_vgg_pass():
             if self._d_vgg_late is None:
                 self._d_vgg_late = torch.empty(T - tc, B, H, H, 3, device=self.dev)
             with seg("vgg_late", "S", ["fwd_b"]):
                 self._vgg_chunk(gen, taps_t, tc, T, _Shifted(self._d_vgg_late, tc), 0, zero=True)
+
+        with seg("fwd_b", "M", ["dreal", "vggt"]):
+            if early_on_side:
+                forward_frames(tc, T)
+            if not late_first:
+                d_gen = losses_and_fake_pass()
+        if late_first:
+            late_vgg_pass()
+            with seg("fwd_c", "M", ["dreal"]):
+                d_gen = losses_and_fake_pass()
+        elif late_on_side:
+            late_vgg_pass()
+        hold.append(d_gen)
+        fwd_last = "fwd_c" if late_first else "fwd_b"            # the segment D's passes and the losses are complete in
         if self.gan:
             sk, cx = part(8)
-            with seg("down", sk, ["fwd_b"]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
+            with seg("down", sk, [fwd_last]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
                 self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
                 self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass

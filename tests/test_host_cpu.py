@@ -318,6 +318,26 @@ def test_plan_launch_order_just_in_time_side_segments():
     assert order[:2] == ["head", "fwd_a"]                     # the forward recurrence is queued before the first wait
 
 
+def test_plan_launch_order_with_the_late_vgg_pass_started_before_the_loss_segment():
+    """TG_OVERLAP_PARTS bit 128 (prepared for round 4): `fwd_b` ends with the last recurrent frame, `vgg_late` depends on it,
+    the losses / D fake pass are their own main-stream segment `fwd_c`.  The plan must enqueue `fwd_c` BEFORE the host waits
+    for `fwd_b` (so the main stream never drains) and launch `vgg_late` right after that wait."""
+    from tecogan_amd.engine import plan_launch_order
+    segs = [(n, k, list(d)) for n, k, d in TECO_SEGS]
+    i = [n for n, _, _ in segs].index("vgg_late")
+    segs.insert(i + 1, ("fwd_c", "M", ["dreal"]))
+    segs = [(n, k, (["fwd_c"] if n == "down" else d)) for n, k, d in segs]
+    acts = list(plan_launch_order(_segs(segs), lazy=True))
+    order = [a[1]["name"] if a[0] == "launch" else ("wait", tuple(a[1])) for a in acts]
+    names = [o for o in order if isinstance(o, str)]
+    assert sorted(names) == sorted(n for n, _, _ in segs)
+    pos = {n: names.index(n) for n in names}
+    for n, k, deps in segs:
+        assert all(pos[d] < pos[n] for d in deps), n
+    w = order.index(("wait", ("fwd_b",)))
+    assert order[w + 1] == "vgg_late" and order.index("fwd_c") < w
+
+
 def test_plan_launch_order_program_order_when_not_lazy():
     from tecogan_amd.engine import plan_launch_order
     acts = list(plan_launch_order(_segs(TECO_SEGS), lazy=False))
