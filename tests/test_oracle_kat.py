@@ -227,3 +227,31 @@ def test_tf_adam_numpy_reference_three_steps():
                 vn[i] = 0.999 * vn[i] + 0.001 * grad[i] * grad[i]
                 pn[i] -= lr_t * mn[i] / (math.sqrt(vn[i]) + 1e-8)
         assert torch.allclose(p, torch.tensor(pn, dtype=torch.float64), rtol=1e-12, atol=0)
+
+
+def test_transposed_conv_equals_a_stride1_conv_into_four_phases():
+    """Groundwork for a latency-regime transposed-conv kernel (DESIGN section 8, round-4 lever "HR nodes"): the generator's
+    k3 s2 SAME transposed conv (lib/ops.py:35-44) equals ONE stride-1 3x3 SAME convolution of the INPUT into 4*Cout channels
+    -- channel block (py, px) holds output phase out[2y+py, 2x+px] -- followed by depth-to-space, with the repacked weights
+        Wc[dy+1, dx+1, ci, (py, px, co)] = W[ky(py, dy), kx(px, dx), co, ci],   ky(0, 0) = 0, ky(0, -1) = 2, ky(1, 0) = 1
+    and zero elsewhere (only the four taps dy, dx in {-1, 0} are used).  So the recurrent chain's conv kernel can serve the two
+    transposed convs of every frame with a phase-aware store, instead of the generic implicit-GEMM kernel."""
+    from oracle import ops as O
+    g = torch.Generator().manual_seed(3)
+    N, H, W, Ci, Co = 2, 5, 7, 6, 4
+    x = torch.randn(N, H, W, Ci, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 3, Co, Ci, generator=g, dtype=torch.float64)                  # TF layout [kh, kw, Cout, Cin]
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    want = O.conv2_tran(x, w, b)                                                    # [N, 2H, 2W, Co]
+    k_of = {(0, 0): 0, (0, -1): 2, (1, 0): 1}                                       # (phase, input offset) -> kernel index
+    wc = torch.zeros(3, 3, Ci, 4 * Co, dtype=torch.float64)                         # HWIO of the stride-1 conv
+    for py in (0, 1):
+        for px in (0, 1):
+            for dy in (-1, 0):
+                for dx in (-1, 0):
+                    if (py, dy) in k_of and (px, dx) in k_of:
+                        blk = (py * 2 + px) * Co
+                        wc[dy + 1, dx + 1, :, blk:blk + Co] = w[k_of[(py, dy)], k_of[(px, dx)]].t()
+    y4 = O.conv2(x, wc, b.repeat(4))                                                # [N, H, W, (py, px, co)]
+    got = y4.view(N, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, Co)
+    assert (got - want).abs().max().item() < 1e-12
