@@ -198,9 +198,25 @@ int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void*
  * output conv 64 -> 3, bicubic_four(LR) skip, value ranges -- the 64-channel HR tensor stays on chip (csrc/hr_tail.hip).
  * t1 [N,h2,w2,64] bf16 (output of the first transposed conv), w_tran [9][64][64] in TF's [kh,kw,Cout,Cin] layout,
  * w_out [9][3][64]; gen_in as in tg_bicubic_add_preprocess; out / state as there (either may be NULL, not both).
- * Round 2: written after the round's GPU budget was spent -- NOT yet validated on hardware; nothing calls it by default. */
+ * Validated on hardware in round 3 (tests/test_kernels_gpu.py::test_hr_tail_*) and the default of the stateless generator
+ * forward for bf16 tensors (TG_HR_TAIL=0 selects the three-kernel path). */
 int tg_hr_tail_forward(const void* t1, const void* w_tran, const float* b_tran, const void* w_out, const float* b_out,
                        const void* gen_in, int Cpad, float* out, float* state, int N, int h2, int w2, void* stream);
+
+/* One residual block of generator_F (reference lib/frvsr.py:50-57: conv3x3 - ReLU - conv3x3 + skip) or the input-gradient
+ * chain of the same block (tf.gradients, lib/Teco.py:441-449) as ONE launch -- the latency regime of the training recurrence
+ * (csrc/resblock_lat.hip; bf16, C = 64; anything else: TG_EINVAL, run the block as two tg_conv_forward launches).  Every
+ * tensor is [N,H,W,64]; w1 / w2 are [9][64][64] = [tap][out][in] of the FIRST / SECOND convolution applied.
+ *   mode 0 (forward):        mid = relu(conv(x, w1) + b1)        out = x + conv(mid, w2) + b2
+ *                            x = block input, w1 / w2 = the W^T copies of conv_1 / conv_2
+ *   mode 1 (input gradient): mid = convT(x, w1) * (aux1 > 0)     out = (x + convT(mid, w2)) [* (aux2 > 0)]
+ *                            x = d(block output), w1 / w2 = conv_2's / conv_1's HWIO weights (taps are mirrored inside),
+ *                            aux1 = the saved relu(conv_1) output, aux2 (nullable) = the ReLU output that fed the block,
+ *                            mid = d(conv_1 pre-activation) -- what conv_1's weight gradient needs; b1 = b2 = NULL
+ * mid may be NULL (stateless forward).  Results are bit-identical to the two-launch path. */
+int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                const void* aux1, const void* aux2, void* mid, void* out, int N, int H, int W, int C, int dtype,
+                void* stream);
 
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.

@@ -166,12 +166,20 @@ def bicubic_add_preprocess(conv_out, gen_in, out, state=None):
 
 def hr_tail_forward(t1, w_tran, b_tran, w_out, b_out, gen_in, out, state=None):
     """Fused second transposed conv + ReLU + output conv + bicubic skip + value ranges (csrc/hr_tail.hip; bf16 only).
-    t1 [N,h2,w2,64]; out / state fp32 [N,2 h2,2 w2,3] (either may be None).  Not yet validated on hardware (round 2)."""
+    t1 [N,h2,w2,64]; out / state fp32 [N,2 h2,2 w2,3] (either may be None)."""
     N, h2, w2, C = t1.shape
     assert C == 64 and t1.dtype == torch.bfloat16 and gen_in.dtype == torch.bfloat16
     check(lib().tg_hr_tail_forward(_p(t1), _p(w_tran), _p(b_tran), _p(w_out), _p(b_out), _p(gen_in), gen_in.shape[-1], _p(out),
                                    _p(state), N, h2, w2, _stream()), "tg_hr_tail_forward")
     return out if out is not None else state
+
+
+def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out):
+    """One residual block (mode 0) / its input-gradient chain (mode 1) as one launch (csrc/resblock_lat.hip; bf16, C = 64)."""
+    N, H, W, Cn = x.shape
+    check(lib().tg_resblock(mode, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(aux1), _p(aux2), _p(mid), _p(out), N, H, W, Cn,
+                            dt(x), _stream()), "tg_resblock")
+    return out
 
 
 def act_backward(d_out, y, d_in, act=0, alpha=0.0, scale=1.0):

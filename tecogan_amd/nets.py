@@ -145,6 +145,10 @@ class Generator:
         # fused HR tail of the stateless (inference) forward (csrc/hr_tail.hip); TG_HR_TAIL=0 is the A/B switch
         # (1080p frame 1.103 -> 1.068 ms, profiles/r03a_ab.txt)
         self.hr_tail = os.environ.get("TG_HR_TAIL", "1") == "1"
+        # one launch per residual block in the training recurrence (csrc/resblock_lat.hip: bf16 frames in the latency regime);
+        # TG_RESBLOCK_LAT=0 is the A/B switch (two tg_conv_forward launches per block, bit-identical results)
+        self.resblock_lat = os.environ.get("TG_RESBLOCK_LAT", "1") == "1"
+        self.resblock_max_tiles = int(os.environ.get("TG_RESBLOCK_LAT_MAX_TILES", "1024"))
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -205,6 +209,13 @@ class Generator:
         self.seq = q
         return q
 
+    def _fused_blocks(self):
+        """True when the recurrence runs its residual blocks as one launch each: bf16 frames whose 4x4-pixel tiles are few
+        enough for one workgroup per tile to be the LATENCY-optimal shape (the training crops; not the 1080p stream)."""
+        q = self.seq
+        tiles = q["B"] * ((q["h"] + 3) // 4) * ((q["w"] + 3) // 4)
+        return self.resblock_lat and self.ps.act_dtype == torch.bfloat16 and tiles <= self.resblock_max_tiles
+
     def forward_t(self, t, out):
         """Frame t: reads seq['x_in'][t] (filled by the warp kernel), writes the HR frame into `out`."""
         ps, p, q = self.ps, self.P, self.seq
@@ -212,8 +223,14 @@ class Generator:
         cf = self.chain_flags
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
                      out=q["a"][0][t], flags=cf)
+        fused = self._fused_blocks()
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
+            if fused:
+                a = K.resblock(0, a, ps.packed(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
+                               ps.packed(s + "conv_2/Conv/weights", True), ps.view(s + "conv_2/Conv/biases"), None, None,
+                               q["r"][i][t], q["a"][i][t])
+                continue
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t], flags=cf)
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
                          out=q["a"][i][t], flags=cf)
@@ -237,8 +254,16 @@ class Generator:
         g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t], flags=cf)
         if n == 0:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
+        fused = self._fused_blocks()
         for i in range(n, 0, -1):
             sc = p + "resblock_%d/" % i
+            if fused:
+                # d r = bwd(conv_2)(g) * relu'(r) -> g_c1 (conv_1's weight gradient reads it); d a_{i-1} = bwd(conv_1)(d r) + g
+                g = K.resblock(1, g, ps.packed(sc + "conv_2/Conv/weights", False), None,
+                               ps.packed(sc + "conv_1/Conv/weights", False), None, q["r"][i][t],
+                               q["a"][0][t] if i == 1 else None, q["g_c1"][i][t],
+                               q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t])
+                continue
             dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
                                out=q["g_c1"][i][t], flags=cf)
             # d a_{i-1} = bwd(conv_1)(dr) + skip gradient; block 1's input is itself a ReLU output (masked here)

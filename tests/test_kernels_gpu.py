@@ -1160,3 +1160,92 @@ def test_wgrad_multi_geometry_grouped_launch_matches_autograd():
     for i, (gw, gb) in enumerate(refs):
         close(dws[i] - 0.5, gw, 3e-4, "multi-geometry dW layer %d %s" % (i, cases[i]))
         close(dbs[i], gb, 3e-4, "multi-geometry dbias layer %d %s" % (i, cases[i]))
+
+
+# ---- csrc/resblock_lat.hip: one launch per residual block of the training recurrence ------------------------------------------
+RB_SHAPES = [(4, 32, 32), (2, 8, 8), (1, 5, 7), (3, 6, 6), (1, 13, 9), (1, 4, 4), (2, 3, 2)]
+
+
+def _rb_setup(shape, seed=0):
+    N, H, W = shape
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    x = bf(rnd(N, H, W, 64, seed=seed + 1))
+    w1, w2 = bf(rnd(3, 3, 64, 64, seed=seed + 2, scale=0.1)), bf(rnd(3, 3, 64, 64, seed=seed + 3, scale=0.1))
+    b1, b2 = rnd(64, seed=seed + 4, scale=0.3), rnd(64, seed=seed + 5, scale=0.3)
+    return x, w1, w2, b1, b2
+
+
+def _dev_bf(t):
+    return t.to(DEV, torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("shape", RB_SHAPES)
+def test_resblock_one_launch_forward_is_bit_identical_to_two_launches_and_matches_oracle(shape):
+    """lib/frvsr.py:50-57: out = x + conv_2(relu(conv_1(x))).  One launch (tg_resblock) against (a) the two tg_conv_forward
+    launches it replaces -- bit for bit, intermediate included -- and (b) the oracle on the bf16-rounded operands."""
+    N, H, W = shape
+    x, w1, w2, b1, b2 = _rb_setup(shape)
+    wt = lambda w: w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16)      # noqa: E731
+    xd, w1t, w2t, b1d, b2d = _dev_bf(x), wt(w1), wt(w2), b1.to(DEV), b2.to(DEV)
+    d1 = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_RELU)
+    d2 = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_NONE)
+    r_ref, a_ref = torch.empty_like(xd), torch.empty_like(xd)
+    K.conv_forward(d1, xd, w1t, b1d, None, None, r_ref)
+    K.conv_forward(d2, r_ref, w2t, b2d, xd, None, a_ref)
+    r, a = torch.full_like(xd, 7.0), torch.full_like(xd, 7.0)
+    K.resblock(0, xd, w1t, b1d, w2t, b2d, None, None, r, a)
+    torch.cuda.synchronize()
+    assert torch.equal(r.view(torch.int16), r_ref.view(torch.int16)), "intermediate differs from the two-launch path"
+    assert torch.equal(a.view(torch.int16), a_ref.view(torch.int16)), "block output differs from the two-launch path"
+    a2 = torch.full_like(xd, 7.0)
+    K.resblock(0, xd, w1t, b1d, w2t, b2d, None, None, None, a2)               # stateless form: no intermediate written
+    assert torch.equal(a2.view(torch.int16), a_ref.view(torch.int16))
+    r_o = torch.relu(O.conv2(x, w1, b1, 1)).bfloat16().float()
+    a_o = x + O.conv2(r_o, w2, b2, 1)
+    close(r, r_o, 1e-2, "resblock intermediate %s" % (shape,))
+    close(a, a_o, 1e-2, "resblock output %s" % (shape,))
+
+
+@pytest.mark.parametrize("mask2", [False, True])
+@pytest.mark.parametrize("shape", RB_SHAPES)
+def test_resblock_one_launch_input_gradient_is_bit_identical_to_two_launches_and_matches_autograd(shape, mask2):
+    """tf.gradients through the block (lib/Teco.py:441-449): d r = bwd(conv_2)(g) * relu'(r), d x = (g + bwd(conv_1)(d r))
+    [* relu'(a0) for the first block, whose input is the input stage's ReLU output]."""
+    N, H, W = shape
+    x, w1, w2, b1, b2 = _rb_setup(shape, seed=10)
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    g = bf(rnd(N, H, W, 64, seed=20))
+    r_saved = bf(torch.relu(O.conv2(x, w1, b1, 1)))
+    a0 = bf(rnd(N, H, W, 64, seed=21))
+    wn = lambda w: w.reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16)   # HWIO as stored = [tap][in][out]      # noqa: E731
+    gd, rd, a0d, w1n, w2n = _dev_bf(g), _dev_bf(r_saved), _dev_bf(a0), wn(w1), wn(w2)
+    aux2 = a0d if mask2 else None
+    dA = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 1, TG_BF16, TG_BF16, 0, 0.0, ACT_RELU, 0.0)
+    dB = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 1, TG_BF16, TG_BF16, 0, 0.0, ACT_RELU if mask2 else ACT_NONE, 0.0)
+    dr_ref, dx_ref = torch.empty_like(gd), torch.empty_like(gd)
+    K.conv_forward(dA, gd, w2n, None, None, rd, dr_ref)
+    K.conv_forward(dB, dr_ref, w1n, None, gd, aux2, dx_ref)
+    dr, dx = torch.full_like(gd, 7.0), torch.full_like(gd, 7.0)
+    K.resblock(1, gd, w2n, None, w1n, None, rd, aux2, dr, dx)
+    torch.cuda.synchronize()
+    assert torch.equal(dr.view(torch.int16), dr_ref.view(torch.int16)), "d r differs from the two-launch path"
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), "d x differs from the two-launch path"
+    # autograd on the bf16-rounded operands (the intermediate gradient rounded to bf16 where the kernels round it)
+    rr = r_saved.clone().requires_grad_()
+    O.conv2(rr, w2, None, 1).backward(g)
+    dr_o = bf(rr.grad * (r_saved > 0).float())
+    xx = torch.zeros(N, H, W, 64, requires_grad=True)
+    O.conv2(xx, w1, None, 1).backward(dr_o)
+    dx_o = g + xx.grad
+    if mask2:
+        dx_o = dx_o * (a0 > 0).float()
+    close(dr, dr_o, 1e-2, "resblock d r %s" % (shape,))
+    close(dx, dx_o, 1e-2, "resblock d x %s" % (shape,))
+
+
+def test_resblock_rejects_what_it_does_not_cover():
+    from tecogan_amd._lib import TecoHipError
+    x = torch.zeros(1, 4, 4, 64, device=DEV)
+    w = torch.zeros(9, 64, 64, device=DEV)
+    with pytest.raises(TecoHipError):
+        K.resblock(0, x, w, None, w, None, None, None, None, torch.empty_like(x))          # fp32: two launches, not this kernel

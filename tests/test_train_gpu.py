@@ -107,6 +107,28 @@ def test_frvsr_step_bf16_error_is_bounded():
     assert abs(L["l2_content_loss"] - float(dict(zip(Rs[-1]["names"], Rs[-1]["vals"]))["l2_content_loss"])) < 2e-2
 
 
+def test_bf16_recurrence_with_one_launch_residual_blocks_equals_the_two_launch_recurrence():
+    """csrc/resblock_lat.hip inside the training step (bf16 mode, configs[1]-shaped crops): the HR frames of all recurrent
+    frames are BIT-identical to the step that runs every residual block as two tg_conv_forward launches, and the gradients
+    agree to the noise of their fp32 atomics (their operands are bit-identical)."""
+    from tecogan_amd.params import damp_values
+    F = OT.frvsr_flags(batch_size=2, RNN_N=4, crop_size=32, num_resblock=3)
+    x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
+    res = []
+    for fused in (True, False):
+        eng = TrainEngine(F, DEV, gan=False, act_dtype=torch.bfloat16, seed=7, use_graph=False)
+        eng.ps.load(damp_values(eng.ps.state_dict()))
+        eng.G.resblock_lat = fused
+        eng.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        assert eng.G._fused_blocks() is fused
+        res.append((eng.gen.clone(), eng.ps.grad.clone(), eng.G.seq["g_in"].clone()))
+    (ga, gra, gia), (gb, grb, gib) = res
+    assert torch.equal(ga, gb), "HR frames differ between the one-launch and the two-launch recurrence"
+    assert torch.equal(gia.view(torch.int16), gib.view(torch.int16)) or rel_err(gia, gib) < 2e-2   # scatter atomics feed the BPTT
+    assert rel_err(gra, grb) < 2e-2
+
+
 def test_tecogan_step_fp32_parity():
     """Full TecoGAN step (ping-pong, VGG, spatio-temporal D, layer loss, 3 Adams, D-gate) vs the oracle."""
     F = OT.default_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=2)

@@ -1,0 +1,54 @@
+"""Cycle-stamp trace of one resblock_lat workgroup (profiling tool; private -DTG_RB_TRACE build of the library).
+    python tools/trace_rb.py --build   (here, cross-compiles)      python tools/trace_rb.py   (on the GPU)"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tecogan_amd import build as B  # noqa: E402
+
+so = os.path.join(ROOT, "tools", "_trace", "libtecogan_trace_rb.so")
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    csrc = os.path.join(ROOT, "tecogan_amd", "csrc")
+    obj = os.path.join(os.path.dirname(so), "resblock_lat_trace.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + ["-DTG_RB_TRACE", "-c", os.path.join(csrc, "resblock_lat.hip"), "-o", obj])
+    others = [os.path.join(csrc, s.replace(".hip", ".o")) for s in B.SOURCES if s != "resblock_lat.hip"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
+    print("built", so)
+    sys.exit(0)
+import tecogan_amd._lib as L  # noqa: E402
+
+L.LIB_PATH = so
+import torch  # noqa: E402
+
+from tecogan_amd import kernels as K  # noqa: E402
+
+lib = C.CDLL(so)
+lib.tg_debug_rb_trace.argtypes = [C.POINTER(C.c_ulonglong)]
+NAMES = ["entry", "all loads issued", "input region landed, LDS written", "barrier 1 passed", "level-1 MFMAs issued",
+         "level-1 epilogue issued", "barrier 2 passed", "level-2 MFMAs issued", "stores issued", "stores retired (vmcnt 0)"]
+N, H, W = 4, 32, 32
+x = torch.randn(N, H, W, 64, device="cuda").bfloat16()
+ws = [(torch.randn(9, 64, 64, device="cuda") * 0.03).bfloat16() for _ in range(8)]
+b = torch.zeros(64, device="cuda")
+aux = torch.randn(N, H, W, 64, device="cuda").bfloat16()
+mid, out = torch.empty_like(x), torch.empty_like(x)
+for mode, label in ((0, "forward"), (1, "input gradient")):
+    for rep in range(6):                                      # different weights per launch: cold weights, as in the chain
+        if mode == 0:
+            K.resblock(0, x, ws[rep % 8], b, ws[(rep + 1) % 8], b, None, None, mid, out)
+        else:
+            K.resblock(1, x, ws[rep % 8], None, ws[(rep + 1) % 8], None, aux, None, mid, out)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 64)()
+    assert lib.tg_debug_rb_trace(buf) == 0
+    t = list(buf)
+    print("== resblock_lat %s [%d,%d,%d,64]: clock64 stamps of the middle workgroup (100 MHz ticks if the counter is the wall clock)"
+          % (label, N, H, W))
+    for wv in range(4):
+        row = t[wv * 16:wv * 16 + 10]
+        print("  wave %d: " % wv + "  ".join("%s +%d" % (NAMES[i][:22], row[i] - row[i - 1]) for i in range(1, 10)) +
+              "  | total %d" % (row[9] - row[0]))
