@@ -59,7 +59,32 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=130.0, help="upper bound for the CPU-oracle baseline leg")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="plumbing test of the N>1 launch (no GPU needed): every rank joins a gloo group, rank 0 prints the rank count")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks HERE -- re-run this command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one process per GPU, rendezvous on 127.0.0.1, a free
+    port) and hand its exit code on.  The driver's own form (torch.distributed.run around bench.py) sets WORLD_SIZE and never
+    gets here."""
+    import socket
+    import subprocess
+    if not a.spawn_check and os.environ.get("TG_DIST_BACKEND", "nccl") == "nccl":
+        ndev = torch.cuda.device_count()
+        if ndev < a.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (TG_DIST_BACKEND=gloo runs the ranks on one GPU: plumbing test)"
+                             % (a.gpus, ndev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting the ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def make_flags(config):
@@ -441,11 +466,27 @@ def cpu_baseline(config, budget_s):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if a.spawn_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     ndev = torch.cuda.device_count()
     if world > 1 and local >= ndev and os.environ.get("TG_DIST_BACKEND", "nccl") != "nccl":
         local = local % ndev                                     # plumbing test: several ranks share one GPU

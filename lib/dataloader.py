@@ -130,7 +130,7 @@ class SceneSequences(_Prefetched):
     decoding and augmentation run in a background thread that keeps `prefetch` batches ahead (the reference uses
     FLAGS.queue_thread TF queue runners), so a training step of a few milliseconds is not input-bound."""
 
-    def __init__(self, FLAGS, device, first_dir, last_dir, seed=1, prefetch=2):
+    def __init__(self, FLAGS, device, first_dir, last_dir, seed=1, prefetch=2, cache_share=1.0):
         if FLAGS.input_video_dir == '':
             raise ValueError('Video input directory input_video_dir is not provided')
         if not os.path.exists(FLAGS.input_video_dir):
@@ -155,13 +155,19 @@ class SceneSequences(_Prefetched):
         self._pool, self._sizes = None, {}
         # decoded-frame cache (uint8): a 352x288 PNG costs ~20 ms of one core to inflate and a TecoGAN step consumes 40 of them
         # every ~12 ms, i.e. ~60 cores of pure decoding; scenes are revisited every epoch, so decoded frames are kept up to
-        # TG_LOADER_CACHE_GB (default 1/4 of the host RAM; 0 switches the cache off).  First-epoch batches are decode-bound.
+        # TG_LOADER_CACHE_GB (0 switches the cache off).  Default: 1/4 of the host RAM divided by the ranks of this node
+        # (every rank builds its own loaders: 8 ranks x RAM/4 would be twice the machine), of which a validation loader
+        # (cache_share < 1) takes its share -- the budgets of all loaders of a node add up to RAM/4.  First-epoch batches are
+        # decode-bound.
         try:
             ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
         except (ValueError, OSError):
             ram = 16 << 30
-        self._cache, self._cache_bytes = {}, 0
-        self._cache_cap = int(float(os.environ.get("TG_LOADER_CACHE_GB", str(ram / 4 / (1 << 30)))) * (1 << 30))
+        import threading
+        self._cache, self._cache_bytes, self._cache_lock = {}, 0, threading.Lock()
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+        self._cache_cap = int(float(os.environ.get("TG_LOADER_CACHE_GB", str(ram / 4 / ranks / (1 << 30)))) * (1 << 30)
+                              * cache_share)
         self.cache_hits = self.cache_misses = 0
         if nthr > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -178,9 +184,10 @@ class SceneSequences(_Prefetched):
             with Image.open(p) as im:
                 a = np.asarray(im.convert("RGB"))
             self.cache_misses += 1
-            if self._cache_bytes + a.nbytes <= self._cache_cap:     # (racing threads may both insert: same content, harmless)
-                self._cache[p] = a
-                self._cache_bytes += a.nbytes
+            with self._cache_lock:                                  # the byte count is shared by the pool's threads
+                if p not in self._cache and self._cache_bytes + a.nbytes <= self._cache_cap:
+                    self._cache[p] = a
+                    self._cache_bytes += a.nbytes
             return a
         if self._pool is None or len(paths) < 2 or all(p in self._cache for p in paths):
             return [dec(p) for p in paths]              # (all cached: no pool round trip, the fewer Python-level thread switches the better)
@@ -274,9 +281,11 @@ def frvsr_gpu_data_loader(FLAGS, useValData_ph=None, device="cuda", synthetic=Fa
     if synthetic or FLAGS.input_video_dir == '':
         train = val = SyntheticSequences(FLAGS, device, seed=1234 + rank)
     else:
-        train = SceneSequences(FLAGS, device, FLAGS.str_dir, FLAGS.end_dir, FLAGS.rand_seed + 1000 * rank)
+        # the validation loader is read once every summary_freq steps: 1/16 of the node's cache budget, the rest for training
+        train = SceneSequences(FLAGS, device, FLAGS.str_dir, FLAGS.end_dir, FLAGS.rand_seed + 1000 * rank, cache_share=15.0 / 16)
         try:
-            val = SceneSequences(FLAGS, device, FLAGS.end_dir + 1, FLAGS.end_dir_val, FLAGS.rand_seed + 1 + 1000 * rank)
+            val = SceneSequences(FLAGS, device, FLAGS.end_dir + 1, FLAGS.end_dir_val, FLAGS.rand_seed + 1 + 1000 * rank,
+                                 cache_share=1.0 / 16)
         except ValueError:
             val = train
     x, y = train.next_batch()

@@ -58,8 +58,16 @@ def testWhileTrain(FLAGS, testno=0, lr_dir="./LR/calendar/"):
     the first 10 frames of the calendar clip, written as `<output_dir>/train/<step>_*.png`.  The reference hard-codes the
     clip folder and the interpreter; here the child runs under the same interpreter and is skipped (with a note) when the
     clip folder does not exist.  The child is its own process group so that Ctrl+C in the trainer does not reach it.
-    Returns the Popen object (None when skipped)."""
+    Returns the Popen object (None when skipped).  The previous try-out is reaped first (waited for if it is still
+    running: two children would share the GPU with the captured training step and each other), so no zombies pile up
+    over a long run; TG_TEST_WHILE_TRAIN=0 disables the try-outs (benchmark runs: the child competes for the GPU)."""
     import subprocess
+    prev = getattr(testWhileTrain, "_child", None)
+    if prev is not None:
+        prev.wait()
+        testWhileTrain._child = None
+    if os.environ.get("TG_TEST_WHILE_TRAIN", "1") == "0":
+        return None
     desstr = os.path.join(FLAGS.output_dir, 'train/')
     cmd1 = [sys.executable, os.path.join(ROOT, "main.py"),
             "--output_dir", desstr, "--summary_dir", desstr, "--mode", "inference",
@@ -72,7 +80,8 @@ def testWhileTrain(FLAGS, testno=0, lr_dir="./LR/calendar/"):
         print('[testWhileTrain] %s not found, inference test skipped' % lr_dir)
         return None
     print(' '.join(cmd1))
-    return subprocess.Popen(cmd1, preexec_fn=os.setpgrp)
+    testWhileTrain._child = subprocess.Popen(cmd1, preexec_fn=os.setpgrp)
+    return testWhileTrain._child
 
 
 def restore_training(eng, FLAGS):
@@ -236,7 +245,8 @@ def run_training(FLAGS):
                     print(name, val)
             if rank == 0 and (run_step % FLAGS.summary_freq) == 0:
                 # reference main.py:391-402: the raw loss scalars on a VALIDATION batch (the TensorBoard summaries themselves
-                # are out of scope); an eager pass of the step's program without the update segment
+                # are out of scope); an eager pass of the step's program without the update segment AND without any exchange
+                # segment (TrainEngine._exchange_seg), so rank 0 alone may run it: no collective is issued
                 print('Run and Recording summary!!')
                 vx, vy = rdata.val_loader.next_batch()
                 V = eng.eval_losses(vx, vy)

@@ -64,7 +64,15 @@ def load_variables(path):
         extra["tb_ema"] = float(r.get(TB_EMA_KEY))
     scopes_here = [sc for sc in ("tdiscriminator", "generator", "fnet") if any(k.startswith(sc + "/") for k in keys)]
     steps = {}
-    for scope, pk in power_keys(scopes_here).items():
+    pmap = power_keys(scopes_here)
+    if "tdicriminator_train/beta1_power" in keys:
+        # round-2 layout of this backend: D's accumulators under its own (misspelt, as in the reference) scope, the generator's
+        # and FNet's as beta1_power / beta1_power_1 -- detected FIRST: read with today's mapping the generator's count would
+        # land on D (whose count lags under the gate) and FNet's on the generator
+        pmap = {"tdiscriminator": "tdicriminator_train/beta1_power", "generator": "generator_train/beta1_power",
+                "fnet": "generator_train/beta1_power_1"}
+        pmap = {sc: k for sc, k in pmap.items() if sc in scopes_here}
+    for scope, pk in pmap.items():
         if STEPS_KEY + scope in keys:                      # exact count written by this backend
             steps[scope] = int(r.get(STEPS_KEY + scope))
             continue
@@ -75,10 +83,6 @@ def load_variables(path):
             steps[scope] = max(int(round(math.log(float(r.get(pk2))) / math.log(0.999))) - 1, 0)
         elif pk in keys and 0.0 < float(r.get(pk)) < 1.0:
             steps[scope] = max(int(round(math.log(float(r.get(pk))) / math.log(b1))) - 1, 0)
-    if "tdiscriminator" in scopes_here and "tdicriminator_train/beta1_power" in keys and "tdiscriminator" not in steps:
-        p1 = float(r.get("tdicriminator_train/beta1_power"))          # round-2 layout
-        if 0.0 < p1 < 1.0:
-            steps["tdiscriminator"] = max(int(round(math.log(p1) / math.log(b1))) - 1, 0)
     if steps:
         extra["adam_steps"] = steps
     for key in r.keys():

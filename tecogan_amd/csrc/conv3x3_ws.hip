@@ -478,9 +478,10 @@ int tg_deconv3x3s2_ws_try(const tg_conv_desc* d, const void* in, const void* wei
   p.tiles_y = (p.H + WS_TH - 1) / WS_TH;
   p.tiles_x = (p.W + 15) / 16;
   const int64_t ntiles = (int64_t)p.N * p.tiles_y * p.tiles_x;
-  // selection threshold in input tiles (A/B switch TG_DECONV_WS_MIN_TILES, default 256 = one tile per CU: the training
-  // chain's two transposed convs -- 32 and 128 tiles -- stay on conv_igemm, 10 / 16 us per launch; unmeasured below 256)
-  static const int min_tiles = getenv("TG_DECONV_WS_MIN_TILES") ? atoi(getenv("TG_DECONV_WS_MIN_TILES")) : 256;
+  // selection threshold in input tiles: 256 = one tile per CU.  The training chain's two transposed convs (32 and 128 tiles)
+  // stay on conv_igemm: 5.3 / 9.2 us per launch there against 10.8 / 11.8 us here, TecoGAN step 10.96 -> 11.23 ms with them on
+  // this kernel (round 4, profiles/r04a_ab.txt: a weights-in-registers prologue is not for 32 workgroups)
+  constexpr int min_tiles = 256;
   if (ntiles < min_tiles || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;

@@ -922,10 +922,10 @@ extern "C" int tg_conv_wgrad_multi(const tg_conv_desc* descs, int groups, const 
     bool any_bias = false;
     for (int k = 0; k < ne; ++k) any_bias = any_bias || be[k] != nullptr;
     if (!tg_wgrad_row3_launch_multi(ds, ne, xe, lx, ye, ly, we, any_bias ? be : nullptr, static_cast<hipStream_t>(stream)))
-      for (int g = 0; g < groups; ++g) taken[g] = false;
+      for (int g = 0; g < groups && g < TG_WGRAD_MAX_GROUPS; ++g) taken[g] = false;
     else if (hipGetLastError() != hipSuccess) { tg_set_error("%s: launch failed", __func__); return TG_ELAUNCH; }
   } else {
-    for (int g = 0; g < groups; ++g) taken[g] = false;
+    for (int g = 0; g < groups && g < TG_WGRAD_MAX_GROUPS; ++g) taken[g] = false;     // (groups > the table: `taken` has 40 entries)
   }
   for (int g = 0; g < groups; ++g) {
     if (g < TG_WGRAD_MAX_GROUPS && taken[g]) continue;

@@ -23,6 +23,7 @@
 // matrix work per node; the kernel is NOT for the throughput regime (conv3x3_ws.hip has the 1080p convs).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct RbP {
   const void* x;        // [N,H,W,64] bf16  block input (forward) / gradient w.r.t. the block output (backward)
@@ -50,6 +51,7 @@ constexpr int RB_P = 160;                       // bytes per LDS position (64 bf
 constexpr int RB_XR = 8, RB_XPOS = 8 * 8 + 2;   // input region: 8x8 positions, row pitch 8 (+2: the padding columns of the last row read on)
 constexpr int RB_HR = 12, RB_HPOS = 6 * 12;     // intermediate: 6 rows, row pitch 12
 constexpr unsigned RB_OOB = 0x80000000u;
+constexpr int RB_VAR_DEFAULT = 1;
 }  // namespace
 
 // Cycle stamps (tools/trace_rb.py builds a private -DTG_RB_TRACE copy of the library; the product build has none of it).
@@ -79,10 +81,19 @@ __device__ __forceinline__ void rb_unpack4(const u32x2r& a, float (&f)[4]) {
   f[3] = __uint_as_float(a.y & 0xffff0000u);
 }
 
-template <bool HAS_AUX1, bool HAS_AUX2>
+// VAR (measurement variants; the product launches RB_VAR_DEFAULT):
+//   bit 0  the second conv's weight loads are issued BETWEEN the first conv's MFMA steps instead of up front: the vector-memory
+//          queue of a wave is shallow, so "issue everything first" leaves the wave stalled in load issue (7900 of the node's
+//          12700 cycles, profiles/r04a_ab.txt) while fragments that have landed wait for their MFMAs;
+//   bit 1  weights in FRAGMENT order ([step][wave][lane][16 B]: a wave-load is 1 KiB contiguous = 8 whole lines, instead of 16
+//          half lines of the [tap][out][in] rows);
+//   bit 2  nt cache policy on the weight loads.
+template <bool HAS_AUX1, bool HAS_AUX2, int VAR>
 __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[RB_XPOS * RB_P];
   __shared__ __attribute__((aligned(16))) unsigned char hs[RB_HPOS * RB_P];
+  constexpr bool INTERLEAVE = (VAR & 1) != 0, FRAG = (VAR & 2) != 0;
+  constexpr int WPOL = (VAR & 4) ? 2 : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fg = lane >> 4;
@@ -104,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX2 ? p.aux2 : p.x), 0, (int)p.bytes, 0x00020000);
   const int cbyte = (wave * 16 + fg * 4) * 2;       // byte offset of this lane's four output channels inside a pixel
 
-  // ---- every global load of the kernel is issued here, in consumption order (no branch around any of them: hipcc answers
-  //      a load inside a branch with s_waitcnt vmcnt(0) at the join -- the whole weight stream -- and a null pointer is a
-  //      zero-length buffer that reads zeros / drops stores) --------------------------------------------------------------
+  // ---- global loads, in consumption order (no branch around any of them: hipcc answers a load inside a branch with
+  //      s_waitcnt vmcnt(0) at the join -- the whole weight stream -- and a null pointer is a zero-length buffer that reads
+  //      zeros / drops stores) ---------------------------------------------------------------------------------------------
   const auto rsB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b1), 0, p.b1 ? 256 : 0, 0x00020000);
   const auto rsB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b2), 0, p.b2 ? 256 : 0, 0x00020000);
   const u32x4r bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsB1, (wave * 16 + fg * 4) * 4, 0, 0);
@@ -121,15 +132,16 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
     const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + ch * 16) : RB_OOB), 0, 0);
   }
-  // (2) first conv's weight fragments: lane (frow, fg) of K-step kk holds w[tap][16 wave + frow][32 kk + 8 fg .. +8]
+  // (2) first conv's weight fragments: lane (frow, fg) of step s = (tap, K-half kk) holds w[tap][16 wave + frow][32 kk + 8 fg .. +8]
   u32x4r wA[18], wB[18];
-  const int wlane = ((wave * 16 + frow) * 64 + fg * 8) * 2;
-#pragma unroll
-  for (int s = 0; s < 18; ++s) {
+  const int wlane = FRAG ? wave * 1024 + lane * 16 : ((wave * 16 + frow) * 64 + fg * 8) * 2;
+  auto wload = [&](const auto& rs, int s) {
     const int tap = s >> 1, kk = s & 1;
     const int wtap = p.flip ? 8 - tap : tap;
-    wA[s] = __builtin_amdgcn_raw_buffer_load_b128(rsW1, wlane, wtap * 8192 + kk * 64, 0);
-  }
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, FRAG ? (wtap * 2 + kk) * 4096 : wtap * 8192 + kk * 64, WPOL);
+  };
+#pragma unroll
+  for (int s = 0; s < 18; ++s) wA[s] = wload(rsW1, s);
   // (3) masks: four channels (8 bytes) of the pixel this lane finishes at each level
   u32x2r m1[HAS_AUX1 ? 3 : 1], m2;
   if constexpr (HAS_AUX1) {
@@ -145,12 +157,10 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   const bool out_ok = oy < p.H && ox < p.W;
   const int out_off = ((n * p.H + oy) * p.W + ox) * 128 + cbyte;
   if constexpr (HAS_AUX2) m2 = __builtin_amdgcn_raw_buffer_load_b64(rsA2, (int)(out_ok ? (unsigned)out_off : RB_OOB), 0, 0);
-  // (4) second conv's weight fragments
+  // (4) second conv's weight fragments: up front, or one per MFMA step of level 1 (INTERLEAVE)
+  if constexpr (!INTERLEAVE) {
 #pragma unroll
-  for (int s = 0; s < 18; ++s) {
-    const int tap = s >> 1, kk = s & 1;
-    const int wtap = p.flip ? 8 - tap : tap;
-    wB[s] = __builtin_amdgcn_raw_buffer_load_b128(rsW2, wlane, wtap * 8192 + kk * 64, 0);
+    for (int s = 0; s < 18; ++s) wB[s] = wload(rsW2, s);
   }
   const float bv1[4] = {__uint_as_float(bq1.x), __uint_as_float(bq1.y), __uint_as_float(bq1.z), __uint_as_float(bq1.w)};
   const float bv2[4] = {__uint_as_float(bq2.x), __uint_as_float(bq2.y), __uint_as_float(bq2.z), __uint_as_float(bq2.w)};
@@ -172,20 +182,29 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   f32x4 acc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // software pipeline: the pixel fragments of step s + 1 are requested from LDS before the MFMAs of step s, so a step costs its
+  // MFMAs, not an LDS round trip (the steps are paced by the weight stream anyway: one fragment per ~200 cycles and wave)
+  auto xfrag = [&](int s, int t) {
+    const int tap = s >> 1, kk = s & 1;
+    return *reinterpret_cast<const uint4*>(xb + ((2 * t + tap / 3) * RB_XR + tap % 3) * RB_P + kk * 64);
+  };
+  uint4 bf[3], nbf[3];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap % 3;
+  for (int t = 0; t < 3; ++t) bf[t] = xfrag(0, t);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      uint4 bf[3];
+  for (int s = 0; s < 18; ++s) {
+    if (s < 17) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-        bf[t] = *reinterpret_cast<const uint4*>(xb + ((2 * t + ky) * RB_XR + kx) * RB_P + kk * 64);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wA[tap * 2 + kk]),
-                                                         *reinterpret_cast<bf16x8*>(&bf[t]), acc[t], 0, 0, 0);
+      for (int t = 0; t < 3; ++t) nbf[t] = xfrag(s + 1, t);
     }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wA[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
+                                                       acc[t], 0, 0, 0);
+    if constexpr (INTERLEAVE) wB[s] = wload(rsW2, s);          // a queue slot has just been freed by wA[s]
+    __builtin_amdgcn_sched_barrier(0);                         // (pinned: hoisted to the top these loads stall the issue again)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bf[t] = nbf[t];
   }
   RB_STAMP(4);
   // level-1 epilogue: bias, activation, mask; zero outside the image (= the second conv's SAME padding); bf16 -> LDS;
@@ -286,9 +305,27 @@ extern "C" int tg_resblock(int mode, const void* x, const void* w1, const float*
   const double px = (double)N * H * W;
   const double fl = 2.0 * 2.0 * px * 64.0 * 576.0;
   const double by = px * 128.0 * (2 + (mid != nullptr) + (aux1 != nullptr) + (aux2 != nullptr)) + 2.0 * 73728.0;
-  if (aux1 && aux2) TG_LAUNCH("resblock_lat<bwd,mask2>", fl, by, (resblock_lat_kernel<true, true>), dim3(p.ntiles), dim3(256), 0, st, p);
-  else if (aux1) TG_LAUNCH("resblock_lat<bwd>", fl, by, (resblock_lat_kernel<true, false>), dim3(p.ntiles), dim3(256), 0, st, p);
-  else if (aux2) TG_LAUNCH("resblock_lat<mask2>", fl, by, (resblock_lat_kernel<false, true>), dim3(p.ntiles), dim3(256), 0, st, p);
-  else TG_LAUNCH("resblock_lat<fwd>", fl, by, (resblock_lat_kernel<false, false>), dim3(p.ntiles), dim3(256), 0, st, p);
+#ifdef TG_RB_TRACE
+  const int var = getenv("TG_RB_VAR") ? atoi(getenv("TG_RB_VAR")) : RB_VAR_DEFAULT;      // read per call: the tool sweeps it
+#else
+  const int var = RB_VAR_DEFAULT;
+#endif
+  auto go = [&](auto vtag) {
+    constexpr int V = decltype(vtag)::value;
+    if (aux1 && aux2) TG_LAUNCH("resblock_lat<bwd,mask2>", fl, by, (resblock_lat_kernel<true, true, V>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else if (aux1) TG_LAUNCH("resblock_lat<bwd>", fl, by, (resblock_lat_kernel<true, false, V>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else if (aux2) TG_LAUNCH("resblock_lat<mask2>", fl, by, (resblock_lat_kernel<false, true, V>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else TG_LAUNCH("resblock_lat<fwd>", fl, by, (resblock_lat_kernel<false, false, V>), dim3(p.ntiles), dim3(256), 0, st, p);
+  };
+  switch (var) {
+#ifdef TG_RB_TRACE
+    case 0: go(std::integral_constant<int, 0>{}); break;
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 3: go(std::integral_constant<int, 3>{}); break;
+    case 5: go(std::integral_constant<int, 5>{}); break;
+    case 7: go(std::integral_constant<int, 7>{}); break;
+#endif
+    default: go(std::integral_constant<int, RB_VAR_DEFAULT>{}); break;
+  }
   TG_CHECK_LAUNCH();
 }

@@ -163,7 +163,7 @@ class TrainEngine:
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
         # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass, 64 the VGG pass
         # of the late frames beside D's generator-side backward pass (before the BPTT)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 239) if self.overlap else 0
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
         # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Off by
         # default until it has been measured on hardware (prepared in round 3 after the GPU budget was spent).
@@ -351,7 +351,9 @@ class TrainEngine:
     def _exchange_seg(self, name, scopes, after, with_balance=False):
         """captured mode: all-reduce `scopes` of the flat gradient buffer as a segment of the communication stream,
         ordered after the segments `after`; it overlaps whatever the compute streams do next, `update` joins."""
-        if self.exchange_mode != "captured":
+        if self.exchange_mode != "captured" or self._skip_update:
+            # eval_losses (validation on ONE rank, main.py) must not issue collectives: an all-reduce from rank 0 alone would
+            # pair with the other ranks' next training step and shift every later collective by one
             return
         with self._seg(name, "C", after):
             if with_balance and self.gan:            # every rank must take the same D-gate branch (lib/Teco.py:493-494)
@@ -486,10 +488,8 @@ class TrainEngine:
         #      against 0.36 ms pro rata), and so were FNet's backward pass / the generator's weight gradients of the late frames
         #      beside the BPTT of the early ones (neutral: their launches are latency-bound, two half-batch passes cost twice).
         late_on_side = self.use_vgg and bool(self.ov_parts & 64) and split and T > tc
-        # bit 128 (prepared for round 4, off by default): the main-stream segment ends with the last recurrent frame, so the
-        # late VGG pass starts beside the loss / D-fake-pass work (segment "fwd_c") instead of after it -- the main stream
-        # idles ~1.1 ms waiting for that pass (profiles/r03w_seg_timeline.txt)
-        late_first = late_on_side and early_on_side and bool(self.ov_parts & 128)
+        # (the late VGG pass started already beside the loss / D-fake-pass work -- its own segment `fwd_c`, overlap bit 128 --
+        #  measured neutral in round 4: 10.98 / 10.99 against 11.00 ms, profiles/r04a_ab.txt; removed)
 
         def losses_and_fake_pass():
             # ---- generator losses seeded into d_gen -------------------------------------------------------
@@ -514,16 +514,11 @@ class TrainEngine:
         with seg("fwd_b", "M", ["dreal", "vggt"]):
             if early_on_side:
                 forward_frames(tc, T)
-            if not late_first:
-                d_gen = losses_and_fake_pass()
-        if late_first:
-            late_vgg_pass()
-            with seg("fwd_c", "M", ["dreal"]):
-                d_gen = losses_and_fake_pass()
-        elif late_on_side:
+            d_gen = losses_and_fake_pass()
+        if late_on_side:
             late_vgg_pass()
         hold.append(d_gen)
-        fwd_last = "fwd_c" if late_first else "fwd_b"            # the segment D's passes and the losses are complete in
+        fwd_last = "fwd_b"                                       # the segment D's passes and the losses are complete in
         if self.gan:
             sk, cx = part(8)
             with seg("down", sk, [fwd_last]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT

@@ -204,6 +204,53 @@ def test_bundle_resume_recovers_long_run_adam_counts(tmp_path):
         assert abs(extra2["adam_steps"][sc] - t) <= max(2, int(2e-4 * t)), (sc, extra2["adam_steps"][sc], t)
 
 
+def test_round2_style_bundle_maps_the_adam_counts_to_the_right_optimisers(tmp_path):
+    """a bundle in the round-2 layout (D's accumulators under `tdicriminator_train/`, generator / FNet as
+    beta1_power / beta1_power_1) must not be read with today's mapping, which would hand the generator's count to the
+    (gated, lagging) discriminator."""
+    from collections import OrderedDict
+    from tecogan_amd import params as P, tf_bundle
+    from tecogan_amd.checkpoint import load_variables
+    specs = OrderedDict(generator=P.generator_spec(1), fnet=P.fnet_spec(), tdiscriminator=P.discriminator_spec())
+    ps = P.ParamStore(specs, "cpu")
+    b = OrderedDict((n, ps.view(n).numpy()) for n in ps.entries)
+    want = {"tdiscriminator": 17, "generator": 40, "fnet": 39}
+    b["generator_train/beta1_power"] = np.asarray(0.9 ** (want["generator"] + 1), np.float32)
+    b["generator_train/beta1_power_1"] = np.asarray(0.9 ** (want["fnet"] + 1), np.float32)
+    b["tdicriminator_train/beta1_power"] = np.asarray(0.9 ** (want["tdiscriminator"] + 1), np.float32)
+    b["global_step"] = np.asarray(40, np.int64)
+    prefix = str(tmp_path / "model-40")
+    tf_bundle.write_bundle(prefix, b)
+    _, extra = load_variables(prefix)
+    assert extra["adam_steps"] == want
+
+
+def test_loader_cache_budget_is_shared_by_the_ranks_of_a_node(tmp_path, monkeypatch):
+    """every rank builds a training and a validation loader; their decoded-frame caches together must stay
+    within RAM/4 per NODE (it was RAM/4 per loader: 8 ranks x 2 loaders = 4x the machine)."""
+    from PIL import Image
+    import lib.dataloader as DL
+    from tecogan_amd.flags import tecogan_flags
+    root = tmp_path / "scenes"
+    for sc in (2000, 2001):
+        d = root / ("scene_%04d" % sc)
+        d.mkdir(parents=True)
+        for f in range(12):
+            Image.fromarray(np.zeros((160, 176, 3), np.uint8)).save(str(d / ("col_high_%04d.png" % f)))
+    F = tecogan_flags(input_video_dir=str(root), input_video_pre="scene", str_dir=2000, end_dir=2000, end_dir_val=2001, max_frm=11,
+                      batch_size=1, RNN_N=3, crop_size=32)
+    monkeypatch.delenv("TG_LOADER_CACHE_GB", raising=False)
+    caps = {}
+    for ranks in (1, 8):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
+        tr = DL.SceneSequences(F, "cpu", 2000, 2000, cache_share=15.0 / 16)
+        va = DL.SceneSequences(F, "cpu", 2001, 2001, cache_share=1.0 / 16)
+        caps[ranks] = (tr._cache_cap, va._cache_cap)
+    ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    assert abs(sum(caps[1]) - ram / 4) < 0.01 * ram and abs(8 * sum(caps[8]) - ram / 4) < 0.01 * ram
+    assert caps[8][1] < caps[8][0] / 8
+
+
 def test_data_parallel_ranks_draw_different_batches():
     """Every rank of a data-parallel run must see its own data stream (otherwise the averaged gradient equals a
     single-GPU step): the loader's seed is offset by the rank."""

@@ -318,26 +318,6 @@ def test_plan_launch_order_just_in_time_side_segments():
     assert order[:2] == ["head", "fwd_a"]                     # the forward recurrence is queued before the first wait
 
 
-def test_plan_launch_order_with_the_late_vgg_pass_started_before_the_loss_segment():
-    """TG_OVERLAP_PARTS bit 128 (prepared for round 4): `fwd_b` ends with the last recurrent frame, `vgg_late` depends on it,
-    the losses / D fake pass are their own main-stream segment `fwd_c`.  The plan must enqueue `fwd_c` BEFORE the host waits
-    for `fwd_b` (so the main stream never drains) and launch `vgg_late` right after that wait."""
-    from tecogan_amd.engine import plan_launch_order
-    segs = [(n, k, list(d)) for n, k, d in TECO_SEGS]
-    i = [n for n, _, _ in segs].index("vgg_late")
-    segs.insert(i + 1, ("fwd_c", "M", ["dreal"]))
-    segs = [(n, k, (["fwd_c"] if n == "down" else d)) for n, k, d in segs]
-    acts = list(plan_launch_order(_segs(segs), lazy=True))
-    order = [a[1]["name"] if a[0] == "launch" else ("wait", tuple(a[1])) for a in acts]
-    names = [o for o in order if isinstance(o, str)]
-    assert sorted(names) == sorted(n for n, _, _ in segs)
-    pos = {n: names.index(n) for n in names}
-    for n, k, deps in segs:
-        assert all(pos[d] < pos[n] for d in deps), n
-    w = order.index(("wait", ("fwd_b",)))
-    assert order[w + 1] == "vgg_late" and order.index("fwd_c") < w
-
-
 def test_plan_launch_order_program_order_when_not_lazy():
     from tecogan_amd.engine import plan_launch_order
     acts = list(plan_launch_order(_segs(TECO_SEGS), lazy=False))
@@ -450,6 +430,10 @@ def test_test_while_train_spawns_the_reference_inference_command(tmp_path, monke
     class FakePopen:
         def __init__(self, cmd, preexec_fn=None):
             seen["cmd"], seen["preexec"] = cmd, preexec_fn
+            seen["spawned"] = seen.get("spawned", 0) + 1
+
+        def wait(self):
+            seen["reaped"] = seen.get("reaped", 0) + 1
 
     monkeypatch.setattr(subprocess, "Popen", FakePopen)
     child = M.testWhileTrain(F, 500)
@@ -462,3 +446,27 @@ def test_test_while_train_spawns_the_reference_inference_command(tmp_path, monke
     assert opts["--output_dir"] == opts["--summary_dir"] == os.path.join(str(tmp_path / "out"), "train/")
     assert opts["--input_dir_LR"] == "./LR/calendar/" and opts["--output_pre"] == "" and opts["--output_name"] == "000000500"
     FL.parse(cmd[2:])                                            # the child's command line parses with the same flag table
+    # the previous try-out is reaped before the next one starts (no zombies, no two children on the GPU at once)
+    M.testWhileTrain(F, 1000)
+    assert seen["spawned"] == 2 and seen["reaped"] == 1
+    monkeypatch.setenv("TG_TEST_WHILE_TRAIN", "0")
+    assert M.testWhileTrain(F, 1500) is None and seen["spawned"] == 2 and seen["reaped"] == 2
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with WORLD_SIZE unset (the form the driver uses for N = 1) must start N ranks itself
+    (re-executing under torch.distributed.run, rendezvous on 127.0.0.1) instead of silently running one: the plumbing
+    mode joins a gloo group on the CPU and reports the rank count."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"spawn_check": True, "n_gpus": 2, "ranks": 2}
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    # a rank count that contradicts the launcher's is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "does not match WORLD_SIZE" in (r2.stderr + r2.stdout)

@@ -419,6 +419,54 @@ def test_captured_exchange_segments_carry_nodes_standin_world2():
         assert d <= 1e-3 * w.abs().max().item() + 6.0 * F.learning_rate, (name, d)
 
 
+def test_validation_pass_issues_no_collective_and_leaves_training_state_untouched():
+    """ADVICE r3 (main.py validation on rank 0, reference main.py:391-402): `eval_losses` runs the step's program without the
+    update segment -- and, in the captured multi-rank program, without ANY exchange segment: an all-reduce issued by one rank
+    alone would pair with the other ranks' next training step and shift every later collective by one.  2-rank stand-in
+    program on one GPU; the weights, Adam state and schedule are unchanged by the validation pass and the next training
+    step equals the one of an engine that never validated."""
+    F = OT.default_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=1)
+    x, y = make_batch(1, F.RNN_N, F.crop_size, seed=5)
+    vx, vy = make_batch(1, F.RNN_N, F.crop_size, seed=6)
+    engs = [TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True, standin_world=2) for _ in range(2)]
+    for e in engs:
+        e.step(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    a, b = engs
+    before = [t.clone() for t in (b.ps.flat, b.ps.m, b.ps.v, b.sched, b.hyper)]
+    issued = []
+    orig = b._sum_all_reduce
+    b._sum_all_reduce = lambda t: (issued.append(t.numel()), orig(t))[1]
+    V = b.eval_losses(vx.to(DEV), vy.to(DEV))
+    b._sum_all_reduce = orig
+    assert issued == [] and b.exchange_segments == [], "the validation pass issued %d collectives" % len(issued)
+    assert all(v == v for v in V.values()) and "l2_content_loss" in V
+    for t, c in zip((b.ps.flat, b.ps.m, b.ps.v, b.sched, b.hyper), before):
+        assert torch.equal(t, c)
+    for e in engs:
+        e.step(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(b.ps.flat, a.ps.flat) < 1e-6 and rel_err(b.gen, a.gen) < 1e-6
+    assert int(a.sched[0].item()) == int(b.sched[0].item()) == 2
+
+
+def test_bench_gpus_2_on_one_device_runs_two_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself; TG_DIST_BACKEND=gloo lets
+    them share this box's single GPU (plumbing: eager-split exchange over gloo).  The line must say n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "frvsr", "--steps", "3", "--warmup", "1",
+                        "--no-sub", "--no-roofline", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["global_batch"] == 8
+    assert line["config"]["exchange"].startswith("eager-split") and line["config"]["allreduce_bytes_per_step"] > 0
+
+
 def test_deterministic_parity_mode_is_bit_reproducible():
     """TG_DETERMINISTIC=1 (csrc/common.h): every accumulation with floating-point atomics runs in a fixed order -- reductions as
     one workgroup, weight gradients without split-K, the scatter kernels as one wavefront -- so that three fresh engines produce

@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Where does the bf16 (timed) mode's error against the fp32 (parity) mode come from?  One eager training step of both modes
+from the same damped weights and batch at BASELINE configs[2] (or --config frvsr / small), then a table of relative-L2
+errors of (a) intermediate tensors along the forward and backward pass and (b) every gradient tensor, grouped by network.
+A second fp32 engine gives the fp32-vs-fp32 control (the noise of the fp32 atomics).
+
+    python tools/bf16_error_table.py [--config tecogan|frvsr|small] [--top 12]
+
+Engine attributes (experiments, set by --set name=value ...) select mixed-precision variants under study."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench as B  # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    nb = float(b.norm())
+    return float((a - b).norm()) / nb if nb > 0 else float("nan")
+
+
+def collect(eng):
+    """Named tensors of the last eager step (fp32 copies on the host)."""
+    out = {}
+    q = eng.G.seq
+    T = eng.T
+    hold = eng._hold
+    out["fwd/flow (FNet output)"] = hold[3]
+    out["fwd/gen frame 0"] = eng.gen[0]
+    out["fwd/gen frame %d" % (T // 2)] = eng.gen[T // 2]
+    out["fwd/gen frame %d (last)" % (T - 1)] = eng.gen[T - 1]
+    out["fwd/gen all"] = eng.gen
+    n = eng.G.nres
+    out["fwd/trunk a[%d] last frame" % n] = q["a"][n][T - 1]
+    out["fwd/t2 last frame"] = q["t2"][T - 1]
+    gd = hold[5]
+    if gd is not None:
+        out["fwd/D prob fake"] = gd["p_fake"]
+        out["fwd/D prob real"] = gd["p_real"]
+        for i, t in enumerate(gd["l_fake"]):
+            out["fwd/D layer %d fake" % i] = t
+        out["bwd/D seed d_fake_G"] = gd["d_fake_G"]
+    if eng.use_vgg:
+        out["bwd/d_vgg early frames"] = eng._d_vgg
+        if eng._d_vgg_late is not None:
+            out["bwd/d_vgg late frames"] = eng._d_vgg_late
+    d_gen = [h for h in hold if torch.is_tensor(h) and h.shape == eng.gen.shape and h is not eng.gen]
+    if d_gen:
+        out["bwd/d_gen (after BPTT: loss seeds + recurrent terms)"] = d_gen[-1]
+    out["bwd/g_out last frame"] = q["g_out"][T - 1]
+    out["bwd/g_t2 last frame"] = q["g_t2"][T - 1]
+    out["bwd/g_c2[%d] last frame" % n] = q["g_c2"][n][T - 1]
+    out["bwd/g_in last frame"] = q["g_in"][T - 1]
+    out["bwd/g_in frame 0"] = q["g_in"][0]
+    out["bwd/g_in all frames"] = q["g_in"]
+    out["bwd/d_flow (loss + BPTT)"] = hold[8]
+    return {k: v.detach().float().cpu().clone() for k, v in out.items()}
+
+
+def run(config, dtype, device, sets):
+    eng = B.new_engine(config, dtype, device, use_graph=False)
+    for k, v in sets.items():
+        tgt = eng
+        parts = k.split(".")
+        for p in parts[:-1]:
+            tgt = getattr(tgt, p)
+        setattr(tgt, parts[-1], v)
+    x, y = B.synthetic_batch(eng.F, 1234, device)
+    eng.step(x, y)
+    torch.cuda.synchronize()
+    grads = {name: eng.ps.gview(name).detach().float().cpu().clone() for name in eng.ps.entries}
+    scopes = {name: e["scope"] for name, e in eng.ps.entries.items()}
+    return collect(eng), grads, scopes, eng.losses()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="tecogan", choices=["tecogan", "frvsr", "small"])
+    ap.add_argument("--top", type=int, default=12)
+    ap.add_argument("--set", nargs="*", default=[], help="engine attribute overrides of the bf16 run, e.g. G.resblock_lat=0")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    if a.config == "small":
+        from tecogan_amd import flags as FL
+        small = FL.tecogan_flags(batch_size=2, RNN_N=3, crop_size=16, num_resblock=2)
+        B.make_flags = lambda c: small
+        a.config = "tecogan"
+    sets = {}
+    for kv in a.set:
+        k, v = kv.split("=")
+        sets[k] = (v == "1" or v == "True") if v in ("0", "1", "True", "False") else float(v)
+    tf, gf, scopes, lf = run(a.config, "f32", dev, {})
+    tc, gc, _, _ = run(a.config, "f32", dev, {})
+    tb, gb, _, lb = run(a.config, "bf16", dev, sets)
+    print("== %s, one eager step from damped weights: relative L2 error against the fp32 mode  [bf16 | fp32 control]" % a.config)
+    for k in tf:
+        print("  %-58s %10.3e | %10.3e" % (k, rel(tb[k], tf[k]), rel(tc[k], tf[k])))
+    print("== gradients per optimiser scope")
+    for sc in dict.fromkeys(scopes.values()):
+        names = [n for n in gf if scopes[n] == sc]
+        cat = lambda g: torch.cat([g[n].flatten() for n in names])              # noqa: E731
+        print("  %-16s %10.3e | %10.3e" % (sc, rel(cat(gb), cat(gf)), rel(cat(gc), cat(gf))))
+    print("== worst gradient tensors (bf16 vs fp32)")
+    rows = sorted(((rel(gb[n], gf[n]), rel(gc[n], gf[n]), n) for n in gf if float(gf[n].norm()) > 0), reverse=True)
+    for e, c, n in rows[:a.top]:
+        print("  %10.3e | %10.3e  %s" % (e, c, n))
+    print("== first and last tensors of each network")
+    for sc in dict.fromkeys(scopes.values()):
+        names = [n for n in gf if scopes[n] == sc and n.endswith("weights") or n.endswith("kernel")]
+        names = [n for n in names if scopes[n] == sc]
+        for n in names[:2] + names[-2:]:
+            print("  %10.3e | %10.3e  %s" % (rel(gb[n], gf[n]), rel(gc[n], gf[n]), n))
+    print("== losses bf16:", {k: round(v, 5) for k, v in lb.items() if v})
+    print("== losses fp32:", {k: round(v, 5) for k, v in lf.items() if v})
+
+
+if __name__ == "__main__":
+    main()

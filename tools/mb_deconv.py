@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """The generator's two transposed convs (k3 s2, 64 -> 64, ReLU) at the TRAINING chain's shapes, graph-chained launches:
-which kernel serves them (conv_igemm by default; deconv3x3s2_ws with TG_DECONV_WS_MIN_TILES=1) and what it costs.
-Run once per setting: the threshold is read once per process."""
+which kernel serves them (conv_igemm below 256 input tiles, deconv3x3s2_ws from there on) and what it costs."""
 import os
 import sys
 
@@ -24,5 +23,4 @@ for N, H in ((4, 32), (4, 64), (1, 270)):
     K.prof_collect(); K.prof_enable(True); K.conv_forward(d, x, w, b, None, None, out); torch.cuda.synchronize(); K.prof_enable(False)
     name = K.prof_collect()[0]["name"]
     t = graph_timeit(lambda: K.conv_forward(d, x, w, b, None, None, out), chain=20)
-    print("deconv k3 s2 [%d,%d,%d,64->64] min_tiles=%s  %-24s %7.2f us" % (N, H, W, os.environ.get("TG_DECONV_WS_MIN_TILES", "256"), name, t),
-          flush=True)
+    print("deconv k3 s2 [%d,%d,%d,64->64]  %-24s %7.2f us" % (N, H, W, name, t), flush=True)

@@ -31,24 +31,42 @@ lib.tg_debug_rb_trace.argtypes = [C.POINTER(C.c_ulonglong)]
 NAMES = ["entry", "all loads issued", "input region landed, LDS written", "barrier 1 passed", "level-1 MFMAs issued",
          "level-1 epilogue issued", "barrier 2 passed", "level-2 MFMAs issued", "stores issued", "stores retired (vmcnt 0)"]
 N, H, W = 4, 32, 32
+NB = 16
 x = torch.randn(N, H, W, 64, device="cuda").bfloat16()
-ws = [(torch.randn(9, 64, 64, device="cuda") * 0.03).bfloat16() for _ in range(8)]
+ws = [(torch.randn(9, 64, 64, device="cuda") * 0.03).bfloat16() for _ in range(2 * NB)]
 b = torch.zeros(64, device="cuda")
 aux = torch.randn(N, H, W, 64, device="cuda").bfloat16()
-mid, out = torch.empty_like(x), torch.empty_like(x)
-for mode, label in ((0, "forward"), (1, "input gradient")):
-    for rep in range(6):                                      # different weights per launch: cold weights, as in the chain
-        if mode == 0:
-            K.resblock(0, x, ws[rep % 8], b, ws[(rep + 1) % 8], b, None, None, mid, out)
-        else:
-            K.resblock(1, x, ws[rep % 8], None, ws[(rep + 1) % 8], None, aux, None, mid, out)
-    torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 64)()
-    assert lib.tg_debug_rb_trace(buf) == 0
-    t = list(buf)
-    print("== resblock_lat %s [%d,%d,%d,64]: clock64 stamps of the middle workgroup (100 MHz ticks if the counter is the wall clock)"
-          % (label, N, H, W))
-    for wv in range(4):
-        row = t[wv * 16:wv * 16 + 10]
-        print("  wave %d: " % wv + "  ".join("%s +%d" % (NAMES[i][:22], row[i] - row[i - 1]) for i in range(1, 10)) +
-              "  | total %d" % (row[9] - row[0]))
+mid = torch.empty_like(x)
+act = [torch.randn(N, H, W, 64, device="cuda").bfloat16() for _ in range(NB + 1)]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from microbench import timeit  # noqa: E402
+
+VARS = {0: "all loads up front (round-4 session A)", 1: "second conv's weights issued between the first conv's MFMA steps",
+        3: "... + fragment-order weights (timing only: operands are not in that order)", 5: "... + nt weight loads",
+        7: "... + fragment order + nt"}
+for var, what in VARS.items():
+    os.environ["TG_RB_VAR"] = str(var)
+    print("== variant %d: %s" % (var, what))
+    for mode, label in ((0, "forward"), (1, "input gradient")):
+        def block(i, mode=mode):
+            if mode == 0:
+                K.resblock(0, act[i], ws[2 * i], b, ws[2 * i + 1], b, None, None, mid, act[i + 1])
+            else:
+                K.resblock(1, act[i], ws[2 * i], None, ws[2 * i + 1], None, aux, None, mid, act[i + 1])
+        for i in range(NB):
+            block(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(NB):
+                block(i)
+        us = timeit(g.replay, 30, 5) / NB
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 64)()
+        assert lib.tg_debug_rb_trace(buf) == 0
+        t = list(buf)
+        print("  %-14s %.2f us per block in a %d-block graph chain; stamps (cycles) of the middle workgroup of the last launch:" % (label, us, NB))
+        for wv in (0, 3):
+            row = t[wv * 16:wv * 16 + 10]
+            print("    wave %d: " % wv + "  ".join("%s +%d" % (NAMES[i][:24], row[i] - row[i - 1]) for i in range(1, 10)) +
+                  "  | total %d" % (row[9] - row[0]))
