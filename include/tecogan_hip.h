@@ -213,10 +213,17 @@ int tg_hr_tail_forward(const void* t1, const void* w_tran, const float* b_tran, 
  *                            x = d(block output), w1 / w2 = conv_2's / conv_1's HWIO weights (taps are mirrored inside),
  *                            aux1 = the saved relu(conv_1) output, aux2 (nullable) = the ReLU output that fed the block,
  *                            mid = d(conv_1 pre-activation) -- what conv_1's weight gradient needs; b1 = b2 = NULL
- * mid may be NULL (stateless forward).  Results are bit-identical to the two-launch path. */
+ * mid may be NULL (stateless forward).  Results are bit-identical to the two-launch path.
+ * w_frag != 0: w1 / w2 are the FRAGMENT-order copies written by tg_pack_weights_frag (a wave's weight load is one contiguous
+ * KiB instead of 16 half cache lines: 6.6 -> 4.4 us per block at [4,32,32,64], profiles/r04b_ab.txt). */
 int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                 const void* aux1, const void* aux2, void* mid, void* out, int N, int H, int W, int C, int dtype,
-                void* stream);
+                int w_frag, void* stream);
+/* Fragment-order bf16 copies of `count` 64 -> 64 3x3 weights (the residual-block convs of lib/frvsr.py:50-57) for tg_resblock:
+ * copy[2 tap + kk][wave][lane][j] = W[tap][row = 16 wave + lane % 16][k = 32 kk + 8 (lane / 16) + j]; dst_t: row = output channel
+ * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 2 x int64 per tensor -- offset of the
+ * HWIO fp32 tensor in src_base, offset (elements) of its 36864-element copy in dst_t / dst_n. */
+int tg_pack_weights_frag(const float* src_base, void* dst_t, void* dst_n, const int64_t* tab, int count, void* stream);
 
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.

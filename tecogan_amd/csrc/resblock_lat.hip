@@ -41,6 +41,7 @@ struct RbP {
   int tiles_y, tiles_x, ntiles;
   unsigned bytes;       // extent of every [N,H,W,64] tensor
   int prio;
+  int wfrag;          // weights in fragment order (tg_pack_weights_frag) instead of [tap][out][in] rows
 };
 
 typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
@@ -51,7 +52,7 @@ constexpr int RB_P = 160;                       // bytes per LDS position (64 bf
 constexpr int RB_XR = 8, RB_XPOS = 8 * 8 + 2;   // input region: 8x8 positions, row pitch 8 (+2: the padding columns of the last row read on)
 constexpr int RB_HR = 12, RB_HPOS = 6 * 12;     // intermediate: 6 rows, row pitch 12
 constexpr unsigned RB_OOB = 0x80000000u;
-constexpr int RB_VAR_DEFAULT = 1;
+constexpr int RB_DIST = 10;                     // prefetch distance of the weight stream (fragments), see the kernel
 }  // namespace
 
 // Cycle stamps (tools/trace_rb.py builds a private -DTG_RB_TRACE copy of the library; the product build has none of it).
@@ -68,6 +69,14 @@ extern "C" int tg_debug_rb_trace(unsigned long long* out) {
 #define RB_STAMP(i) do { } while (0)
 #endif
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void rb_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    rb_static_for<I + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ u32x2r rb_pack4(const float (&v)[4]) {
   u32x2r o;
   o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
@@ -81,19 +90,19 @@ __device__ __forceinline__ void rb_unpack4(const u32x2r& a, float (&f)[4]) {
   f[3] = __uint_as_float(a.y & 0xffff0000u);
 }
 
-// VAR (measurement variants; the product launches RB_VAR_DEFAULT):
-//   bit 0  the second conv's weight loads are issued BETWEEN the first conv's MFMA steps instead of up front: the vector-memory
-//          queue of a wave is shallow, so "issue everything first" leaves the wave stalled in load issue (7900 of the node's
-//          12700 cycles, profiles/r04a_ab.txt) while fragments that have landed wait for their MFMAs;
-//   bit 1  weights in FRAGMENT order ([step][wave][lane][16 B]: a wave-load is 1 KiB contiguous = 8 whole lines, instead of 16
-//          half lines of the [tap][out][in] rows);
-//   bit 2  nt cache policy on the weight loads.
-template <bool HAS_AUX1, bool HAS_AUX2, int VAR>
+// FRAG: weights in FRAGMENT order ([step][wave][lane][16 B], tg_pack_weights_frag: a wave-load is 1 KiB contiguous = 8 whole cache
+//   lines) instead of the [tap][out][in] rows of tg_conv_forward's operand (16 HALF lines per wave-load).  This is the lever:
+//   6.59 -> 4.42 us per block, weight stream of a node 3400 + 4300 -> 1900 + 1900 cycles (profiles/r04b_ab.txt): the CU's miss
+//   path is bound by the number of lines in flight, and a half-line request holds a whole line's slot.  (nt loads: no gain.)
+// DIST: prefetch distance of the weight stream in fragments.  The 36 fragments of both convs are ONE stream in consumption
+//   order; DIST of them are requested before the input region is staged, and fragment i + DIST is requested right before the
+//   MFMAs of fragment i.  A wave's vector-memory queue is shallow: "issue everything first" (round-4 session A) left the wave
+//   stalled in load issue for 7900 of the node's 12700 cycles while landed fragments waited for their MFMAs.
+template <bool HAS_AUX1, bool HAS_AUX2, bool FRAG, int DIST>
 __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[RB_XPOS * RB_P];
   __shared__ __attribute__((aligned(16))) unsigned char hs[RB_HPOS * RB_P];
-  constexpr bool INTERLEAVE = (VAR & 1) != 0, FRAG = (VAR & 2) != 0;
-  constexpr int WPOL = (VAR & 4) ? 2 : 0;
+  static_assert(DIST >= 1 && DIST <= 36, "prefetch distance in fragments");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fg = lane >> 4;
@@ -115,9 +124,8 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX2 ? p.aux2 : p.x), 0, (int)p.bytes, 0x00020000);
   const int cbyte = (wave * 16 + fg * 4) * 2;       // byte offset of this lane's four output channels inside a pixel
 
-  // ---- global loads, in consumption order (no branch around any of them: hipcc answers a load inside a branch with
-  //      s_waitcnt vmcnt(0) at the join -- the whole weight stream -- and a null pointer is a zero-length buffer that reads
-  //      zeros / drops stores) ---------------------------------------------------------------------------------------------
+  // ---- global loads (no branch around any of them: hipcc answers a load inside a branch with s_waitcnt vmcnt(0) at the join
+  //      -- the whole weight stream -- and a null pointer is a zero-length buffer that reads zeros / drops stores) -------------
   const auto rsB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b1), 0, p.b1 ? 256 : 0, 0x00020000);
   const auto rsB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b2), 0, p.b2 ? 256 : 0, 0x00020000);
   const u32x4r bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsB1, (wave * 16 + fg * 4) * 4, 0, 0);
@@ -132,17 +140,7 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
     const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + ch * 16) : RB_OOB), 0, 0);
   }
-  // (2) first conv's weight fragments: lane (frow, fg) of step s = (tap, K-half kk) holds w[tap][16 wave + frow][32 kk + 8 fg .. +8]
-  u32x4r wA[18], wB[18];
-  const int wlane = FRAG ? wave * 1024 + lane * 16 : ((wave * 16 + frow) * 64 + fg * 8) * 2;
-  auto wload = [&](const auto& rs, int s) {
-    const int tap = s >> 1, kk = s & 1;
-    const int wtap = p.flip ? 8 - tap : tap;
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, FRAG ? (wtap * 2 + kk) * 4096 : wtap * 8192 + kk * 64, WPOL);
-  };
-#pragma unroll
-  for (int s = 0; s < 18; ++s) wA[s] = wload(rsW1, s);
-  // (3) masks: four channels (8 bytes) of the pixel this lane finishes at each level
+  // (2) masks: four channels (8 bytes) of the pixel this lane finishes at each level
   u32x2r m1[HAS_AUX1 ? 3 : 1], m2;
   if constexpr (HAS_AUX1) {
 #pragma unroll
@@ -157,11 +155,21 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   const bool out_ok = oy < p.H && ox < p.W;
   const int out_off = ((n * p.H + oy) * p.W + ox) * 128 + cbyte;
   if constexpr (HAS_AUX2) m2 = __builtin_amdgcn_raw_buffer_load_b64(rsA2, (int)(out_ok ? (unsigned)out_off : RB_OOB), 0, 0);
-  // (4) second conv's weight fragments: up front, or one per MFMA step of level 1 (INTERLEAVE)
-  if constexpr (!INTERLEAVE) {
-#pragma unroll
-    for (int s = 0; s < 18; ++s) wB[s] = wload(rsW2, s);
-  }
+  // (3) the weight stream: fragment i < 18 is step i of the first conv, i >= 18 step i - 18 of the second; lane (frow, fg) of
+  //     step s = (tap, K-half kk) holds w[tap][16 wave + frow][32 kk + 8 fg .. +8]
+  u32x4r wA[18], wB[18];
+  const int wlane = FRAG ? wave * 1024 + lane * 16 : ((wave * 16 + frow) * 64 + fg * 8) * 2;
+  auto wload = [&](const auto& rs, int s) {
+    const int tap = s >> 1, kk = s & 1;
+    const int wtap = p.flip ? 8 - tap : tap;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, FRAG ? (wtap * 2 + kk) * 4096 : wtap * 8192 + kk * 64, 0);
+  };
+#define RB_WISSUE(i)                                            \
+  do {                                                          \
+    if constexpr ((i) < 18) wA[(i) < 18 ? (i) : 0] = wload(rsW1, (i));          \
+    else if constexpr ((i) < 36) wB[(i) < 36 && (i) >= 18 ? (i) - 18 : 0] = wload(rsW2, (i) - 18); \
+  } while (0)
+  rb_static_for<0, DIST>([&](auto i) { RB_WISSUE(decltype(i)::value); });
   const float bv1[4] = {__uint_as_float(bq1.x), __uint_as_float(bq1.y), __uint_as_float(bq1.z), __uint_as_float(bq1.w)};
   const float bv2[4] = {__uint_as_float(bq2.x), __uint_as_float(bq2.y), __uint_as_float(bq2.z), __uint_as_float(bq2.w)};
   __builtin_amdgcn_sched_barrier(0);          // keep the loads up here (hipcc sinks them to their uses otherwise)
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // software pipeline: the pixel fragments of step s + 1 are requested from LDS before the MFMAs of step s, so a step costs its
-  // MFMAs, not an LDS round trip (the steps are paced by the weight stream anyway: one fragment per ~200 cycles and wave)
+  // MFMAs, not an LDS round trip
   auto xfrag = [&](int s, int t) {
     const int tap = s >> 1, kk = s & 1;
     return *reinterpret_cast<const uint4*>(xb + ((2 * t + tap / 3) * RB_XR + tap % 3) * RB_P + kk * 64);
@@ -191,9 +199,10 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
   uint4 bf[3], nbf[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) bf[t] = xfrag(0, t);
-#pragma unroll
-  for (int s = 0; s < 18; ++s) {
-    if (s < 17) {
+  rb_static_for<0, 18>([&](auto sv) {
+    constexpr int s = decltype(sv)::value;
+    RB_WISSUE(s + DIST);                                       // (a queue slot has just been freed by fragment s)
+    if constexpr (s < 17) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) nbf[t] = xfrag(s + 1, t);
     }
@@ -201,11 +210,10 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
     for (int t = 0; t < 3; ++t)
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wA[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
                                                        acc[t], 0, 0, 0);
-    if constexpr (INTERLEAVE) wB[s] = wload(rsW2, s);          // a queue slot has just been freed by wA[s]
     __builtin_amdgcn_sched_barrier(0);                         // (pinned: hoisted to the top these loads stall the issue again)
 #pragma unroll
     for (int t = 0; t < 3; ++t) bf[t] = nbf[t];
-  }
+  });
   RB_STAMP(4);
   // level-1 epilogue: bias, activation, mask; zero outside the image (= the second conv's SAME padding); bf16 -> LDS;
   // the tile's own 4x4 pixels also go to HBM
@@ -241,18 +249,22 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
 
   // ---- level 2: second conv on the 4x4 tile (lane: row frow/4, column frow%4) ----------------------------------------
   const unsigned char* hb = hs + ((frow >> 2) * RB_HR + (frow & 3)) * RB_P + fg * 16;
-  // one accumulator, 18 dependent MFMAs: all 18 fragments are requested up front (the first conv's weight registers are
-  // free by now), so the chain never waits for an LDS round trip
+  // one accumulator, 18 dependent MFMAs: all 18 pixel fragments are requested up front (the first conv's weight registers are
+  // free by now), so the chain never waits for an LDS round trip -- only for its weight fragments
   f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
   uint4 hf[18];
 #pragma unroll
   for (int s = 0; s < 18; ++s)
     hf[s] = *reinterpret_cast<const uint4*>(hb + ((s / 6) * RB_HR + (s >> 1) % 3) * RB_P + (s & 1) * 64);
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int s = 0; s < 18; ++s)
+  rb_static_for<0, 18>([&](auto sv) {
+    constexpr int s = decltype(sv)::value;
+    RB_WISSUE(18 + s + DIST);
     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&hf[s]),
                                                    acc2, 0, 0, 0);
+    if constexpr (18 + s + DIST < 36) __builtin_amdgcn_sched_barrier(0);
+  });
+#undef RB_WISSUE
   RB_STAMP(7);
   // level-2 epilogue: bias, skip (the centre of the staged input region), mask, store
   {
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void resblock_lat_kernel(RbP p) {
 
 extern "C" int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                            const void* aux1, const void* aux2, void* mid, void* out, int N, int H, int W, int C, int dtype,
-                           void* stream) {
+                           int w_frag, void* stream) {
   TG_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (input gradient)");
   TG_CHECK_ARG(dtype == TG_BF16 && C == 64, "bf16 tensors with 64 channels only (the fp32 parity mode runs the block as two tg_conv_forward launches)");
   TG_CHECK_ARG(x && w1 && w2 && out && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
@@ -301,31 +313,35 @@ extern "C" int tg_resblock(int mode, const void* x, const void* w1, const float*
   p.bytes = (unsigned)bytes;
   static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
   p.prio = prio;
+  p.wfrag = w_frag != 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double px = (double)N * H * W;
   const double fl = 2.0 * 2.0 * px * 64.0 * 576.0;
   const double by = px * 128.0 * (2 + (mid != nullptr) + (aux1 != nullptr) + (aux2 != nullptr)) + 2.0 * 73728.0;
+  int dist = RB_DIST;
 #ifdef TG_RB_TRACE
-  const int var = getenv("TG_RB_VAR") ? atoi(getenv("TG_RB_VAR")) : RB_VAR_DEFAULT;      // read per call: the tool sweeps it
-#else
-  const int var = RB_VAR_DEFAULT;
+  if (getenv("TG_RB_DIST")) dist = atoi(getenv("TG_RB_DIST"));       // read per call: tools/trace_rb.py sweeps it
 #endif
-  auto go = [&](auto vtag) {
-    constexpr int V = decltype(vtag)::value;
-    if (aux1 && aux2) TG_LAUNCH("resblock_lat<bwd,mask2>", fl, by, (resblock_lat_kernel<true, true, V>), dim3(p.ntiles), dim3(256), 0, st, p);
-    else if (aux1) TG_LAUNCH("resblock_lat<bwd>", fl, by, (resblock_lat_kernel<true, false, V>), dim3(p.ntiles), dim3(256), 0, st, p);
-    else if (aux2) TG_LAUNCH("resblock_lat<mask2>", fl, by, (resblock_lat_kernel<false, true, V>), dim3(p.ntiles), dim3(256), 0, st, p);
-    else TG_LAUNCH("resblock_lat<fwd>", fl, by, (resblock_lat_kernel<false, false, V>), dim3(p.ntiles), dim3(256), 0, st, p);
+  auto go = [&](auto ftag, auto dtag) {
+    constexpr bool F = decltype(ftag)::value;
+    constexpr int D = decltype(dtag)::value;
+    if (aux1 && aux2) TG_LAUNCH("resblock_lat<bwd,mask2>", fl, by, (resblock_lat_kernel<true, true, F, D>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else if (aux1) TG_LAUNCH("resblock_lat<bwd>", fl, by, (resblock_lat_kernel<true, false, F, D>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else if (aux2) TG_LAUNCH("resblock_lat<mask2>", fl, by, (resblock_lat_kernel<false, true, F, D>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else TG_LAUNCH("resblock_lat<fwd>", fl, by, (resblock_lat_kernel<false, false, F, D>), dim3(p.ntiles), dim3(256), 0, st, p);
   };
-  switch (var) {
+  using T = std::true_type;
+  using Fa = std::false_type;
+  if (!w_frag) go(Fa{}, std::integral_constant<int, RB_DIST>{});
 #ifdef TG_RB_TRACE
-    case 0: go(std::integral_constant<int, 0>{}); break;
-    case 1: go(std::integral_constant<int, 1>{}); break;
-    case 3: go(std::integral_constant<int, 3>{}); break;
-    case 5: go(std::integral_constant<int, 5>{}); break;
-    case 7: go(std::integral_constant<int, 7>{}); break;
+  else if (dist == 4) go(T{}, std::integral_constant<int, 4>{});
+  else if (dist == 6) go(T{}, std::integral_constant<int, 6>{});
+  else if (dist == 8) go(T{}, std::integral_constant<int, 8>{});
+  else if (dist == 14) go(T{}, std::integral_constant<int, 14>{});
+  else if (dist == 18) go(T{}, std::integral_constant<int, 18>{});
+  else if (dist == 36) go(T{}, std::integral_constant<int, 36>{});
 #endif
-    default: go(std::integral_constant<int, RB_VAR_DEFAULT>{}); break;
-  }
+  else go(T{}, std::integral_constant<int, RB_DIST>{});
+  (void)dist;
   TG_CHECK_LAUNCH();
 }

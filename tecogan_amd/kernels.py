@@ -174,12 +174,24 @@ def hr_tail_forward(t1, w_tran, b_tran, w_out, b_out, gen_in, out, state=None):
     return out if out is not None else state
 
 
-def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out):
-    """One residual block (mode 0) / its input-gradient chain (mode 1) as one launch (csrc/resblock_lat.hip; bf16, C = 64)."""
+def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out, w_frag=False):
+    """One residual block (mode 0) / its input-gradient chain (mode 1) as one launch (csrc/resblock_lat.hip; bf16, C = 64).
+    w_frag: w1 / w2 are fragment-order copies (pack_weights_frag / frag_order)."""
     N, H, W, Cn = x.shape
     check(lib().tg_resblock(mode, _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(aux1), _p(aux2), _p(mid), _p(out), N, H, W, Cn,
-                            dt(x), _stream()), "tg_resblock")
+                            dt(x), int(bool(w_frag)), _stream()), "tg_resblock")
     return out
+
+
+def pack_weights_frag(src_base, dst_t, dst_n, tab, count):
+    check(lib().tg_pack_weights_frag(_p(src_base), _p(dst_t), _p(dst_n), _p(tab), count, _stream()), "tg_pack_weights_frag")
+
+
+def frag_order(w_rows):
+    """[9][64 rows][64 k] (the operand layout of tg_conv_forward) -> the fragment order of tg_resblock(w_frag=1):
+    [2 tap + kk][wave][lane = 16 fg + frow][j] = W[tap][16 wave + frow][32 kk + 8 fg + j].  (torch view / permute; tests and
+    one-off callers -- the training engine's copies come from tg_pack_weights_frag.)"""
+    return w_rows.reshape(9, 4, 16, 2, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)
 
 
 def act_backward(d_out, y, d_in, act=0, alpha=0.0, scale=1.0):

@@ -227,9 +227,9 @@ class Generator:
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
             if fused:
-                a = K.resblock(0, a, ps.packed(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
-                               ps.packed(s + "conv_2/Conv/weights", True), ps.view(s + "conv_2/Conv/biases"), None, None,
-                               q["r"][i][t], q["a"][i][t])
+                a = K.resblock(0, a, ps.packed_frag(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
+                               ps.packed_frag(s + "conv_2/Conv/weights", True), ps.view(s + "conv_2/Conv/biases"), None, None,
+                               q["r"][i][t], q["a"][i][t], w_frag=True)
                 continue
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU, out=q["r"][i][t], flags=cf)
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
@@ -259,10 +259,10 @@ class Generator:
             sc = p + "resblock_%d/" % i
             if fused:
                 # d r = bwd(conv_2)(g) * relu'(r) -> g_c1 (conv_1's weight gradient reads it); d a_{i-1} = bwd(conv_1)(d r) + g
-                g = K.resblock(1, g, ps.packed(sc + "conv_2/Conv/weights", False), None,
-                               ps.packed(sc + "conv_1/Conv/weights", False), None, q["r"][i][t],
+                g = K.resblock(1, g, ps.packed_frag(sc + "conv_2/Conv/weights", False), None,
+                               ps.packed_frag(sc + "conv_1/Conv/weights", False), None, q["r"][i][t],
                                q["a"][0][t] if i == 1 else None, q["g_c1"][i][t],
-                               q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t])
+                               q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], w_frag=True)
                 continue
             dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
                                out=q["g_c1"][i][t], flags=cf)

@@ -168,6 +168,18 @@ class ParamStore:
         self.wN = torch.zeros(max(poff, 8), device=device, dtype=act_dtype)
         self.table = torch.tensor(rows, dtype=torch.int64, device=device).contiguous()
         self.ntab = len(rows)
+        # fragment-order copies of the generator's residual-block convs (64 -> 64, 3x3) for the one-launch block kernel
+        # (csrc/resblock_lat.hip; bf16 compute copies only): forward operand in wTf, input-gradient operand in wNf
+        self.frag = OrderedDict()
+        if act_dtype == torch.bfloat16:
+            for name, e in self.entries.items():
+                if "/resblock_" in name and e.get("taps") == 9 and e["A"] == 64 and e["B"] == 64:
+                    self.frag[name] = len(self.frag) * 36864
+        nf = len(self.frag)
+        self.wTf = torch.zeros(max(nf * 36864, 8), device=device, dtype=torch.bfloat16)
+        self.wNf = torch.zeros(max(nf * 36864, 8), device=device, dtype=torch.bfloat16)
+        self.frag_table = torch.tensor([[self.entries[n]["offset"], o] for n, o in self.frag.items()] or [[0, 0]],
+                                       dtype=torch.int64, device=device).contiguous()
 
     # ---- views ------------------------------------------------------------------------------
     def view(self, name, buf=None):
@@ -183,6 +195,13 @@ class ParamStore:
         e = self.entries[name]
         n = e["taps"] * e["Apad"] * (e["B"] if transposed else e["Bpad"])
         return (self.wT if transposed else self.wN)[e["packed"]:e["packed"] + n]
+
+    def packed_frag(self, name, transposed):
+        """Fragment-order copy (csrc/resblock_lat.hip) of a residual-block conv, or None when the store keeps none."""
+        o = self.frag.get(name)
+        if o is None:
+            return None
+        return (self.wTf if transposed else self.wNf)[o:o + 36864]
 
     def scope_slice(self, scope, buf):
         a, b = self.scope_range[scope]
@@ -206,6 +225,8 @@ class ParamStore:
         """Refresh both compute copies from the fp32 master (one launch for the whole store)."""
         if self.ntab:
             K.pack_weights_both(self.flat, self.wT, self.wN, self.table, self.ntab)
+        if self.frag:
+            K.pack_weights_frag(self.flat, self.wTf, self.wNf, self.frag_table, len(self.frag))
 
     def zero_grad(self):
         self.grad.zero_()

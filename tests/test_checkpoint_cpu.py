@@ -314,3 +314,33 @@ def test_v1_tensor_slice_checkpoint_reader(tmp_path):
     variables, _ = load_variables(path)                                # the front end keeps the float variables
     assert set(variables) == {"vgg_19/conv1/conv1_1/weights", "vgg_19/conv1/conv1_1/biases"}
     assert torch.equal(variables["vgg_19/conv1/conv1_1/weights"], torch.from_numpy(tensors["vgg_19/conv1/conv1_1/weights"]))
+
+
+TF_BUNDLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_bundle")
+TF_BUNDLE_EXPECTED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_bundle_expected.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(TF_BUNDLE_EXPECTED),
+                    reason="tests/golden/tf_bundle* absent: run tools/make_tf_goldens.py on a box with TensorFlow 1.x")
+def test_reads_a_tensorflow_written_bundle():
+    """a checkpoint written by TensorFlow's own Saver (tools/make_tf_goldens.py: the reference's variable names,
+    an AdamOptimizer under variable_scope('generator_train'), global_step = 3) through tf_bundle.BundleReader and the
+    checkpoint front end -- every variable bit for bit, the Adam slots under their TF names, the step counts recovered."""
+    import glob
+    from tecogan_amd.checkpoint import load_variables
+    idx = glob.glob(os.path.join(TF_BUNDLE, "model-*.index"))
+    assert idx, "no bundle under " + TF_BUNDLE
+    prefix = idx[0][:-len(".index")]
+    want = {k.replace("|", "/"): v for k, v in np.load(TF_BUNDLE_EXPECTED).items()}
+    r = TB.BundleReader(prefix)
+    assert set(want) <= set(r.keys()), sorted(set(want) - set(r.keys()))
+    for k, v in want.items():
+        got = r.get(k)
+        assert got.shape == v.shape and np.array_equal(got, v), k
+    variables, extra = load_variables(prefix)
+    assert extra["global_step"] == 3
+    w = "generator/generator_unit/input_stage/conv/Conv/weights"
+    assert torch.equal(variables[w], torch.from_numpy(want[w]))
+    assert torch.equal(extra["adam_m"][w], torch.from_numpy(want["generator_train/" + w + "/Adam"]))
+    assert torch.equal(extra["adam_v"][w], torch.from_numpy(want["generator_train/" + w + "/Adam_1"]))
+    assert extra["adam_steps"]["generator"] == 3

@@ -86,10 +86,58 @@ def test_calendar_clip_fp32_parity_every_frame():
     stream_parity(seq, 144, 180, 16, "calendar")
 
 
-def test_inference_270x480_fp32_parity():
-    """BASELINE configs[4] geometry (480x270 -> 1920x1080, oh = 6), 8 frames of a smooth synthetic clip."""
-    g = torch.Generator().manual_seed(9)
-    base = torch.nn.functional.interpolate(torch.rand(1, 3, 18, 32, generator=g), size=(270 + 16, 480 + 16), mode="bicubic",
-                                           align_corners=False).clamp(0, 1).permute(0, 2, 3, 1)
-    seq = [base[:, 2 * i:2 * i + 270, i:i + 480].contiguous() for i in range(8)]        # a slow pan
-    stream_parity(seq, 270, 480, 16, "270x480")
+def _pan_clip(frames, seed=9):
+    """A slow pan over a smooth random field, 270x480 LR frames in [0,1]."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, 24, 40, generator=g), size=(270 + 2 * frames + 8, 480 + frames + 8),
+                                           mode="bicubic", align_corners=False).clamp(0, 1).permute(0, 2, 3, 1)
+    return [base[:, 2 * i:2 * i + 270, i:i + 480].contiguous() for i in range(frames)]
+
+
+def test_inference_270x480_120_frame_stream_fp32_parity():
+    """BASELINE configs[4] as specified: 480x270 -> 1920x1080 (oh = 6), a 120-frame stream through the loop of reference
+    main.py:253-260, fp32 mode.  The CPU oracle costs seconds per 1080p frame, so it runs FREE for the first 8 frames (every
+    frame compared per pixel, the recurrence included) and is then re-seeded from the HIP engine's own recurrent state before
+    every 16th frame and compared on that frame (each checked step starts from identical state: parity of the step deep in
+    the stream, where the state has long forgotten the cold start) -- 15 oracle frames for 120 stream frames."""
+    nres, h, w = 16, 270, 480
+    seq = _pan_clip(120)
+    P = params(nres, damp=True)
+    st = OT.InferenceState(h, w)
+    eng = InferenceEngine(nres, h, w, "cuda", torch.float32, use_graph=True)
+    eng.load(P)
+    worst, checked = 0.0, 0
+    for i, f in enumerate(seq):
+        free = i < 8
+        forced = i >= 8 and i % 16 == 15
+        if forced:                                   # the oracle's state := the engine's state before this frame
+            st.pre_inputs, st.pre_gen, st.first = eng.pre_inputs.cpu().clone(), eng.pre_gen.cpu().clone(), False
+        out = eng.step(f.cuda())
+        if free or forced:
+            ref = OT.inference_step(P, st, f, nres)
+            worst = max(worst, assert_close_per_elem(out.cpu(), ref, 1e-3, 1e-3, what="270x480 stream frame %d" % i))
+            assert ref.min().item() > -0.5 and ref.max().item() < 1.5
+            checked += 1
+    assert checked == 15
+    print("\n[270x480 x 120 frames] %d frames checked, worst per-pixel relative error %.2e" % (checked, worst))
+
+
+def test_inference_270x480_bf16_stream_is_bounded_against_the_fp32_stream():
+    """The timed inference mode (bf16 activations) at the configs[4] size: every frame of a 120-frame stream against the fp32
+    HIP stream (itself held to the oracle by the test above).  Stated bound, not parity: 2e-2 of the frame range (measured
+    worst case ~6e-3), no drift over the stream (the last 20 frames are no worse than 2x the first 20)."""
+    nres, h, w = 16, 270, 480
+    seq = _pan_clip(120)
+    P = params(nres, damp=True)
+    a = InferenceEngine(nres, h, w, "cuda", torch.float32, use_graph=True)
+    b = InferenceEngine(nres, h, w, "cuda", torch.bfloat16, use_graph=True)
+    a.load(P)
+    b.load(P)
+    errs = []
+    for f in seq:
+        fa, fb = a.step(f.cuda()), b.step(f.cuda())
+        errs.append(float((fa - fb).abs().max() / fa.abs().max()))
+    print("\n[270x480 bf16 vs fp32 stream] max-norm error: first 20 frames %.2e, last 20 %.2e, worst %.2e"
+          % (max(errs[:20]), max(errs[-20:]), max(errs)))
+    assert max(errs) < 2e-2, max(errs)
+    assert max(errs[-20:]) <= 2.0 * max(errs[:20]) + 1e-3

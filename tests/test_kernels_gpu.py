@@ -1179,8 +1179,9 @@ def _dev_bf(t):
     return t.to(DEV, torch.bfloat16).contiguous()
 
 
+@pytest.mark.parametrize("frag", [False, True])
 @pytest.mark.parametrize("shape", RB_SHAPES)
-def test_resblock_one_launch_forward_is_bit_identical_to_two_launches_and_matches_oracle(shape):
+def test_resblock_one_launch_forward_is_bit_identical_to_two_launches_and_matches_oracle(shape, frag):
     """lib/frvsr.py:50-57: out = x + conv_2(relu(conv_1(x))).  One launch (tg_resblock) against (a) the two tg_conv_forward
     launches it replaces -- bit for bit, intermediate included -- and (b) the oracle on the bf16-rounded operands."""
     N, H, W = shape
@@ -1193,12 +1194,13 @@ def test_resblock_one_launch_forward_is_bit_identical_to_two_launches_and_matche
     K.conv_forward(d1, xd, w1t, b1d, None, None, r_ref)
     K.conv_forward(d2, r_ref, w2t, b2d, xd, None, a_ref)
     r, a = torch.full_like(xd, 7.0), torch.full_like(xd, 7.0)
-    K.resblock(0, xd, w1t, b1d, w2t, b2d, None, None, r, a)
+    w1k, w2k = (K.frag_order(w1t), K.frag_order(w2t)) if frag else (w1t, w2t)       # fragment-order copies of the same operands
+    K.resblock(0, xd, w1k, b1d, w2k, b2d, None, None, r, a, w_frag=frag)
     torch.cuda.synchronize()
     assert torch.equal(r.view(torch.int16), r_ref.view(torch.int16)), "intermediate differs from the two-launch path"
     assert torch.equal(a.view(torch.int16), a_ref.view(torch.int16)), "block output differs from the two-launch path"
     a2 = torch.full_like(xd, 7.0)
-    K.resblock(0, xd, w1t, b1d, w2t, b2d, None, None, None, a2)               # stateless form: no intermediate written
+    K.resblock(0, xd, w1k, b1d, w2k, b2d, None, None, None, a2, w_frag=frag)   # stateless form: no intermediate written
     assert torch.equal(a2.view(torch.int16), a_ref.view(torch.int16))
     r_o = torch.relu(O.conv2(x, w1, b1, 1)).bfloat16().float()
     a_o = x + O.conv2(r_o, w2, b2, 1)
@@ -1206,9 +1208,10 @@ def test_resblock_one_launch_forward_is_bit_identical_to_two_launches_and_matche
     close(a, a_o, 1e-2, "resblock output %s" % (shape,))
 
 
+@pytest.mark.parametrize("frag", [False, True])
 @pytest.mark.parametrize("mask2", [False, True])
 @pytest.mark.parametrize("shape", RB_SHAPES)
-def test_resblock_one_launch_input_gradient_is_bit_identical_to_two_launches_and_matches_autograd(shape, mask2):
+def test_resblock_one_launch_input_gradient_is_bit_identical_to_two_launches_and_matches_autograd(shape, mask2, frag):
     """tf.gradients through the block (lib/Teco.py:441-449): d r = bwd(conv_2)(g) * relu'(r), d x = (g + bwd(conv_1)(d r))
     [* relu'(a0) for the first block, whose input is the input stage's ReLU output]."""
     N, H, W = shape
@@ -1226,7 +1229,8 @@ def test_resblock_one_launch_input_gradient_is_bit_identical_to_two_launches_and
     K.conv_forward(dA, gd, w2n, None, None, rd, dr_ref)
     K.conv_forward(dB, dr_ref, w1n, None, gd, aux2, dx_ref)
     dr, dx = torch.full_like(gd, 7.0), torch.full_like(gd, 7.0)
-    K.resblock(1, gd, w2n, None, w1n, None, rd, aux2, dr, dx)
+    w2k, w1k = (K.frag_order(w2n), K.frag_order(w1n)) if frag else (w2n, w1n)
+    K.resblock(1, gd, w2k, None, w1k, None, rd, aux2, dr, dx, w_frag=frag)
     torch.cuda.synchronize()
     assert torch.equal(dr.view(torch.int16), dr_ref.view(torch.int16)), "d r differs from the two-launch path"
     assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), "d x differs from the two-launch path"
@@ -1249,3 +1253,19 @@ def test_resblock_rejects_what_it_does_not_cover():
     w = torch.zeros(9, 64, 64, device=DEV)
     with pytest.raises(TecoHipError):
         K.resblock(0, x, w, None, w, None, None, None, None, torch.empty_like(x))          # fp32: two launches, not this kernel
+
+
+def test_pack_weights_frag_matches_the_host_permutation_of_both_operands():
+    """tg_pack_weights_frag (one launch after the Adam updates) against kernels.frag_order applied to the two row-order compute
+    copies tg_pack_weights_both writes: forward operand [tap][out][in] and input-gradient operand [tap][in][out]."""
+    from collections import OrderedDict
+    from tecogan_amd import params as P
+    ps = P.ParamStore(OrderedDict(generator=P.generator_spec(2)), DEV, torch.bfloat16)
+    ps.load(P.init_values(P.generator_spec(2), 5))
+    assert len(ps.frag) == 4
+    for name in ps.frag:
+        for tr in (True, False):
+            rows = ps.packed(name, tr).view(9, 64, 64)
+            assert torch.equal(ps.packed_frag(name, tr).view(torch.int16), K.frag_order(rows).view(torch.int16)), (name, tr)
+    assert ps.packed_frag("generator/generator_unit/input_stage/conv/Conv/weights", True) is None
+    assert not P.ParamStore(OrderedDict(generator=P.generator_spec(1)), DEV, torch.float32).frag        # bf16 compute copies only

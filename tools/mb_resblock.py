@@ -45,8 +45,10 @@ for N, H, W in ((4, 32, 32), (4, 24, 24), (1, 32, 32), (8, 32, 32)):
         K.conv_forward(d1, a[i], w1[i], b1[i], None, None, r[i])
         K.conv_forward(d2, r[i], w2[i], b1[i], a[i], None, a[i + 1])
 
+    f1, f2 = [K.frag_order(w) for w in w1], [K.frag_order(w) for w in w2]
+
     def one_fwd(i):
-        K.resblock(0, a[i], w1[i], b1[i], w2[i], b1[i], None, None, r[i], a[i + 1])
+        K.resblock(0, a[i], f1[i], b1[i], f2[i], b1[i], None, None, r[i], a[i + 1], w_frag=True)
 
     aux = [torch.randn(N, H, W, 64, device=DEV).to(bf) for _ in range(NB)]
     gmid = [torch.empty(N, H, W, 64, device=DEV, dtype=bf) for _ in range(NB)]
@@ -56,7 +58,7 @@ for N, H, W in ((4, 32, 32), (4, 24, 24), (1, 32, 32), (8, 32, 32)):
         K.conv_forward(dB, gmid[i], w1[i], None, a[i], None, a[i + 1])
 
     def one_bwd(i):
-        K.resblock(1, a[i], w2[i], None, w1[i], None, aux[i], None, gmid[i], a[i + 1])
+        K.resblock(1, a[i], f2[i], None, f1[i], None, aux[i], None, gmid[i], a[i + 1], w_frag=True)
 
     t2f, t1f, t2b, t1b = chain_time(two_fwd), chain_time(one_fwd), chain_time(two_bwd), chain_time(one_bwd)
     print("res block [%d,%d,%d,64] bf16, us per block in a %d-block graph chain: forward two launches %6.2f  one launch %6.2f | "

@@ -28,7 +28,7 @@ from tecogan_amd import kernels as K  # noqa: E402
 
 lib = C.CDLL(so)
 lib.tg_debug_rb_trace.argtypes = [C.POINTER(C.c_ulonglong)]
-NAMES = ["entry", "all loads issued", "input region landed, LDS written", "barrier 1 passed", "level-1 MFMAs issued",
+NAMES = ["entry", "first loads issued", "input region landed, LDS written", "barrier 1 passed", "level-1 MFMAs issued",
          "level-1 epilogue issued", "barrier 2 passed", "level-2 MFMAs issued", "stores issued", "stores retired (vmcnt 0)"]
 N, H, W = 4, 32, 32
 NB = 16
@@ -41,18 +41,17 @@ act = [torch.randn(N, H, W, 64, device="cuda").bfloat16() for _ in range(NB + 1)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from microbench import timeit  # noqa: E402
 
-VARS = {0: "all loads up front (round-4 session A)", 1: "second conv's weights issued between the first conv's MFMA steps",
-        3: "... + fragment-order weights (timing only: operands are not in that order)", 5: "... + nt weight loads",
-        7: "... + fragment order + nt"}
-for var, what in VARS.items():
-    os.environ["TG_RB_VAR"] = str(var)
-    print("== variant %d: %s" % (var, what))
+print("weight stream of the one-launch residual block [%d,%d,%d,64]: layout x prefetch distance (fragments requested ahead)" % (N, H, W))
+for frag, dist in ((False, 10), (True, 4), (True, 6), (True, 8), (True, 10), (True, 14), (True, 18), (True, 36)):
+    os.environ["TG_RB_DIST"] = str(dist)
+    print("== %s, prefetch distance %d%s" % ("fragment-order weights" if frag else "[tap][out][in] rows", dist,
+                                             " (everything up front)" if dist == 36 else ""))
     for mode, label in ((0, "forward"), (1, "input gradient")):
-        def block(i, mode=mode):
+        def block(i, mode=mode, frag=frag):
             if mode == 0:
-                K.resblock(0, act[i], ws[2 * i], b, ws[2 * i + 1], b, None, None, mid, act[i + 1])
+                K.resblock(0, act[i], ws[2 * i], b, ws[2 * i + 1], b, None, None, mid, act[i + 1], w_frag=frag)
             else:
-                K.resblock(1, act[i], ws[2 * i], None, ws[2 * i + 1], None, aux, None, mid, act[i + 1])
+                K.resblock(1, act[i], ws[2 * i], None, ws[2 * i + 1], None, aux, None, mid, act[i + 1], w_frag=frag)
         for i in range(NB):
             block(i)
         torch.cuda.synchronize()
