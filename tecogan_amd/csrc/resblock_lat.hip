@@ -52,7 +52,9 @@ constexpr int RB_P = 160;                       // bytes per LDS position (64 bf
 constexpr int RB_XR = 8, RB_XPOS = 8 * 8 + 2;   // input region: 8x8 positions, row pitch 8 (+2: the padding columns of the last row read on)
 constexpr int RB_HR = 12, RB_HPOS = 6 * 12;     // intermediate: 6 rows, row pitch 12
 constexpr unsigned RB_OOB = 0x80000000u;
-constexpr int RB_DIST = 10;                     // prefetch distance of the weight stream (fragments), see the kernel
+constexpr int RB_DIST = 14;                     // prefetch distance of the weight stream (fragments): 4 .. 18 measured within 8 %
+                                                // (4.57 / 4.31 / 4.32 / 4.31 / 4.20 / 4.25 us per block at 4 / 6 / 8 / 10 / 14 / 18,
+                                                // everything up front 4.91; profiles/r04c_ab.txt)
 }  // namespace
 
 // Cycle stamps (tools/trace_rb.py builds a private -DTG_RB_TRACE copy of the library; the product build has none of it).
@@ -337,7 +339,7 @@ extern "C" int tg_resblock(int mode, const void* x, const void* w1, const float*
   else if (dist == 4) go(T{}, std::integral_constant<int, 4>{});
   else if (dist == 6) go(T{}, std::integral_constant<int, 6>{});
   else if (dist == 8) go(T{}, std::integral_constant<int, 8>{});
-  else if (dist == 14) go(T{}, std::integral_constant<int, 14>{});
+  else if (dist == 10) go(T{}, std::integral_constant<int, 10>{});
   else if (dist == 18) go(T{}, std::integral_constant<int, 18>{});
   else if (dist == 36) go(T{}, std::integral_constant<int, 36>{});
 #endif

@@ -303,6 +303,47 @@ def test_bf16_mode_error_at_baseline_config_C2():
     assert abs(eng.losses()["l2_content_loss"] - ref) < 2e-2 * ref
 
 
+def test_bf16_mode_error_at_baseline_config_C3():
+    """The TIMED mode (bf16 activations / fp32 master weights) at the full configs[2] size against the fp32 mode of the same
+    engine (held to the fp64 oracle by test_tecogan_step_fp32_parity_at_baseline_config_C3): one step from identical damped
+    weights and batch.  Stated, measured bounds -- not parity (profiles/r04b_bf16_error_table.txt, tools/bf16_error_table.py):
+      * HR frames: relative L2 <= 6e-3 (measured 3.3e-3), every loss scalar within 1 %;
+      * gradients per optimiser scope, relative L2: generator <= 2e-2 (9.6e-3), FNet <= 1e-1 (6.6e-2), D <= 1.6e-1 (1.06e-1);
+      * the gradient of D's LAST layer (no activation decision between it and the loss) <= 1e-2 (2.6e-3): bf16 accumulation is
+        not what separates the modes.  What does: every ReLU / LeakyReLU / max-pool decision whose pre-activation lies within
+        the forward difference of the two modes (1e-2 after 5-35 bf16 layers) flips, and a flipped unit contributes its FULL
+        gradient as error -- a fraction f of flipped units costs ~sqrt(f) in relative L2 (VGG's input gradient: 2.6e-1 after
+        16 ReLU layers and 4 pools).  Both gradients are exact gradients of networks 1e-2 apart; no storage format short of
+        fp32 activations removes this, and bench.py's trajectory control shows the modes' loss curves differ by what an fp32
+        run differs from itself under a one-time perturbation of bf16's size."""
+    from tecogan_amd.params import damp_values
+    F = OT.default_flags()
+    x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
+    res = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        eng = TrainEngine(F, DEV, gan=True, act_dtype=dt, seed=7, use_graph=False)
+        eng.ps.load(damp_values(eng.ps.state_dict()))
+        eng.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        grads = {sc: eng.ps.scope_slice(sc, eng.ps.grad).double().cpu() for sc in eng.ps.scope_range}
+        last = eng.ps.gview("tdiscriminator/discriminator_unit/dense_layer_2/dense/kernel").double().cpu().clone()
+        res[name] = (eng.gen.double().cpu(), eng.losses(), grads, last)
+        del eng
+        torch.cuda.empty_cache()
+    (gf, lf, grf, lastf), (gb, lb, grb, lastb) = res["f32"], res["bf16"]
+    rl2 = lambda a, b: float((a - b).norm() / b.norm())                           # noqa: E731
+    e_gen = rl2(gb, gf)
+    e_scope = {sc: rl2(grb[sc], grf[sc]) for sc in grf}
+    e_last = rl2(lastb, lastf)
+    print("\n[C3 bf16 vs fp32] frames %.2e, gradients %s, D last layer %.2e" % (e_gen, {k: "%.2e" % v for k, v in e_scope.items()}, e_last))
+    assert e_gen < 6e-3, e_gen
+    for k, v in lf.items():
+        if k in lb and abs(v) > 1e-6 and k not in ("t_balance", "t_balance_now"):
+            assert abs(lb[k] - v) <= 1e-2 * abs(v), (k, lb[k], v)
+    assert e_scope["generator"] < 2e-2 and e_scope["fnet"] < 1e-1 and e_scope["tdiscriminator"] < 1.6e-1, e_scope
+    assert e_last < 1e-2, e_last
+
+
 def test_tecogan_temporal_only_discriminator_Dt_mergeDs_false():
     """lib/Teco.py:246-250,269-272,423-424: D sees only the 9 warped channels, centre-cropped to (4h - 2 off)^2, and its
     learning rate is 0.3 x.  (The reference's own branch cannot run -- discriminator_F returns a tuple there and the layer
@@ -446,8 +487,10 @@ def test_validation_pass_issues_no_collective_and_leaves_training_state_untouche
     for e in engs:
         e.step(x.to(DEV), y.to(DEV))
     torch.cuda.synchronize()
-    ea, eg = rel_err(b.ps.flat, a.ps.flat), rel_err(b.gen, a.gen)
-    assert ea < 1e-4 and eg < 1e-4, (ea, eg)        # two engines: the noise of their fp32 atomics through two Adam steps
+    # (gradients and frames, not weights: two engines differ by the noise of their fp32 atomics, and Adam's first updates are
+    #  lr * sign(g) -- a gradient element near zero moves its weight by a whole step either way)
+    eg, ef = rel_err(b.ps.grad, a.ps.grad), rel_err(b.gen, a.gen)
+    assert eg < 1e-3 and ef < 1e-4, (eg, ef)
     assert int(a.sched[0].item()) == int(b.sched[0].item()) == 2
 
 
