@@ -39,8 +39,6 @@ struct ConvDmaP {
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope
   int tiles_y, tiles_x, ntiles;
   unsigned in_bytes, w_bytes, out_bytes;
-  int wchunk;         // weights in chunk-major order [Cin/32][tap][Cout][32]: a stage's 36 KB panel is contiguous (whole lines)
-  int htest;          // TIMING ONLY (TG_C3DMA_HTEST=1): halo addressed as if activations were channel-blocked [C/32][N][H][W][32]
 };
 
 typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
@@ -83,6 +81,10 @@ extern "C" int tg_debug_dma_trace(unsigned long long* out) {
 #define DM_STAMP(i) do { } while (0)
 #endif
 
+// (Round 4, session D: the stage's two streams read 64-byte pieces of longer rows -- half cache lines, the pattern that halved the
+// weight stream of resblock_lat.hip.  Timing-only hooks that addressed the weight panel as one contiguous 36 KB block per stage
+// and the halo as channel-blocked activations bought 2-3 % here (1105 -> 1133 TFLOP/s at [76,32,32,256], profiles/
+// r04d_dma_stream.txt): this kernel is not bound by its line requests, and neither layout change was built.)
 // (A two-tiles-per-stage variant -- one weight panel for two halos, 39 instead of 57 KB per 256 output pixels -- lost twice:
 // alone to tile quantisation (1044 vs 1143 TFLOP/s at [76,32,32,256], profiles/r02t_microbench.txt), and in round 3 also as
 // "whole rounds of pairs + a second launch of single tiles for the remainder" (78.8 -> 81.8 us, profiles/r03q_microbench.txt):
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
     const int dy = q / DM_HW, dx = q - DM_HW * dy;
     if constexpr (PK == 1) {
-      hrel[k] = p.htest ? (dy * p.W + dx) * 64 + ch * 16 : (dy * p.W + dx) * row_bytes + ch * 16;
+      hrel[k] = (dy * p.W + dx) * row_bytes + ch * 16;
       hcode[k] = dy | (dx << 8) | (q < DM_HALO ? (1 << 24) : 0);
     } else {                  // packed: block (by, bx) = image within the tile, (ry, rx) = pixel of that image (or its border)
       constexpr int S = G::S;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
     const int tap = q >> 6, co = n0 + (q & 63);
     const int wt = p.flip ? 8 - tap : tap;
-    wrel[k] = (i0 < DM_W_INST && co < p.Cout) ? (p.wchunk ? (wt * p.Cout + co) * 64 + ch * 16 : ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16) : -1;
+    wrel[k] = (i0 < DM_W_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
   }
 
   // One DMA round (r compile-time after unrolling) of the stage set up by dma_setup: rounds [3t, 3t+3) = halo of tile t,
@@ -164,15 +166,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
         const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
         d_y0[t] = ty * DM_TH - 1;
         d_x0[t] = tx * 16 - 1;
-        d_base[t] = p.htest ? (((chunk * p.N + n) * p.H + d_y0[t]) * p.W + d_x0[t]) * 64
-                            : ((n * p.H + d_y0[t]) * p.W + d_x0[t]) * row_bytes + chunk * 64;    // wave-uniform
+        d_base[t] = ((n * p.H + d_y0[t]) * p.W + d_x0[t]) * row_bytes + chunk * 64;    // wave-uniform
       } else {                // packed: the tile's first image; d_y0 = images of the batch left from there on
         d_y0[t] = p.N - tile * PK * PK;
         d_x0[t] = 0;
         d_base[t] = tile * PK * PK * G::S * G::S * row_bytes + chunk * 64;
       }
     }
-    d_wofs = p.wchunk ? chunk * 9 * p.Cout * 64 : chunk * 64;
+    d_wofs = chunk * 64;
     d_dst = smem + buf * BUF;
   };
   auto dma_round = [&](int r) {
@@ -453,10 +454,6 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   if (ntiles * (p.Cout / 64) < (pk == 1 ? min_wg : min_wg_pack) || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-  // measurement hooks (timing only, results are garbage): what would whole-line streams buy?  (round 4, session D)
-  static const int wtest = getenv("TG_C3DMA_WTEST") ? atoi(getenv("TG_C3DMA_WTEST")) : 0;
-  static const int htest = getenv("TG_C3DMA_HTEST") ? atoi(getenv("TG_C3DMA_HTEST")) : 0;
-  p.wchunk = wtest; p.htest = htest;
   if (pk == 2) launch_dma_pk<2>(p, res != nullptr, aux != nullptr, st);
   else if (pk == 4) launch_dma_pk<4>(p, res != nullptr, aux != nullptr, st);
   else launch_dma_pk<1>(p, res != nullptr, aux != nullptr, st);
