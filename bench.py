@@ -123,12 +123,15 @@ HOST_ENQUEUE_MS = [None]          # host time to enqueue one step (no device wai
 
 
 def time_steps(eng, steps, warmup, fence):
+    # target lookahead (engine.py): the resident batch is also the "next" batch, so every step puts one batch of targets
+    # through VGG-19 as before -- during its own backward phase, for the step that follows
+    kw = {"next_targets": True} if getattr(eng, "lookahead", False) else {}
     for _ in range(warmup):
-        eng.step()
+        eng.step(**kw)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.step()
+        eng.step(**kw)
     t1 = time.perf_counter()
     fence()
     HOST_ENQUEUE_MS[0] = (t1 - t0) / steps * 1e3
@@ -374,9 +377,11 @@ def loss_trajectory(config, device, steps=200, every=20):
         if perturb:
             e.ps.load({k: v.bfloat16().float() for k, v in e.ps.state_dict().items()})
         rows = []
+        x, y = synthetic_batch(e.F, 5000, device)
         for it in range(steps):
-            x, y = synthetic_batch(e.F, 5000 + it, device)
-            e.step(x, y)
+            xn, yn = synthetic_batch(e.F, 5000 + it + 1, device)     # the loader is one batch ahead: target lookahead
+            e.step(x, y, next_targets=yn if getattr(e, "lookahead", False) else None)
+            x, y = xn, yn
             if (it + 1) % every == 0:
                 torch.cuda.synchronize()
                 L = e.losses()

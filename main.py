@@ -226,10 +226,13 @@ def run_training(FLAGS):
     try:
         for step in range(max_iter):
             run_step = eng.global_step() + 1 if step == 0 else run_step + 1
-            eng.step(x, y)
+            # one batch of lookahead: the NEXT batch's targets go through VGG-19 during this step's backward phase
+            # (TrainEngine target lookahead); the loader's prefetch thread is ahead of the GPU, so this does not wait
+            nx, ny = rdata.loader.next_batch()
+            eng.step(x, y, next_targets=ny if eng.lookahead else None)
             K.lincomb(avg_raw, eng.loss, avg_raw, 0.99, 0.01)
             n_avg += 1
-            x, y = rdata.loader.next_batch()                     # next batch is prepared while the GPU runs
+            x, y = nx, ny
             if step == 0 and rank == 0:
                 print('Optimization starts!!!(Ctrl+C to stop, will try saving the last model...)')
             if rank == 0 and (run_step % FLAGS.display_freq) == 0:

@@ -165,9 +165,21 @@ class TrainEngine:
         # of the late frames beside D's generator-side backward pass (before the BPTT)
         self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
         # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
-        # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Off by
-        # default until it has been measured on hardware (prepared in round 3 after the GPU budget was spent).
-        self.vggt_dedup = os.environ.get("TG_VGGT_DEDUP", "0") == "1" and bool(F.pingpang) and self.T0 > 1
+        # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Measured in
+        # round 4 (same box, profiles/r04a_ab.txt): 10.97 -> 10.66 ms per TecoGAN step; TG_VGGT_DEDUP=0 is the A/B switch.
+        self.vggt_dedup = os.environ.get("TG_VGGT_DEDUP", "1") == "1" and bool(F.pingpang) and self.T0 > 1
+        # Target LOOKAHEAD (round 4).  The target features depend on the data only, and before the BPTT the side stream is the
+        # step's critical path (target pass 1.4 ms + D real pass + 4 ms of VGG passes over the generated frames,
+        # profiles/r04c_ab.txt) while it idles ~2 ms during the BPTT.  A caller that knows the NEXT batch's targets
+        # (`step(x, y, next_targets=...)`: the loaders prefetch anyway) gets them put through VGG-19 during THIS step's BPTT
+        # phase (segment `vggt_next`); the next step then starts from the stored features (segment `vggt_pre`: one gather).
+        # Every step still computes one batch of target features -- one step earlier.  Without `next_targets` the features are
+        # computed in-step as before (segment `vggt`).  TG_TARGET_LOOKAHEAD=0 disables the mechanism.
+        self.lookahead = os.environ.get("TG_TARGET_LOOKAHEAD", "1") == "1" and self.use_vgg
+        self.in_hr_next = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev) if self.lookahead else None
+        self._taps_t, self._taps_next = None, None      # persistent feature buffers (outside the graph pools: they cross steps)
+        self._next_ready = False                        # _taps_next holds the features of the batch the NEXT step() will get
+        self._have_next = False                         # this step() was given next_targets
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
@@ -180,35 +192,55 @@ class TrainEngine:
         # and each such node would wait for a CU to drain (~50 us, 27 + 19 nodes per step)
         if uses_side:
             self.G.chain_flags = K.CONV_COEXIST
+        self.lookahead = self.lookahead and self.segmented and bool(self.ov_parts & 1)
 
     # ------------------------------------------------------------------------------------------
     def set_batch(self, r_inputs, r_targets):
         """r_inputs [B,T0,h,w,3] in [0,1]; r_targets [B,T0,4h,4w,3] in [-1,1] (lib/Teco.py:78)."""
         self.in_lr.copy_(r_inputs, non_blocking=True)
         self.in_hr.copy_(r_targets, non_blocking=True)
+        self._next_ready = False          # a new batch: stored target features (if any) belonged to the announced one only
 
-    def step(self, r_inputs=None, r_targets=None):
+    def step(self, r_inputs=None, r_targets=None, next_targets=None):
+        """One training step.  next_targets (optional, [B,T0,4h,4w,3]): the targets of the batch the NEXT call will train on
+        -- their VGG features are computed during this step's backward phase (target lookahead, see __init__); pass the
+        very tensor values the next call passes as r_targets (next_targets=True: the resident batch stays, as in bench.py)."""
+        ready = self._next_ready
         if r_inputs is not None:
             self.set_batch(r_inputs, r_targets)
+            if ready:
+                # the previous call announced this batch's targets and their features are stored: the targets of this step
+                # ARE the announced ones by construction (a caller passing something else would otherwise train against
+                # features of other images); TG_CHECK_LOOKAHEAD=1 verifies the caller's promise (costs a sync)
+                if os.environ.get("TG_CHECK_LOOKAHEAD") == "1":
+                    assert torch.equal(self.in_hr, self.in_hr_next), "step(): r_targets differ from the announced next_targets"
+                self.in_hr.copy_(self.in_hr_next, non_blocking=True)
+            self._next_ready = ready
+        self._have_next = self.lookahead and next_targets is not None
+        if self._have_next:
+            self.in_hr_next.copy_(self.in_hr if next_targets is True else next_targets, non_blocking=True)
         self.host_step += 1
         if not self.use_graph:
             self._run_program("eager")
-            return
-        if self._segs is None:
-            self._capture()
-        self._replay()
+        else:
+            if self._segs is None:
+                self._capture()
+            self._replay()
+        self._next_ready = self._have_next
 
     def eval_losses(self, r_inputs, r_targets):
         """The loss scalars of `losses()` on a batch WITHOUT updating anything that training reads (reference main.py:391-402:
         the validation fetches every summary_freq steps).  Runs the step's program eagerly and skips the update segment:
         weights, Adam moments, the step counter and the balance average are untouched (the gradient buffer is overwritten --
         every training step clears it first -- and D's unused batch-norm moving statistics take one more update)."""
+        ready, have = self._next_ready, self._have_next
         self.set_batch(r_inputs, r_targets)
-        self._skip_update = True
+        self._skip_update, self._have_next = True, False        # (validation data: features in-step, none stored)
         try:
             self._run_program("eager")
         finally:
             self._skip_update = False
+        self._next_ready, self._have_next = ready, have         # the training stream's stored features are untouched
         torch.cuda.synchronize(self.dev)
         return self.losses()
 
@@ -222,8 +254,17 @@ class TrainEngine:
     # more than the overlap returns; single-stream graphs on two streams overlap as well as a forked graph does and
     # keep the 3.6 us node.  Memory: one graph pool per stream (segments of a stream replay in capture order, so reuse
     # inside a pool is safe; tensors that cross streams stay referenced in self._hold).
+    def _seg_on(self, name, skey, cond):
+        """Conditional segments (`cond`: a host predicate evaluated per step): captured always, replayed -- or, in the eager
+        program, executed -- only when cond() holds; a skipped segment counts as done.  Use as
+        `if self._seg_on(name, skey, cond): with self._seg(name, skey, after, cond=cond): ...`."""
+        if self._mode in ("eager", "flat") and not cond():
+            self._done[name] = (None, skey)
+            return False
+        return True
+
     @contextlib.contextmanager
-    def _seg(self, name, skey="M", after=()):
+    def _seg(self, name, skey="M", after=(), cond=None):
         deps = [d for d in after if d in self._done and self._done[d][1] != skey]
         if self._mode == "flat":                       # one stream, one graph (or plain eager): nothing to do
             self._done[name] = (None, "M")
@@ -232,7 +273,8 @@ class TrainEngine:
         if self._mode == "eager":
             st = self._main if skey == "M" else self.streams[skey]
             for d in deps:
-                st.wait_event(self._done[d][0])
+                if self._done[d][0] is not None:       # (None: a skipped conditional segment)
+                    st.wait_event(self._done[d][0])
             with torch.cuda.stream(st):
                 self._stamp(name, 0)
                 yield
@@ -246,7 +288,7 @@ class TrainEngine:
             self._stamp(name, 0)
             yield
             self._stamp(name, 1)
-        seg = dict(name=name, skey=skey, deps=deps, graph=g, fn=None, event=torch.cuda.Event())
+        seg = dict(name=name, skey=skey, deps=deps, graph=g, fn=None, event=torch.cuda.Event(), cond=cond)
         self._segs.append(seg)
         self._done[name] = (seg["event"], skey)
 
@@ -285,9 +327,13 @@ class TrainEngine:
         evs = {}
 
         def launch(seg):
+            if seg.get("cond") is not None and not seg["cond"]():
+                evs[seg["name"]] = None                 # skipped this step: nothing to wait for
+                return
             st = main if seg["skey"] == "M" else self.streams[seg["skey"]]
             for d in seg["deps"]:
-                st.wait_event(evs[d])
+                if evs[d] is not None:
+                    st.wait_event(evs[d])
             if st is main:
                 seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
             else:
@@ -299,7 +345,8 @@ class TrainEngine:
         for what, arg in plan_launch_order(self._segs, self.lazy_side):
             if what == "wait":
                 for d in arg:
-                    evs[d].synchronize()
+                    if evs[d] is not None:
+                        evs[d].synchronize()
             else:
                 launch(arg)
 
@@ -430,19 +477,20 @@ class TrainEngine:
         taps_t = None
         if self.use_vgg:
             sk, cx = part(1)
-            with seg("vggt", sk, ["head"]):
-                Tu = self.T0 if self.vggt_dedup else T                  # frames whose features are actually computed
-                xt = K.vgg_preprocess_forward(hr_seq[:Tu].view(Tu * B, H, H, 3),
-                                              torch.empty(Tu * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
-                taps_t, _ = self.V.forward(xt, keep=False, flags=cx)
-                if self.vggt_dedup:
-                    taps_u, taps_t = taps_t, {}
-                    for key, u in taps_u.items():                       # frame-major [Tu*B,...] -> [T*B,...] in sequence order
-                        full = torch.empty((T * B,) + tuple(u.shape[1:]), device=self.dev, dtype=u.dtype)
-                        K.seq_gather(u.view(1, Tu, -1).view(torch.float32), full.view(T, 1, -1).view(torch.float32), self.seq_idx)
-                        taps_t[key] = full
-                    hold.append(taps_u)
-            hold += [xt, taps_t]
+            Tu = self.T0 if self.vggt_dedup else T                      # frames whose features are actually computed
+            taps_t = self._alloc_taps(Tu)
+            in_step = (lambda: not self._next_ready) if self.lookahead else None
+            if in_step is None or self._seg_on("vggt", sk, in_step):
+                with seg("vggt", sk, ["head"], cond=in_step):
+                    xt = K.vgg_preprocess_forward(hr_seq[:Tu].view(Tu * B, H, H, 3),
+                                                  torch.empty(Tu * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+                    taps_u, _ = self.V.forward(xt, keep=False, flags=cx)
+                    self._spread_taps(taps_u, Tu)                       # frame-major [Tu*B,...] -> [T*B,...] in sequence order
+                    hold += [xt, taps_u]
+            if self.lookahead and self._seg_on("vggt_pre", sk, lambda: self._next_ready):
+                # the features were computed during the previous step's backward phase (segment vggt_next of that step)
+                with seg("vggt_pre", sk, ["head"], cond=lambda: self._next_ready):
+                    self._spread_taps(self._taps_next, Tu)
         if self.gan:
             sk, cx = part(2)
             with seg("dreal", sk, ["head"]):
@@ -478,7 +526,7 @@ class TrainEngine:
             forward_frames(0, tc if early_on_side else T)
         if self.use_vgg:
             sk, cx = part(4)
-            with seg("vgg_early", sk, ["fwd_a", "vggt"]):
+            with seg("vgg_early", sk, ["fwd_a", "vggt", "vggt_pre"]):
                 self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx if early_on_side else 0, zero=True)
         # ---- side: VGG pass of the LATE frames [tc, T) as ONE full-tile piece on the side stream, beside D's generator-side
         #      backward pass on the main stream (throughput work beside throughput work); the BPTT starts when both are done and
@@ -511,7 +559,7 @@ class TrainEngine:
             with seg("vgg_late", "S", ["fwd_b"]):
                 self._vgg_chunk(gen, taps_t, tc, T, _Shifted(self._d_vgg_late, tc), 0, zero=True)
 
-        with seg("fwd_b", "M", ["dreal", "vggt"]):
+        with seg("fwd_b", "M", ["dreal", "vggt", "vggt_pre"]):
             if early_on_side:
                 forward_frames(tc, T)
             d_gen = losses_and_fake_pass()
@@ -526,6 +574,17 @@ class TrainEngine:
                 self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
             self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
+        if self.lookahead and not self._skip_update and self._seg_on("vggt_next", "S", lambda: self._have_next):
+            # target lookahead: the NEXT batch's target features, beside this step's BPTT (the side stream idles there)
+            with seg("vggt_next", "S", [fwd_last], cond=lambda: self._have_next):
+                Tu = self.T0 if self.vggt_dedup else T
+                hn = K.seq_gather(self.in_hr_next, torch.empty(Tu, B, H, H, 3, device=self.dev), self.seq_idx[:Tu])
+                xn = K.vgg_preprocess_forward(hn.view(Tu * B, H, H, 3),
+                                              torch.empty(Tu * B, H, H, VGG_CPAD, device=self.dev, dtype=self.act_dtype))
+                taps_n, _ = self.V.forward(xn, keep=False, flags=K.CONV_COEXIST)
+                for key, u in taps_n.items():
+                    self._taps_next[key].copy_(u)
+                hold += [hn, xn, taps_n]
         # ---- backward through the recurrence ------------------------------------------------------------------
         d_flow_t = d_flow.view(T - 1, B, h, h, 2)
         tail_split = self.exchange_mode == "captured"    # the RCCL segments hook in after wgrad and after FNet's backward
@@ -564,6 +623,29 @@ class TrainEngine:
             with seg("fnet_bwd"):
                 self.Fn.backward(fsaved, d_flow)
             self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
+
+    def _alloc_taps(self, Tu):
+        """Persistent target-feature buffers: `_taps_t` [T*B,...] (what the VGG passes over the generated frames compare with)
+        and, with the lookahead, `_taps_next` [Tu*B,...] (the next batch's).  They cross steps, so they live outside the graph
+        pools (allocated in the eager warm-up run, before any capture)."""
+        if self._taps_t is None:
+            H, n = 4 * self.cs, self.T * self.B
+            dims = {VGG_TAPS[0]: (H // 2, 128), VGG_TAPS[1]: (H // 4, 256), VGG_TAPS[2]: (H // 8, 512), VGG_TAPS[3]: (H // 16, 512)}
+            mk = lambda m: {k: torch.empty(m, hw, hw, c, device=self.dev, dtype=self.act_dtype) for k, (hw, c) in dims.items()}   # noqa: E731
+            self._taps_t = mk(n)
+            if self.lookahead:
+                self._taps_next = mk(Tu * self.B)
+        return self._taps_t
+
+    def _spread_taps(self, taps_u, Tu):
+        """[Tu*B,...] features of the distinct target frames -> `_taps_t` [T*B,...] in sequence order (ping-pong mirror)."""
+        T = self.T
+        for key, u in taps_u.items():
+            full = self._taps_t[key]
+            if Tu == T:
+                full.copy_(u)
+            else:
+                K.seq_gather(u.view(1, Tu, -1).view(torch.float32), full.view(T, 1, -1).view(torch.float32), self.seq_idx)
 
     def _program_update(self):
         """Device-side schedule, the TF-Adams (D gated) and the refresh of the MFMA weight copies."""

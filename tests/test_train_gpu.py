@@ -170,6 +170,37 @@ def test_tecogan_three_steps_graph_and_gate():
     assert eng.global_step() == 3
 
 
+def test_target_lookahead_equals_in_step_target_features():
+    """TrainEngine target lookahead: `step(x, y, next_targets=y_next)` puts the NEXT batch's targets through VGG-19 during this
+    step's backward phase (segment vggt_next) and the next step starts from the stored features (vggt_pre) -- the same
+    features the in-step target pass (vggt) computes, one step earlier.  Three captured steps over three DIFFERENT batches,
+    with and without the lookahead: the same frames and losses (the fp32 atomics' noise apart); a validation pass in between
+    must not disturb the stored features; a step without an announcement falls back to the in-step pass."""
+    F = OT.default_flags(batch_size=1, RNN_N=3, crop_size=16, num_resblock=1)
+    batches = [make_batch(1, F.RNN_N, F.crop_size, seed=20 + i) for i in range(4)]
+    vx, vy = make_batch(1, F.RNN_N, F.crop_size, seed=99)
+    a = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True)
+    b = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True)
+    assert b.lookahead
+    ran = []
+    for i in range(3):
+        x, y = (t.to(DEV) for t in batches[i])
+        a.step(x, y)
+        announce = batches[i + 1][1].to(DEV) if i != 1 else None        # step 1 announces nothing: step 2 computes in-step
+        if i == 1:
+            b.eval_losses(vx.to(DEV), vy.to(DEV))                       # validation between two training steps
+        b.step(x, y, next_targets=announce)
+        torch.cuda.synchronize()
+        ran.append((b._next_ready,))
+        assert rel_err(b.gen, a.gen) < 1e-5, (i, rel_err(b.gen, a.gen))
+        la, lb = a.losses(), b.losses()
+        for k in ("vgg_loss_2", "vgg_loss_5", "l2_content_loss", "t_discrim_loss"):
+            assert abs(la[k] - lb[k]) <= 1e-4 * max(1.0, abs(la[k])), (i, k, la[k], lb[k])
+    assert ran == [(True,), (False,), (True,)]
+    names = [s["name"] for s in b._segs]
+    assert "vggt" in names and "vggt_pre" in names and "vggt_next" in names
+
+
 def test_tecogan_fading_in_adversarial_weight_stays_captured():
     """lib/Teco.py:379-380: dt_ratio = min(Dt_ratio_max, Dt_ratio_0 + Dt_ratio_add * global_step) scales the adversarial and
     layer losses.  The factor is a device scalar derived from the device-side step counter, so the step is CAPTURED (round 2

@@ -30,7 +30,7 @@ def main():
         if i == a.steps - 1:
             prev.copy_(eng.seg_stamps)          # on the main stream, between the two steps: the previous step's stamps
         h0 = time.perf_counter()
-        eng.step()
+        eng.step(**({"next_targets": True} if getattr(eng, "lookahead", False) else {}))
         host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     t = eng.seg_stamps.cpu().tolist()
