@@ -25,16 +25,6 @@ LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_
 LI = {n: i for i, n in enumerate(LOSS_NAMES)}
 
 
-class _Shifted:
-    """`x[t0:t1]` of a tensor whose first frame is frame `base` of the sequence (scratch buffers of a frame range)."""
-
-    def __init__(self, t, base):
-        self.t, self.base = t, base
-
-    def __getitem__(self, sl):
-        return self.t[sl.start - self.base:sl.stop - self.base]
-
-
 def plan_launch_order(segs, lazy=True):
     """Host-side order in which a step's captured segments are launched: yields ("launch", seg) and ("wait", [names]).
 
@@ -149,7 +139,7 @@ class TrainEngine:
         self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
         self.seg_stamp_names = {}
         self._pools = {}
-        self._done, self._mode, self._main, self._d_vgg, self._d_vgg_late = {}, "flat", None, None, None
+        self._done, self._mode, self._main, self._d_vgg = {}, "flat", None, None
         # the fade-in factor of the adversarial / layer losses (lib/Teco.py:379-380) is a DEVICE scalar derived from the
         # device-side step counter at the head of every step: Dt_ratio_add != 0 stays inside the captured graph
         self.dt_ratio = torch.ones(1, device=self.dev)
@@ -497,20 +487,26 @@ class TrainEngine:
                 gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
                                                     gd["merge"])
                 gd["p_real"], gd["l_real"], gd["sv_real"] = self.D.forward(gd["real"], flags=cx)
-        # ---- recurrent generator (lib/Teco.py:125-155); side: VGG pass of the early frames ----------------------
+        # ---- recurrent generator (lib/Teco.py:125-155) in CHUNKS of frames; side: the VGG pass (forward, cosine loss against the
+        #      target features, input gradient) of every chunk as soon as its frames exist, beside the forward recurrence of
+        #      the next chunk -- the last one beside the loss / D work.
+        # Chunking history: round 2/3 used ONE cut a little past the middle (11 + 8 of 19 frames; several early chunks measured
+        # slower then, profiles/r03x_ab.txt: the side stream was full anyway -- target pass, D real pass, then the generated
+        # frames -- and every extra chunk cost ~0.35 ms of fixed VGG-pass cost).  With the target pass moved to the previous
+        # step's backward phase (lookahead) the side stream idles until the first chunk arrives, and what is exposed before the
+        # BPTT is the LAST chunk's VGG pass: chunks of ~5 frames start the passes early and leave 4 frames at the end
+        # (TG_VGG_CUTS="5,10,15" for 19 frames is the default; "11" restores the old schedule).
+        # (Schedules measured and rejected in round 3, profiles/r03c_ab.txt, r03e_ab.txt: VGG passes of frame-DESCENDING pieces
+        #  beside the BPTT of the frames above them, FNet's backward pass / the generator's weight gradients of the late frames
+        #  beside the BPTT of the early ones.  The last chunk's pass on the side stream beside D's generator-side backward pass
+        #  on the main stream was that round's one gain: 12.87 -> 12.68 ms.)
         gen = torch.empty(T, B, H, H, 3, device=self.dev) if self.gen is None else self.gen
         self.gen = gen
-        # frames [0, tc): early chunk (VGG pass on the side stream, beside the forward recurrence of the LATER frames),
-        # [tc, T): late frames.  One cut a little past the middle (19 frames: 11 early + 8 late measured 12.28 ms against 12.51 at
-        # 10 + 9 and 12.5-12.7 at 12..14, profiles/r02x_ab.txt: the early chunk has the forward pass to hide in).
-        tc = (min((T + 3) // 2, T - 1) if T > 1 else T) if self.use_vgg else T
-        # (SEVERAL early chunks -- cuts at 6/12/15, 5/10/15, 7/13/16, 6/11/14/17 frames, each chunk's VGG pass beside the next
-        #  forward segment and only 4 / 3 / 2 frames left exposed -- measured 11.94-12.75 ms against 11.70-11.80 for the one
-        #  cut, profiles/r03x_ab.txt: a VGG pass costs ~0.35 ms + 41 us per image alone and 1.3 ms beside the chain whatever
-        #  its size from 12 to 24 images, so every extra chunk costs more than the exposure it removes.)
+        cuts = [0] + (self._vgg_cuts(T) if self.use_vgg else []) + [T]
+        chunks = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
         d_vgg = None
         if self.use_vgg:
-            d_vgg = self._d_vgg = (torch.empty(tc, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
+            d_vgg = self._d_vgg = (torch.empty(T, B, H, H, 3, device=self.dev) if self._d_vgg is None else self._d_vgg)
 
         def forward_frames(t0, t1):
             for t in range(t0, t1):
@@ -519,25 +515,21 @@ class TrainEngine:
                 self.G.forward_t(t, gen[t])
 
         split = self._mode != "flat"
-        early_on_side = self.use_vgg and bool(self.ov_parts & 4) and split
-        with seg("fwd_a"):
-            if self.G.seq is None or self._mode != "capture":
-                self.G.begin_sequence(T, B, h, h, self.dev)
-            forward_frames(0, tc if early_on_side else T)
-        if self.use_vgg:
-            sk, cx = part(4)
-            with seg("vgg_early", sk, ["fwd_a", "vggt", "vggt_pre"]):
-                self._vgg_chunk(gen, taps_t, 0, tc, d_vgg, cx if early_on_side else 0, zero=True)
-        # ---- side: VGG pass of the LATE frames [tc, T) as ONE full-tile piece on the side stream, beside D's generator-side
-        #      backward pass on the main stream (throughput work beside throughput work); the BPTT starts when both are done and
-        #      D's own-gradient passes run beside it.  Measured (same box, profiles/r03e_ab.txt): 12.87 -> 12.68 ms against the
-        #      late pass on the main stream.  Frame-DESCENDING pieces of 1 / 2 / 4 frames beside the BPTT of the frames above
-        #      them were slower (16.3 / 13.8 / 12.85 ms, profiles/r03c_ab.txt: a 2-frame VGG pass takes 0.95 ms beside the chain
-        #      against 0.36 ms pro rata), and so were FNet's backward pass / the generator's weight gradients of the late frames
-        #      beside the BPTT of the early ones (neutral: their launches are latency-bound, two half-batch passes cost twice).
-        late_on_side = self.use_vgg and bool(self.ov_parts & 64) and split and T > tc
-        # (the late VGG pass started already beside the loss / D-fake-pass work -- its own segment `fwd_c`, overlap bit 128 --
-        #  measured neutral in round 4: 10.98 / 10.99 against 11.00 ms, profiles/r04a_ab.txt; removed)
+        vgg_segs = []
+        for k, (t0, t1) in enumerate(chunks):
+            fname = "fwd_%d" % k
+            with seg(fname):
+                if k == 0 and (self.G.seq is None or self._mode != "capture"):
+                    self.G.begin_sequence(T, B, h, h, self.dev)
+                forward_frames(t0, t1)
+            if self.use_vgg:
+                last = k == len(chunks) - 1 and k > 0
+                # (bit 4: the chunks that run beside the forward chain, with co-residency-friendly tiles; bit 64: the last chunk,
+                #  beside the loss / D work -- throughput beside throughput, full tiles)
+                on_side = split and bool(self.ov_parts & (64 if last else 4))
+                with seg("vgg_%d" % k, "S" if on_side else "M", [fname, "vggt", "vggt_pre"]):
+                    self._vgg_chunk(gen, taps_t, t0, t1, d_vgg, K.CONV_COEXIST if (on_side and not last) else 0, zero=True)
+                vgg_segs.append("vgg_%d" % k)
 
         def losses_and_fake_pass():
             # ---- generator losses seeded into d_gen -------------------------------------------------------
@@ -553,20 +545,10 @@ class TrainEngine:
                 self._gan_losses(gd)
             return d_gen
 
-        def late_vgg_pass():
-            if self._d_vgg_late is None:
-                self._d_vgg_late = torch.empty(T - tc, B, H, H, 3, device=self.dev)
-            with seg("vgg_late", "S", ["fwd_b"]):
-                self._vgg_chunk(gen, taps_t, tc, T, _Shifted(self._d_vgg_late, tc), 0, zero=True)
-
-        with seg("fwd_b", "M", ["dreal", "vggt", "vggt_pre"]):
-            if early_on_side:
-                forward_frames(tc, T)
+        with seg("fwd_loss", "M", ["dreal", "vggt", "vggt_pre"]):
             d_gen = losses_and_fake_pass()
-        if late_on_side:
-            late_vgg_pass()
         hold.append(d_gen)
-        fwd_last = "fwd_b"                                       # the segment D's passes and the losses are complete in
+        fwd_last = "fwd_loss"                                    # the segment D's passes and the losses are complete in
         if self.gan:
             sk, cx = part(8)
             with seg("down", sk, [fwd_last]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
@@ -596,20 +578,16 @@ class TrainEngine:
                 if t > 0:
                     K.warp_s2d_backward(dx_in, gen[t - 1], flow_t[t - 1], d_gen[t - 1], d_flow_t[t - 1], 0.5)
 
-        if self.gan or (self.use_vgg and not late_on_side and T > tc):
+        if self.gan:
             with seg("bwd", "M", []):
-                if self.gan:   # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
-                    dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
-                    K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
-                                            gd["off"], gd["merge"])
-                    hold.append(dx)
-                if self.use_vgg and not late_on_side and T > tc:          # the late frames on the main stream: straight into d_gen
-                    self._vgg_chunk(gen, taps_t, tc, T, d_gen, 0, zero=False)
-        with seg("bwd_b", "M", ["vgg_early", "vgg_late"]):
-            if late_on_side:
-                K.lincomb(self._d_vgg_late, None, d_gen[tc:], 1.0, 0.0, accumulate=True)
+                # generator-side gradient through the fake pass (adversarial + layer loss): no D weight gradients
+                dx = self.D.backward(gd["sv_fake"], gd["d_fake_G"], gd["d_layers"], wgrad=False, need_dx=True)
+                K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
+                                        gd["off"], gd["merge"])
+                hold.append(dx)
+        with seg("bwd_b", "M", vgg_segs):
             if self.use_vgg:
-                K.lincomb(d_vgg, None, d_gen[:tc], 1.0, 0.0, accumulate=True)      # early frames (computed beside the chain)
+                K.lincomb(d_vgg, None, d_gen, 1.0, 0.0, accumulate=True)           # the chunks' perceptual-loss gradients
             backward_frames(T, 0)
             if not tail_split and not gw_side:
                 self.G.wgrad_sequence(0, T)
@@ -623,6 +601,19 @@ class TrainEngine:
             with seg("fnet_bwd"):
                 self.Fn.backward(fsaved, d_flow)
             self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
+
+    @staticmethod
+    def _vgg_cuts(T):
+        """Frame indices at which the forward recurrence is cut into chunks for the VGG passes (see _program_compute)."""
+        env = os.environ.get("TG_VGG_CUTS")
+        if env is not None:
+            return sorted({int(c) for c in env.split(",") if c.strip() and 0 < int(c) < T})
+        if T <= 6:
+            return []
+        cuts = list(range(5, T, 5))
+        if T - cuts[-1] < 3:
+            cuts.pop()
+        return cuts
 
     def _alloc_taps(self, Tu):
         """Persistent target-feature buffers: `_taps_t` [T*B,...] (what the VGG passes over the generated frames compare with)

@@ -282,12 +282,26 @@ def _segs(spec):
     return [dict(name=n, skey=k, deps=list(d)) for n, k, d in spec]
 
 
-# the round-3 TecoGAN schedule (engine._program_compute, TG_OVERLAP_PARTS default) with a process group
-TECO_SEGS = [("head", "M", []), ("vggt", "S", ["head"]), ("dreal", "S", ["head"]), ("fwd_a", "M", []),
-             ("vgg_early", "S", ["fwd_a"]), ("fwd_b", "M", ["dreal", "vggt"]), ("vgg_late", "S", ["fwd_b"]),
-             ("down", "S", ["fwd_b"]), ("ar_d", "C", ["down"]), ("bwd", "M", []), ("bwd_b", "M", ["vgg_early", "vgg_late"]),
+# the round-4 TecoGAN schedule (engine._program_compute, TG_OVERLAP_PARTS default, 19 frames in chunks of 5 / 5 / 5 / 4, target
+# lookahead) with a process group; "vggt" (in-step target pass), "vggt_pre" (stored features) and "vggt_next" are CONDITIONAL
+TECO_SEGS = [("head", "M", []), ("vggt", "S", ["head"]), ("vggt_pre", "S", ["head"]), ("dreal", "S", ["head"]),
+             ("fwd_0", "M", []), ("vgg_0", "S", ["fwd_0"]), ("fwd_1", "M", []), ("vgg_1", "S", ["fwd_1"]),
+             ("fwd_2", "M", []), ("vgg_2", "S", ["fwd_2"]), ("fwd_3", "M", []), ("vgg_3", "S", ["fwd_3"]),
+             ("fwd_loss", "M", ["dreal", "vggt", "vggt_pre"]), ("down", "S", ["fwd_loss"]), ("ar_d", "C", ["down"]),
+             ("vggt_next", "S", ["fwd_loss"]), ("bwd", "M", []), ("bwd_b", "M", ["vgg_0", "vgg_1", "vgg_2", "vgg_3"]),
              ("wgrad", "S", ["bwd_b"]), ("ar_g", "C", ["wgrad"]), ("fnet_bwd", "M", []), ("ar_f", "C", ["fnet_bwd"]),
              ("update", "M", ["down", "wgrad", "ar_d", "ar_g", "ar_f"])]
+
+
+def test_vgg_chunk_cuts_default_and_override(monkeypatch):
+    from tecogan_amd.engine import TrainEngine
+    monkeypatch.delenv("TG_VGG_CUTS", raising=False)
+    assert TrainEngine._vgg_cuts(19) == [5, 10, 15] and TrainEngine._vgg_cuts(10) == [5]
+    assert TrainEngine._vgg_cuts(7) == [] and TrainEngine._vgg_cuts(5) == [] and TrainEngine._vgg_cuts(3) == []
+    monkeypatch.setenv("TG_VGG_CUTS", "11")
+    assert TrainEngine._vgg_cuts(19) == [11] and TrainEngine._vgg_cuts(5) == []
+    monkeypatch.setenv("TG_VGG_CUTS", "")
+    assert TrainEngine._vgg_cuts(19) == []
 
 
 def test_plan_launch_order_just_in_time_side_segments():
@@ -315,7 +329,7 @@ def test_plan_launch_order_just_in_time_side_segments():
                 if dict((n, k) for n, k, _ in TECO_SEGS)[d] == "M" and d != "fnet_bwd":
                     later_m = [n for n in launched[launched.index(d) + 1:] if dict((n, k) for n, k, _ in TECO_SEGS)[n] == "M"]
                     assert later_m, "host would wait for %s with nothing queued behind it" % d
-    assert order[:2] == ["head", "fwd_a"]                     # the forward recurrence is queued before the first wait
+    assert order[:2] == ["head", "fwd_0"]                     # the forward recurrence is queued before the first wait
 
 
 def test_plan_launch_order_program_order_when_not_lazy():
@@ -373,18 +387,28 @@ def test_engine_replay_executes_the_plan_with_streams_and_events(monkeypatch):
 
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: current[-1])
     monkeypatch.setattr(torch.cuda, "stream", stream_ctx)
-    segs = [dict(name=n, skey=k, deps=list(d), graph=Graph(n), fn=None, event=Event(n)) for n, k, d in TECO_SEGS]
-    for lazy in (True, False):
+    # conditional segments: a steady-state step with the target lookahead replays "vggt_pre" and "vggt_next", not "vggt"
+    state = {"ready": True, "have": True}
+    conds = {"vggt": lambda: not state["ready"], "vggt_pre": lambda: state["ready"], "vggt_next": lambda: state["have"]}
+    segs = [dict(name=n, skey=k, deps=list(d), graph=Graph(n), fn=None, event=Event(n), cond=conds.get(n)) for n, k, d in TECO_SEGS]
+    for lazy, ready in ((True, True), (False, True), (True, False)):
         del log[:]
+        state["ready"] = state["have"] = ready
+        skipped = {"vggt"} if ready else {"vggt_pre", "vggt_next"}
         eng = types.SimpleNamespace(_segs=segs, streams={"S": side, "C": comm}, lazy_side=lazy)
         TrainEngine._replay(eng)
         replays = [e for e in log if e[0] == "replay"]
-        assert sorted(r[1] for r in replays) == sorted(n for n, _, _ in TECO_SEGS)
+        assert sorted(r[1] for r in replays) == sorted(n for n, _, _ in TECO_SEGS if n not in skipped)
         for _, name, st in replays:                             # on its own stream
             assert st == dict((n, k) for n, k, _ in TECO_SEGS)[name]
         for n, k, deps in TECO_SEGS:
+            if n in skipped:
+                continue
             i = log.index(("replay", n, k))
             for d in deps:
+                if d in skipped:                                # a skipped segment is nothing to wait for
+                    assert ("stream_wait", k, d) not in log and ("host_wait", d) not in log
+                    continue
                 if dict((a, b) for a, b, _ in TECO_SEGS)[d] != k or True:
                     assert ("stream_wait", k, d) in log[:i], (n, d)          # device-side wait before the replay
                     assert log.index(("record", d, dict((a, b) for a, b, _ in TECO_SEGS)[d])) < log.index(("stream_wait", k, d))

@@ -46,9 +46,7 @@ def collect(eng):
             out["fwd/D layer %d fake" % i] = t
         out["bwd/D seed d_fake_G"] = gd["d_fake_G"]
     if eng.use_vgg:
-        out["bwd/d_vgg early frames"] = eng._d_vgg
-        if eng._d_vgg_late is not None:
-            out["bwd/d_vgg late frames"] = eng._d_vgg_late
+        out["bwd/d_vgg (perceptual-loss gradient, all frames)"] = eng._d_vgg
     d_gen = [h for h in hold if torch.is_tensor(h) and h.shape == eng.gen.shape and h is not eng.gen]
     if d_gen:
         out["bwd/d_gen (after BPTT: loss seeds + recurrent terms)"] = d_gen[-1]
