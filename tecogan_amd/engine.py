@@ -490,12 +490,9 @@ class TrainEngine:
         # ---- recurrent generator (lib/Teco.py:125-155) in CHUNKS of frames; side: the VGG pass (forward, cosine loss against the
         #      target features, input gradient) of every chunk as soon as its frames exist, beside the forward recurrence of
         #      the next chunk -- the last one beside the loss / D work.
-        # Chunking history: round 2/3 used ONE cut a little past the middle (11 + 8 of 19 frames; several early chunks measured
-        # slower then, profiles/r03x_ab.txt: the side stream was full anyway -- target pass, D real pass, then the generated
-        # frames -- and every extra chunk cost ~0.35 ms of fixed VGG-pass cost).  With the target pass moved to the previous
-        # step's backward phase (lookahead) the side stream idles until the first chunk arrives, and what is exposed before the
-        # BPTT is the LAST chunk's VGG pass: chunks of ~5 frames start the passes early and leave 4 frames at the end
-        # (TG_VGG_CUTS="5,10,15" for 19 frames is the default; "11" restores the old schedule).
+        # The cuts are `_vgg_cuts(T)` (TG_VGG_CUTS overrides): one cut a little past the middle; more, smaller chunks start the
+        # passes earlier but lose more to the fixed cost of a pass than they gain (round 3: profiles/r03x_ab.txt; round 4 with the
+        # shorter chain and the target lookahead: profiles/r04f_ab.txt).
         # (Schedules measured and rejected in round 3, profiles/r03c_ab.txt, r03e_ab.txt: VGG passes of frame-DESCENDING pieces
         #  beside the BPTT of the frames above them, FNet's backward pass / the generator's weight gradients of the late frames
         #  beside the BPTT of the early ones.  The last chunk's pass on the side stream beside D's generator-side backward pass
@@ -608,12 +605,11 @@ class TrainEngine:
         env = os.environ.get("TG_VGG_CUTS")
         if env is not None:
             return sorted({int(c) for c in env.split(",") if c.strip() and 0 < int(c) < T})
-        if T <= 6:
-            return []
-        cuts = list(range(5, T, 5))
-        if T - cuts[-1] < 3:
-            cuts.pop()
-        return cuts
+        # ONE cut a little past the middle (19 frames: 11 + 8).  Round 4 re-measured the alternatives with the shorter chain and
+        # the target lookahead (profiles/r04f_ab.txt, one box): 11 -> 9.19 ms; 6,12 -> 9.28; 7,14 -> 9.45; 8,14 -> 9.53;
+        # 5,10,15 -> 10.03; 4,8,12,16 -> 10.48.  A VGG pass has ~0.4 ms of fixed cost (60 launches, half of them latency-bound)
+        # and its small layers need >= 32 images to fill the chip: 20-image passes run at 69 us per image, 44-image ones at 52.
+        return [min((T + 3) // 2, T - 1)] if T > 1 else []
 
     def _alloc_taps(self, Tu):
         """Persistent target-feature buffers: `_taps_t` [T*B,...] (what the VGG passes over the generated frames compare with)

@@ -296,10 +296,10 @@ TECO_SEGS = [("head", "M", []), ("vggt", "S", ["head"]), ("vggt_pre", "S", ["hea
 def test_vgg_chunk_cuts_default_and_override(monkeypatch):
     from tecogan_amd.engine import TrainEngine
     monkeypatch.delenv("TG_VGG_CUTS", raising=False)
-    assert TrainEngine._vgg_cuts(19) == [5, 10, 15] and TrainEngine._vgg_cuts(10) == [5]
-    assert TrainEngine._vgg_cuts(7) == [] and TrainEngine._vgg_cuts(5) == [] and TrainEngine._vgg_cuts(3) == []
-    monkeypatch.setenv("TG_VGG_CUTS", "11")
-    assert TrainEngine._vgg_cuts(19) == [11] and TrainEngine._vgg_cuts(5) == []
+    assert TrainEngine._vgg_cuts(19) == [11] and TrainEngine._vgg_cuts(10) == [6] and TrainEngine._vgg_cuts(3) == [2]
+    assert TrainEngine._vgg_cuts(1) == []
+    monkeypatch.setenv("TG_VGG_CUTS", "5,10,15")
+    assert TrainEngine._vgg_cuts(19) == [5, 10, 15] and TrainEngine._vgg_cuts(5) == []
     monkeypatch.setenv("TG_VGG_CUTS", "")
     assert TrainEngine._vgg_cuts(19) == []
 
