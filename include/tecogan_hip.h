@@ -225,6 +225,16 @@ int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const 
  * HWIO fp32 tensor in src_base, offset (elements) of its 36864-element copy in dst_t / dst_n. */
 int tg_pack_weights_frag(const float* src_base, void* dst_t, void* dst_n, const int64_t* tab, int count, void* stream);
 
+/* Input-gradient chain of generator_F's HR tail (reference lib/frvsr.py:73-87 under tf.gradients, lib/Teco.py:441-449) as ONE
+ * launch, latency regime of the training recurrence (csrc/hr_bwd_lat.hip; bf16, 64 channels):
+ *     g_out = bf16(scale * d_frame), 3 channels zero-padded to 8        [N,2H2,2W2,8]    (what tg_concat2_pad wrote)
+ *     g_t2  = bwd_data(output_stage conv 64 -> 3)(g_out) * relu'(t2)   [N,2H2,2W2,64]   (bit-identical to tg_conv_forward's)
+ *     g_t1  = bwd_data(conv_tran2, k3 s2)(g_t2) * relu'(t1)            [N,H2,W2,64]
+ * d_frame [N,2H2,2W2,3] fp32; w_out = the output conv's HWIO weights with the 3 outputs padded to 8 ([9][64][8], the natural
+ * compute copy); w_tr_frag = conv_tran2's [tap][in][out] operand in FRAGMENT order (tg_pack_weights_frag, dst_t). */
+int tg_hr_tail_backward(const float* d_frame, float scale, const void* w_out, const void* t2, const void* w_tr_frag,
+                        const void* t1, void* g_out, void* g_t2, void* g_t1, int N, int H2, int W2, void* stream);
+
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.
  * d_out and y share in_dtype; d_in has out_dtype. */

@@ -183,6 +183,15 @@ def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out, w_frag=False):
     return out
 
 
+def hr_tail_backward(d_frame, scale, w_out, t2, w_tr_frag, t1, g_out, g_t2, g_t1):
+    """Frame gradient -> g_out, g_t2, g_t1 in one launch (csrc/hr_bwd_lat.hip; bf16): see tg_hr_tail_backward."""
+    N, H2, W2, C = t1.shape
+    assert C == 64 and t1.dtype == torch.bfloat16 and d_frame.dtype == torch.float32
+    check(lib().tg_hr_tail_backward(_p(d_frame), float(scale), _p(w_out), _p(t2), _p(w_tr_frag), _p(t1), _p(g_out), _p(g_t2),
+                                    _p(g_t1), N, H2, W2, _stream()), "tg_hr_tail_backward")
+    return g_t1
+
+
 def pack_weights_frag(src_base, dst_t, dst_n, tab, count):
     check(lib().tg_pack_weights_frag(_p(src_base), _p(dst_t), _p(dst_n), _p(tab), count, _stream()), "tg_pack_weights_frag")
 

@@ -149,6 +149,8 @@ class Generator:
         # TG_RESBLOCK_LAT=0 is the A/B switch (two tg_conv_forward launches per block, bit-identical results)
         self.resblock_lat = os.environ.get("TG_RESBLOCK_LAT", "1") == "1"
         self.resblock_max_tiles = int(os.environ.get("TG_RESBLOCK_LAT_MAX_TILES", "1024"))
+        # the BPTT's HR tail (frame gradient -> g_out -> g_t2 -> g_t1) as one launch; TG_HR_BWD_LAT=0 is the A/B switch
+        self.hr_bwd_lat = os.environ.get("TG_HR_BWD_LAT", "1") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -245,12 +247,17 @@ class Generator:
         """bwd_data chain of frame t (no weight gradients here).  Returns d x_in [B,h,w,56] or None."""
         ps, p, q, n = self.ps, self.P, self.seq, self.nres
         h, w = q["h"], q["w"]
-        dc = K.concat2_pad(d_out, None, q["g_out"][t], scale=2.0)                              # d/dc of (.)*2-1
         cf = self.chain_flags
-        g = conv_bwd_data(ps, p + "output_stage/conv/Conv/weights", dc, (4 * h, 4 * w), 1, aux=q["t2"][t],
-                          mask_act=ACT_RELU, out=q["g_t2"][t], flags=cf)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
-        g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=q["t1"][t], mask_act=ACT_RELU, out=q["g_t1"][t], flags=cf)
+        if self._fused_blocks() and self.hr_bwd_lat:
+            # frame gradient -> g_out, g_t2 (both kept for the weight gradients) and g_t1 in ONE launch (csrc/hr_bwd_lat.hip)
+            g = K.hr_tail_backward(d_out, 2.0, ps.packed(p + "output_stage/conv/Conv/weights", False), q["t2"][t],
+                                   ps.packed_frag(s % 2 + "weights", True), q["t1"][t], q["g_out"][t], q["g_t2"][t], q["g_t1"][t])
+        else:
+            dc = K.concat2_pad(d_out, None, q["g_out"][t], scale=2.0)                          # d/dc of (.)*2-1
+            g = conv_bwd_data(ps, p + "output_stage/conv/Conv/weights", dc, (4 * h, 4 * w), 1, aux=q["t2"][t],
+                              mask_act=ACT_RELU, out=q["g_t2"][t], flags=cf)
+            g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=q["t1"][t], mask_act=ACT_RELU, out=q["g_t1"][t], flags=cf)
         g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t], flags=cf)
         if n == 0:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)

@@ -168,12 +168,13 @@ class ParamStore:
         self.wN = torch.zeros(max(poff, 8), device=device, dtype=act_dtype)
         self.table = torch.tensor(rows, dtype=torch.int64, device=device).contiguous()
         self.ntab = len(rows)
-        # fragment-order copies of the generator's residual-block convs (64 -> 64, 3x3) for the one-launch block kernel
-        # (csrc/resblock_lat.hip; bf16 compute copies only): forward operand in wTf, input-gradient operand in wNf
+        # fragment-order copies of the generator's residual-block convs and transposed convs (64 -> 64, 3x3) for the
+        # latency-regime kernels (csrc/resblock_lat.hip, hr_bwd_lat.hip; bf16 compute copies only): the [tap][out][in]-style
+        # operand (dst_t: row = the tensor's LAST axis) in wTf, the [tap][in][out]-style one in wNf
         self.frag = OrderedDict()
         if act_dtype == torch.bfloat16:
             for name, e in self.entries.items():
-                if "/resblock_" in name and e.get("taps") == 9 and e["A"] == 64 and e["B"] == 64:
+                if ("/resblock_" in name or "/conv_tran" in name) and e.get("taps") == 9 and e["A"] == 64 and e["B"] == 64:
                     self.frag[name] = len(self.frag) * 36864
         nf = len(self.frag)
         self.wTf = torch.zeros(max(nf * 36864, 8), device=device, dtype=torch.bfloat16)

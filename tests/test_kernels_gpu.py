@@ -1269,3 +1269,49 @@ def test_pack_weights_frag_matches_the_host_permutation_of_both_operands():
             assert torch.equal(ps.packed_frag(name, tr).view(torch.int16), K.frag_order(rows).view(torch.int16)), (name, tr)
     assert ps.packed_frag("generator/generator_unit/input_stage/conv/Conv/weights", True) is None
     assert not P.ParamStore(OrderedDict(generator=P.generator_spec(1)), DEV, torch.float32).frag        # bf16 compute copies only
+
+
+# ---- csrc/hr_bwd_lat.hip: the BPTT's HR tail (frame gradient -> g_out -> g_t2 -> g_t1) as one launch -----------------------
+@pytest.mark.parametrize("shape", [(4, 64, 64), (1, 8, 8), (2, 6, 10), (1, 4, 8), (3, 5, 7), (1, 12, 24)])
+def test_hr_tail_backward_one_launch_matches_the_three_launches_and_autograd(shape):
+    """lib/frvsr.py:73-87 under tf.gradients: frame gradient -> (.)*2 -> output conv (64 -> 3) -> relu'(t2) -> conv_tran2 (k3 s2)
+    -> relu'(t1).  One launch (tg_hr_tail_backward) against the three it replaces (tg_concat2_pad, tg_conv_forward in
+    input-gradient form on the 8-channel kernel, tg_conv_forward in gather form): g_out and g_t2 bit for bit, g_t1 to bf16
+    rounding (another kernel's accumulation order), and all three against autograd on the bf16-rounded operands."""
+    N, H2, W2 = shape
+    Ho, Wo = 2 * H2, 2 * W2
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    d_frame = rnd(N, Ho, Wo, 3, seed=1, scale=0.01)
+    w_out = bf(rnd(3, 3, 64, 3, seed=2, scale=0.1))                       # HWIO
+    w_tr = bf(rnd(3, 3, 64, 64, seed=3, scale=0.1))                       # TF conv2d_transpose layout [kh,kw,Cout,Cin]
+    t2, t1 = bf(rnd(N, Ho, Wo, 64, seed=4)), bf(rnd(N, H2, W2, 64, seed=5))
+    dev16 = lambda t: t.to(DEV, torch.bfloat16).contiguous()             # noqa: E731
+    # compute copies as ParamStore packs them: output conv natural copy [tap][in][out pad 8]; conv_tran2 [tap][in][out] = wT
+    wo_n = torch.zeros(9, 64, 8)
+    wo_n[:, :, :3] = w_out.reshape(9, 64, 3)
+    wo_n = dev16(wo_n)
+    wtr_t = dev16(w_tr.reshape(9, 64, 64).permute(0, 2, 1))              # [tap][cin][cout]
+    dfd, t2d, t1d = d_frame.to(DEV), dev16(t2), dev16(t1)
+    # the three launches
+    g_out_ref = K.concat2_pad(dfd, None, torch.empty(N, Ho, Wo, 8, device=DEV, dtype=torch.bfloat16), scale=2.0)
+    dA = K.conv_desc(N, Ho, Wo, 8, Ho, Wo, 64, 3, 3, 1, 1, 1, 1, TG_BF16, TG_BF16, 0, 0.0, ACT_RELU, 0.0)
+    g_t2_ref = torch.empty(N, Ho, Wo, 64, device=DEV, dtype=torch.bfloat16)
+    K.conv_forward(dA, g_out_ref, wo_n, None, None, t2d, g_t2_ref)
+    dB = K.conv_desc(N, Ho, Wo, 64, H2, W2, 64, 3, 3, 2, 0, 0, 0, TG_BF16, TG_BF16, 0, 0.0, ACT_RELU, 0.0)
+    g_t1_ref = torch.empty(N, H2, W2, 64, device=DEV, dtype=torch.bfloat16)
+    K.conv_forward(dB, g_t2_ref, wtr_t, None, None, t1d, g_t1_ref)
+    # one launch
+    g_out, g_t2, g_t1 = (torch.full_like(t, 7.0) for t in (g_out_ref, g_t2_ref, g_t1_ref))
+    K.hr_tail_backward(dfd, 2.0, wo_n, t2d, K.frag_order(wtr_t), t1d, g_out, g_t2, g_t1)
+    torch.cuda.synchronize()
+    assert torch.equal(g_out.view(torch.int16), g_out_ref.view(torch.int16)), "g_out differs"
+    assert torch.equal(g_t2.view(torch.int16), g_t2_ref.view(torch.int16)), "g_t2 differs from the 8-channel kernel's"
+    close(g_t1, g_t1_ref.float(), 1e-2, "g_t1 vs the gather-form kernel %s" % (shape,))
+    # autograd on the bf16-rounded operands
+    x2 = torch.zeros(N, Ho, Wo, 64, requires_grad=True)
+    O.conv2(x2, w_out, None, 1).backward(bf(2.0 * d_frame))
+    gt2_o = bf(x2.grad * (t2 > 0).float())
+    close(g_t2, gt2_o, 1e-2, "g_t2 vs autograd %s" % (shape,))
+    x1 = torch.zeros(N, H2, W2, 64, requires_grad=True)
+    O.conv2_tran(x1, w_tr, None, 2).backward(gt2_o)
+    close(g_t1, x1.grad * (t1 > 0).float(), 1e-2, "g_t1 vs autograd %s" % (shape,))

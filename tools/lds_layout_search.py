@@ -38,19 +38,24 @@ def check(tiles, Ri, P, swz):
                     w,tt = conflicts(addrs)
                     worst=max(worst,w); tot+=tt; n+=4
     return worst, tot/n
-swzs = {"none": lambda y,x:0, "x&1": lambda y,x:x&1, "y&1": lambda y,x:y&1, "(x^y)&1": lambda y,x:(x^y)&1,
-        "x&3": lambda y,x:x&3, "y&3":lambda y,x:y&3, "(y&1)*2": lambda y,x:(y&1)*2, "(y&3)*2": lambda y,x:(y&3)*2 & 7,
-        "(y&1)*2+(x&1)": lambda y,x:(y&1)*2+(x&1), "(y&1)*4": lambda y,x:(y&1)*4, "(y&1)*4 ^ (x&1)": lambda y,x:((y&1)*4)^(x&1),
-        "y&7": lambda y,x:y&7, "(y*2)&7 ^ (x&1)": lambda y,x: ((y*2)&7)^(x&1), "(y>>1&1)*2": lambda y,x:((y>>1)&1)*2}
-def t44(): return [[(f>>2, f&3) for f in range(16)]]
-def t28(rows): return [[(2*t+(f>>3), f&7) for f in range(16)] for t in range(rows//2)]
-def t116(rows): return [[(t, f) for f in range(16)] for t in range(rows)]
-shapes = {"4x4 (So=4)": t44(), "2x8 x3 (So=6)": t28(6), "2x8 x4 (So=8)": t28(8), "2x8x5 + (So=10, 2 tiles per row pair)": None}
-for name, tiles in shapes.items():
-    if tiles is None: continue
-    print("==", name)
-    for Ri in range(6, 21):
-        for P in (128,144,160,176,192):
-            for sn, f in swzs.items():
-                w, avg = check(tiles, Ri, P, f)
-                if w==1: print("  Ri=%d P=%d swz=%s OK" % (Ri,P,sn))
+def main():
+    swzs = {"none": lambda y,x:0, "x&1": lambda y,x:x&1, "y&1": lambda y,x:y&1, "(x^y)&1": lambda y,x:(x^y)&1,
+            "x&3": lambda y,x:x&3, "y&3":lambda y,x:y&3, "(y&1)*2": lambda y,x:(y&1)*2, "(y&3)*2": lambda y,x:(y&3)*2 & 7,
+            "(y&1)*2+(x&1)": lambda y,x:(y&1)*2+(x&1), "(y&1)*4": lambda y,x:(y&1)*4, "(y&1)*4 ^ (x&1)": lambda y,x:((y&1)*4)^(x&1),
+            "y&7": lambda y,x:y&7, "(y*2)&7 ^ (x&1)": lambda y,x: ((y*2)&7)^(x&1), "(y>>1&1)*2": lambda y,x:((y>>1)&1)*2}
+    def t44(): return [[(f>>2, f&3) for f in range(16)]]
+    def t28(rows): return [[(2*t+(f>>3), f&7) for f in range(16)] for t in range(rows//2)]
+    def t116(rows): return [[(t, f) for f in range(16)] for t in range(rows)]
+    shapes = {"4x4 (So=4)": t44(), "2x8 x3 (So=6)": t28(6), "2x8 x4 (So=8)": t28(8), "2x8x5 + (So=10, 2 tiles per row pair)": None}
+    for name, tiles in shapes.items():
+        if tiles is None: continue
+        print("==", name)
+        for Ri in range(6, 21):
+            for P in (128,144,160,176,192):
+                for sn, f in swzs.items():
+                    w, avg = check(tiles, Ri, P, f)
+                    if w==1: print("  Ri=%d P=%d swz=%s OK" % (Ri,P,sn))
+
+
+if __name__ == "__main__":
+    main()
