@@ -1262,7 +1262,7 @@ def test_pack_weights_frag_matches_the_host_permutation_of_both_operands():
     from tecogan_amd import params as P
     ps = P.ParamStore(OrderedDict(generator=P.generator_spec(2)), DEV, torch.bfloat16)
     ps.load(P.init_values(P.generator_spec(2), 5))
-    assert len(ps.frag) == 4
+    assert len(ps.frag) == 6 and sum('/resblock_' in n for n in ps.frag) == 4 and sum('/conv_tran' in n for n in ps.frag) == 2
     for name in ps.frag:
         for tr in (True, False):
             rows = ps.packed(name, tr).view(9, 64, 64)
