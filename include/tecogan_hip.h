@@ -235,6 +235,17 @@ int tg_pack_weights_frag(const float* src_base, void* dst_t, void* dst_n, const 
 int tg_hr_tail_backward(const float* d_frame, float scale, const void* w_out, const void* t2, const void* w_tr_frag,
                         const void* t1, void* g_out, void* g_t2, void* g_t1, int N, int H2, int W2, void* stream);
 
+/* generator_F's transposed convs in the latency regime of the training recurrence (csrc/hr_fwd_lat.hip; bf16, 64 channels), one
+ * launch each (reference lib/frvsr.py:73-87):
+ *   tg_deconv_lat_forward: y = relu(conv2d_transpose_k3s2(x, W) + b), x [N,H1,W1,64] -> y [N,2H1,2W1,64]
+ *   tg_hr_tail_train:      t2 = relu(conv2d_transpose_k3s2(t1, W2) + b2) (stored: the backward pass needs it) and
+ *                          frame = (conv3x3(t2, W3) + b3 + bicubic_four(LR)) * 2 - 1, frame [N,2H1,2W1,3] fp32
+ * w_frag / w2_frag: the transposed conv's [tap][out][in] operand (TF's [kh,kw,Cout,Cin] as stored) in FRAGMENT order
+ * (tg_pack_weights_frag, dst_n); w3 [9][3][64] = the output conv's [tap][out][in] copy; gen_in as in tg_bicubic_add_preprocess. */
+int tg_deconv_lat_forward(const void* x, const void* w_frag, const float* bias, void* y, int N, int H1, int W1, void* stream);
+int tg_hr_tail_train(const void* t1, const void* w2_frag, const float* b2, const void* w3, const float* b3, const void* gen_in,
+                     int Cpad, void* t2, float* frame, int N, int H1, int W1, void* stream);
+
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.
  * d_out and y share in_dtype; d_in has out_dtype. */

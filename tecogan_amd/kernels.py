@@ -192,6 +192,23 @@ def hr_tail_backward(d_frame, scale, w_out, t2, w_tr_frag, t1, g_out, g_t2, g_t1
     return g_t1
 
 
+def deconv_lat_forward(x, w_frag, bias, out):
+    """relu(conv2d_transpose k3 s2 (x) + b) in the latency regime (csrc/hr_fwd_lat.hip; bf16, 64 channels)."""
+    N, H1, W1, C = x.shape
+    assert C == 64 and x.dtype == torch.bfloat16
+    check(lib().tg_deconv_lat_forward(_p(x), _p(w_frag), _p(bias), _p(out), N, H1, W1, _stream()), "tg_deconv_lat_forward")
+    return out
+
+
+def hr_tail_train(t1, w2_frag, b2, w3, b3, gen_in, t2, frame):
+    """Second transposed conv (t2 stored) + output conv + bicubic skip + value range in one launch (training recurrence)."""
+    N, H1, W1, C = t1.shape
+    assert C == 64 and t1.dtype == torch.bfloat16 and gen_in.dtype == torch.bfloat16 and frame.dtype == torch.float32
+    check(lib().tg_hr_tail_train(_p(t1), _p(w2_frag), _p(b2), _p(w3), _p(b3), _p(gen_in), gen_in.shape[-1], _p(t2), _p(frame),
+                                 N, H1, W1, _stream()), "tg_hr_tail_train")
+    return frame
+
+
 def pack_weights_frag(src_base, dst_t, dst_n, tab, count):
     check(lib().tg_pack_weights_frag(_p(src_base), _p(dst_t), _p(dst_n), _p(tab), count, _stream()), "tg_pack_weights_frag")
 

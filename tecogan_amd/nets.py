@@ -151,6 +151,9 @@ class Generator:
         self.resblock_max_tiles = int(os.environ.get("TG_RESBLOCK_LAT_MAX_TILES", "1024"))
         # the BPTT's HR tail (frame gradient -> g_out -> g_t2 -> g_t1) as one launch; TG_HR_BWD_LAT=0 is the A/B switch
         self.hr_bwd_lat = os.environ.get("TG_HR_BWD_LAT", "1") == "1"
+        # the forward HR tail: both transposed convs as latency-regime launches, the second fused with the output conv and the
+        # bicubic skip (csrc/hr_fwd_lat.hip); TG_HR_FWD_LAT=0 is the A/B switch
+        self.hr_fwd_lat = os.environ.get("TG_HR_FWD_LAT", "1") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -237,6 +240,12 @@ class Generator:
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a,
                          out=q["a"][i][t], flags=cf)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
+        if fused and self.hr_fwd_lat:
+            # the two transposed convs as latency-regime launches; the second one fused with the output conv and the bicubic skip
+            t1 = K.deconv_lat_forward(a, ps.packed_frag(s % 1 + "weights", False), ps.view(s % 1 + "biases"), q["t1"][t])
+            return K.hr_tail_train(t1, ps.packed_frag(s % 2 + "weights", False), ps.view(s % 2 + "biases"),
+                                   ps.packed(p + "output_stage/conv/Conv/weights", True),
+                                   ps.view(p + "output_stage/conv/Conv/biases"), x_in, q["t2"][t], out)
         t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU, out=q["t1"][t], flags=cf)
         t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU, out=q["t2"][t], flags=cf)
         c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1, out=q["c"],

@@ -1315,3 +1315,48 @@ def test_hr_tail_backward_one_launch_matches_the_three_launches_and_autograd(sha
     x1 = torch.zeros(N, H2, W2, 64, requires_grad=True)
     O.conv2_tran(x1, w_tr, None, 2).backward(gt2_o)
     close(g_t1, x1.grad * (t1 > 0).float(), 1e-2, "g_t1 vs autograd %s" % (shape,))
+
+
+# ---- csrc/hr_fwd_lat.hip: the transposed convs of the training recurrence as latency-regime launches -------------------------
+@pytest.mark.parametrize("shape", [(4, 32, 32), (4, 64, 64), (1, 5, 7), (2, 4, 8), (3, 9, 17), (1, 6, 10)])
+def test_deconv_latency_kernel_matches_oracle_and_the_generic_kernel(shape):
+    """relu(conv2d_transpose k3 s2 SAME (x) + b), lib/ops.py:35-44 / lib/frvsr.py:73-78: the phase-form latency kernel with
+    fragment-order weights against the oracle (TF alignment: output 2i + k <- input i) and the generic transposed-mode engine."""
+    N, H1, W1 = shape
+    x = rnd(N, H1, W1, 64, seed=1).bfloat16()
+    wt = rnd(3, 3, 64, 64, seed=2, scale=0.06).bfloat16()                # TF conv2d_transpose layout [kh,kw,Cout,Cin]
+    bt = rnd(64, seed=3, scale=0.1)
+    ref = torch.relu(O.conv2_tran(x.float(), wt.float(), bt, 2))
+    w_rows = wt.reshape(9, 64, 64).contiguous().to(DEV)                   # [tap][Cout][Cin]: the operand of the transposed mode
+    out = torch.full((N, 2 * H1, 2 * W1, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    K.deconv_lat_forward(x.to(DEV), K.frag_order(w_rows), bt.to(DEV), out)
+    close(out, ref, 1e-2, "deconv latency kernel %s" % (shape,))
+    d = K.conv_desc(N, H1, W1, 64, 2 * H1, 2 * W1, 64, 3, 3, 2, 0, 0, 1, TG_BF16, TG_BF16, ACT_RELU)
+    gen = torch.empty_like(out)
+    K.conv_forward(d, x.to(DEV), w_rows, bt.to(DEV), None, None, gen)
+    close(out, gen.float(), 1e-2, "deconv latency kernel vs transposed-mode engine %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 64), (1, 14, 30), (2, 22, 36), (1, 4, 8), (3, 6, 10)])
+def test_hr_tail_training_kernel_matches_oracle(shape):
+    """t1 -> t2 = relu(conv2d_transpose) (stored) -> conv 64 -> 3 -> + bicubic_four(LR) -> *2-1 (lib/frvsr.py:73-87) in one
+    launch for the training recurrence: t2 to bf16 rounding, the frame as the inference kernel is held (the staged t2 is rounded
+    to bf16 exactly where the three-launch path stores it as bf16)."""
+    N, h2, w2 = shape
+    h, w = h2 // 2, w2 // 2
+    t1 = rnd(N, h2, w2, 64, seed=1).bfloat16()
+    wt = rnd(3, 3, 64, 64, seed=2, scale=0.06).bfloat16()
+    bt = rnd(64, seed=3, scale=0.1)
+    wo = rnd(3, 3, 64, 3, seed=4, scale=0.06).bfloat16()                 # HWIO
+    bo = rnd(3, seed=5, scale=0.1)
+    gen_in = rnd(N, h, w, 56, seed=6).bfloat16()
+    t2_ref = torch.relu(O.conv2_tran(t1.float(), wt.float(), bt, 2))
+    w_tran = wt.reshape(9, 64, 64).contiguous().to(DEV)
+    w_out = wo.permute(0, 1, 3, 2).reshape(9, 3, 64).contiguous().to(DEV)
+    t2 = torch.full((N, 2 * h2, 2 * w2, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    out = torch.full((N, 2 * h2, 2 * w2, 3), 7.0, device=DEV)
+    K.hr_tail_train(t1.to(DEV), K.frag_order(w_tran), bt.to(DEV), w_out, bo.to(DEV), gen_in.to(DEV), t2, out)
+    close(t2, t2_ref, 1e-2, "hr_tail_train t2 %s" % (shape,))
+    ref = O.preprocess(O.conv2(t2.float().cpu(), wo.float(), bo, 1) + O.bicubic_four(gen_in[..., :3].float()))   # from the kernel's own t2
+    err = (out.cpu() - ref).abs()
+    assert (err <= 2e-3 * ref.abs() + 2e-3).all(), "hr_tail_train frame %s: max err %g" % (shape, err.max().item())
