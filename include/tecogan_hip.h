@@ -243,6 +243,10 @@ int tg_hr_tail_backward(const float* d_frame, float scale, const void* w_out, co
  * w_frag / w2_frag: the transposed conv's [tap][out][in] operand (TF's [kh,kw,Cout,Cin] as stored) in FRAGMENT order
  * (tg_pack_weights_frag, dst_n); w3 [9][3][64] = the output conv's [tap][out][in] copy; gen_in as in tg_bicubic_add_preprocess. */
 int tg_deconv_lat_forward(const void* x, const void* w_frag, const float* bias, void* y, int N, int H1, int W1, void* stream);
+/* Input gradient of the same transposed conv in the latency regime (csrc/hr_bwd_lat.hip): dx = bwd_data(conv2d_transpose k3 s2)(dy)
+ * [* relu'(aux)], dy [N,2H,2W,64] bf16 -> dx [N,H,W,64] bf16; w_frag = the [tap][in][out] operand in fragment order
+ * (tg_pack_weights_frag, dst_t); aux nullable. */
+int tg_deconv_lat_backward(const void* dy, const void* w_frag, const void* aux, void* dx, int N, int H, int W, void* stream);
 int tg_hr_tail_train(const void* t1, const void* w2_frag, const float* b2, const void* w3, const float* b3, const void* gen_in,
                      int Cpad, void* t2, float* frame, int N, int H1, int W1, void* stream);
 

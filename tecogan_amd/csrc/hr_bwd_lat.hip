@@ -63,6 +63,48 @@ __device__ __forceinline__ void hb_static_for(F&& f) {
   }
 }
 
+// The k3 s2 gather over a staged 9 x 17 region (160-byte positions, 18-position rows, chunk index XORed by 2 * (column bit 2)):
+// out[i, j, ci] = sum_{ky, kx, co} region[2 i + ky, 2 j + kx, co] * W[ky, kx, co, ci] for the 4 x 8 tile, this wave's 16 output
+// channels.  lane = pixel (2 t + frow / 8, frow % 8) of pixel tile t; fragment (tap, kk): region position (2 i + ky, 2 j + kx), chunk
+// (4 kk + fg) ^ 2 * bit 2 of the column -- which is (j >> 1) & 1 for kx < 2 and ((j + 1) >> 1) & 1 for kx = 2.  The first ISSUED
+// weight fragments are already requested; the rest is requested here, one per step (prefetch distance ISSUED).
+template <int ISSUED, typename RS>
+__device__ __forceinline__ void hb_gather_level(const unsigned char* rs, const RS& rsW, int wlane, u32x4b (&wB)[18], int frow, int fg,
+                                                f32x4 (&acc2)[2]) {
+  const int pj = frow & 7;
+  const unsigned char* rb = rs + ((2 * (frow >> 3)) * HB_RP + 2 * pj) * HB_P;
+  int ch[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    ch[kk][0] = ((kk * 4 + fg) ^ (((pj >> 1) & 1) * 2)) << 4;
+    ch[kk][1] = ((kk * 4 + fg) ^ ((((pj + 1) >> 1) & 1) * 2)) << 4;
+  }
+  auto rfrag = [&](int s, int t) {
+    const int tap = s >> 1, kk = s & 1, ky = tap / 3, kx = tap % 3;
+    return *reinterpret_cast<const uint4*>(rb + ((4 * t + ky) * HB_RP + kx) * HB_P + ch[kk][kx == 2 ? 1 : 0]);
+  };
+  acc2[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 bf[2], nbf[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bf[t] = rfrag(0, t);
+  hb_static_for<0, 18>([&](auto sv) {
+    constexpr int s = decltype(sv)::value;
+    if constexpr (s + ISSUED < 18) wB[s + ISSUED < 18 ? s + ISSUED : 0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wlane, (s + ISSUED) * 4096, 0);
+    if constexpr (s < 17) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) nbf[t] = rfrag(s + 1, t);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
+                                                        acc2[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bf[t] = nbf[t];
+  });
+}
+
 __global__ __launch_bounds__(256, 2) void hr_bwd_lat_kernel(HbP p) {
   __shared__ __attribute__((aligned(16))) unsigned char rs[HB_REGION];
   __shared__ __attribute__((aligned(16))) unsigned char gs[HB_GH * HB_GP * 16];
@@ -200,39 +242,8 @@ __global__ __launch_bounds__(256, 2) void hr_bwd_lat_kernel(HbP p) {
   __syncthreads();
 
   // ---- level 2: g_t1[i, j, ci] = sum_{ky, kx, co} g_t2[2 i + ky, 2 j + kx, co] * W[ky, kx, co, ci]  (gather, stride 2) ------------
-  // lane = pixel (2 t + frow / 8, frow % 8) of pixel tile t; fragment (tap, kk): region position (2 i + ky, 2 j + kx), chunk
-  // (4 kk + fg) ^ 2 * bit 2 of the column -- the column's bit 2 is (j >> 1) & 1 for kx < 2 and ((j + 1) >> 1) & 1 for kx = 2
-  const int pj = frow & 7;
-  const unsigned char* rb = rs + ((2 * (frow >> 3)) * HB_RP + 2 * pj) * HB_P;
-  int ch[2][2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    ch[kk][0] = ((kk * 4 + fg) ^ (((pj >> 1) & 1) * 2)) << 4;
-    ch[kk][1] = ((kk * 4 + fg) ^ ((((pj + 1) >> 1) & 1) * 2)) << 4;
-  }
-  auto rfrag = [&](int s, int t) {
-    const int tap = s >> 1, kk = s & 1, ky = tap / 3, kx = tap % 3;
-    return *reinterpret_cast<const uint4*>(rb + ((4 * t + ky) * HB_RP + kx) * HB_P + ch[kk][kx == 2 ? 1 : 0]);
-  };
-  f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  uint4 bf[2], nbf[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) bf[t] = rfrag(0, t);
-  hb_static_for<0, 18>([&](auto sv) {
-    constexpr int s = decltype(sv)::value;
-    HB_WISSUE(s + HB_DIST + 3);
-    if constexpr (s < 17) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) nbf[t] = rfrag(s + 1, t);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
-                                                        acc2[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) bf[t] = nbf[t];
-  });
+  f32x4 acc2[2];
+  hb_gather_level<HB_DIST + 3>(rs, rsW, wlane, wB, frow, fg, acc2);
 #undef HB_WISSUE
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -247,6 +258,110 @@ __global__ __launch_bounds__(256, 2) void hr_bwd_lat_kernel(HbP p) {
     __builtin_amdgcn_raw_buffer_store_b64(o, rsG1, (int)o1[t], 0, 0);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same gather as its own launch: input gradient of a k3 s2 transposed conv (conv_tran1 in the BPTT: [B,64,64,64] -> [B,32,32,64],
+// was conv_igemm gather, 9.6 us): the 9 x 17 region of the output gradient comes from HBM (whole 128-byte rows, cooperatively).
+struct DbP {
+  const void* dy;       // [N, 2H, 2W, 64] bf16
+  const void* w_frag;   // [tap][in][out] operand in fragment order (tg_pack_weights_frag, dst_t)
+  const void* aux;      // nullable [N,H,W,64]: result *= (aux > 0)
+  void* dx;             // [N, H, W, 64] bf16
+  int N, H, W;
+  int tiles_i, tiles_j, ntiles;
+  unsigned dy_bytes, dx_bytes;
+  int prio;
+};
+
+template <bool HAS_AUX>
+__global__ __launch_bounds__(256, 2) void deconv_bwd_lat_kernel(DbP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char rs[HB_REGION];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fg = lane >> 4;
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
+  int b = blockIdx.x;
+  if ((p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);
+  const int tj = b % p.tiles_j, tq = b / p.tiles_j;
+  const int ti = tq % p.tiles_i, n = tq / p.tiles_i;
+  const int i0 = ti * HB_TI, j0 = tj * HB_TJ, Y0 = 2 * i0, X0 = 2 * j0;
+  const int Ho = 2 * p.H, Wo = 2 * p.W;
+  const auto rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_frag), 0, 9 * 64 * 64 * 2, 0x00020000);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.dx), 0, (int)p.dx_bytes, 0x00020000);
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(p.dx, 0, (int)p.dx_bytes, 0x00020000);
+  constexpr int ITEMS = HB_NPX * 8, NL = (ITEMS + 255) / 256;            // 1224 16-byte items, 5 per thread
+  u32x4b rr[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int item = tid + k * 256;
+    const int pix = min(item >> 3, HB_NPX - 1), c = item & 7;
+    const int y = pix / HB_RW, x = pix - y * HB_RW;
+    const bool ok = item < ITEMS && Y0 + y < Ho && X0 + x < Wo;
+    rr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(ok ? (unsigned)(((n * Ho + Y0 + y) * Wo + X0 + x) * 128 + c * 16) : HB_OOB), 0, 0);
+  }
+  u32x4b wB[18];
+  const int wlane = wave * 1024 + lane * 16;
+  hb_static_for<0, HB_DIST + 3>([&](auto i) { wB[decltype(i)::value] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wlane, decltype(i)::value * 4096, 0); });
+  u32x2b mk[2];
+  unsigned o1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int i = i0 + 2 * t + (frow >> 3), j = j0 + (frow & 7);
+    const bool ok = i < p.H && j < p.W;
+    o1[t] = ok ? (unsigned)(((n * p.H + i) * p.W + j) * 128 + (wave * 16 + fg * 4) * 2) : HB_OOB;
+    if constexpr (HAS_AUX) mk[t] = __builtin_amdgcn_raw_buffer_load_b64(rsA, (int)o1[t], 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int item = tid + k * 256;
+    const int pix = item >> 3, c = item & 7;
+    const int y = pix / HB_RW, x = pix - y * HB_RW;
+    if (item < ITEMS) *reinterpret_cast<u32x4b*>(rs + (y * HB_RP + x) * HB_P + ((c ^ (((x >> 2) & 1) * 2)) << 4)) = rr[k];
+  }
+  __syncthreads();
+  f32x4 acc2[2];
+  hb_gather_level<HB_DIST + 3>(rs, rsW, wlane, wB, frow, fg, acc2);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float v[4] = {acc2[t][0], acc2[t][1], acc2[t][2], acc2[t][3]};
+    if constexpr (HAS_AUX) {
+      const float a[4] = {__uint_as_float(mk[t].x << 16), __uint_as_float(mk[t].x & 0xffff0000u),
+                          __uint_as_float(mk[t].y << 16), __uint_as_float(mk[t].y & 0xffff0000u)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= a[r] > 0.f ? 1.f : 0.f;
+    }
+    u32x2b o;
+    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(o, rsX, (int)o1[t], 0, 0);
+  }
+}
+
+// dx = bwd_data(conv2d_transpose k3 s2)(dy) [* relu'(aux)]: dy [N,2H,2W,64] bf16 -> dx [N,H,W,64] bf16; w_frag = the [tap][in][out]
+// operand in fragment order (tg_pack_weights_frag, dst_t)
+extern "C" int tg_deconv_lat_backward(const void* dy, const void* w_frag, const void* aux, void* dx, int N, int H, int W, void* stream) {
+  TG_CHECK_ARG(dy && w_frag && dx && N > 0 && H > 0 && W > 0, "bad argument");
+  TG_CHECK_ARG((((uintptr_t)dy | (uintptr_t)w_frag | (uintptr_t)aux | (uintptr_t)dx) & 15) == 0, "alignment");
+  const int64_t px = (int64_t)N * H * W;
+  TG_CHECK_ARG(px * 4 * 128 < ((int64_t)1 << 31), "tensor too large for 32-bit buffer offsets");
+  DbP p;
+  p.dy = dy; p.w_frag = w_frag; p.aux = aux; p.dx = dx; p.N = N; p.H = H; p.W = W;
+  p.tiles_i = (H + HB_TI - 1) / HB_TI; p.tiles_j = (W + HB_TJ - 1) / HB_TJ;
+  const int64_t nt = (int64_t)N * p.tiles_i * p.tiles_j;
+  TG_CHECK_ARG(nt < ((int64_t)1 << 24), "too many tiles: this is the latency-regime kernel");
+  p.ntiles = (int)nt;
+  p.dy_bytes = (unsigned)(px * 4 * 128); p.dx_bytes = (unsigned)(px * 128);
+  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
+  p.prio = prio;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double fl = 2.0 * px * 64 * 576, by = px * 128.0 * (5 + (aux != nullptr)) + 73728.0;
+  if (aux) TG_LAUNCH("deconv_bwd_lat<aux>", fl, by, (deconv_bwd_lat_kernel<true>), dim3(p.ntiles), dim3(256), 0, st, p);
+  else TG_LAUNCH("deconv_bwd_lat<>", fl, by, (deconv_bwd_lat_kernel<false>), dim3(p.ntiles), dim3(256), 0, st, p);
+  TG_CHECK_LAUNCH();
+}
+
 
 // d_frame [N,2H2,2W2,3] fp32 -> g_out [.,8] bf16 = bf16(scale * d_frame) (zero-padded), g_t2 = bwd_data(output conv)(g_out) *
 // relu'(t2), g_t1 = bwd_data(conv_tran2, k3 s2)(g_t2) * relu'(t1).  w_out: the output conv's HWIO weights with the outputs padded

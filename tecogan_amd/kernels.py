@@ -200,6 +200,14 @@ def deconv_lat_forward(x, w_frag, bias, out):
     return out
 
 
+def deconv_lat_backward(dy, w_frag, aux, dx):
+    """Input gradient of the k3 s2 transposed conv in the latency regime (csrc/hr_bwd_lat.hip): dy [N,2H,2W,64] -> dx [N,H,W,64]."""
+    N, H, W, C = dx.shape
+    assert C == 64 and dy.dtype == torch.bfloat16 and tuple(dy.shape) == (N, 2 * H, 2 * W, 64)
+    check(lib().tg_deconv_lat_backward(_p(dy), _p(w_frag), _p(aux), _p(dx), N, H, W, _stream()), "tg_deconv_lat_backward")
+    return dx
+
+
 def hr_tail_train(t1, w2_frag, b2, w3, b3, gen_in, t2, frame):
     """Second transposed conv (t2 stored) + output conv + bicubic skip + value range in one launch (training recurrence)."""
     N, H1, W1, C = t1.shape

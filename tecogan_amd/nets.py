@@ -267,7 +267,10 @@ class Generator:
             g = conv_bwd_data(ps, p + "output_stage/conv/Conv/weights", dc, (4 * h, 4 * w), 1, aux=q["t2"][t],
                               mask_act=ACT_RELU, out=q["g_t2"][t], flags=cf)
             g = deconv_bwd_data(ps, s % 2 + "weights", g, aux=q["t1"][t], mask_act=ACT_RELU, out=q["g_t1"][t], flags=cf)
-        g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t], flags=cf)
+        if self._fused_blocks() and self.hr_bwd_lat:
+            g = K.deconv_lat_backward(g, ps.packed_frag(s % 1 + "weights", True), None, q["g_c2"][n][t] if n else q["g_in"][t])
+        else:
+            g = deconv_bwd_data(ps, s % 1 + "weights", g, out=q["g_c2"][n][t] if n else q["g_in"][t], flags=cf)
         if n == 0:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
         fused = self._fused_blocks()

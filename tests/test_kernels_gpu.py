@@ -1360,3 +1360,27 @@ def test_hr_tail_training_kernel_matches_oracle(shape):
     ref = O.preprocess(O.conv2(t2.float().cpu(), wo.float(), bo, 1) + O.bicubic_four(gen_in[..., :3].float()))   # from the kernel's own t2
     err = (out.cpu() - ref).abs()
     assert (err <= 2e-3 * ref.abs() + 2e-3).all(), "hr_tail_train frame %s: max err %g" % (shape, err.max().item())
+
+
+@pytest.mark.parametrize("mask", [False, True])
+@pytest.mark.parametrize("shape", [(4, 32, 32), (1, 5, 7), (2, 4, 8), (3, 9, 17), (4, 64, 64)])
+def test_deconv_latency_input_gradient_matches_autograd_and_the_generic_kernel(shape, mask):
+    """Input gradient of conv2d_transpose k3 s2 SAME (the stride-2 gather, lib/ops.py:35-44 under tf.gradients) on the latency
+    kernel with fragment-order weights: against autograd through the oracle and against the gather-form engine."""
+    N, H, W = shape
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    wt = bf(rnd(3, 3, 64, 64, seed=2, scale=0.06))                        # TF layout [kh,kw,Cout,Cin]
+    dy = bf(rnd(N, 2 * H, 2 * W, 64, seed=3))
+    aux = bf(rnd(N, H, W, 64, seed=4))
+    x = torch.zeros(N, H, W, 64, requires_grad=True)
+    O.conv2_tran(x, wt, None, 2).backward(dy)
+    want = x.grad * ((aux > 0).float() if mask else 1.0)
+    w_t = wt.reshape(9, 64, 64).permute(0, 2, 1).contiguous().to(DEV, torch.bfloat16)        # [tap][cin][cout]
+    dyd, auxd = dy.to(DEV, torch.bfloat16), aux.to(DEV, torch.bfloat16)
+    dx = torch.full((N, H, W, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    K.deconv_lat_backward(dyd, K.frag_order(w_t), auxd if mask else None, dx)
+    close(dx, want, 1e-2, "deconv latency input gradient %s" % (shape,))
+    d = K.conv_desc(N, 2 * H, 2 * W, 64, H, W, 64, 3, 3, 2, 0, 0, 0, TG_BF16, TG_BF16, 0, 0.0, ACT_RELU if mask else ACT_NONE, 0.0)
+    gen = torch.empty_like(dx)
+    K.conv_forward(d, dyd, w_t, None, None, auxd if mask else None, gen)
+    close(dx, gen.float(), 1e-2, "deconv latency input gradient vs the gather-form engine %s" % (shape,))

@@ -108,25 +108,30 @@ def test_frvsr_step_bf16_error_is_bounded():
 
 
 def test_bf16_recurrence_with_one_launch_residual_blocks_equals_the_two_launch_recurrence():
-    """csrc/resblock_lat.hip inside the training step (bf16 mode, configs[1]-shaped crops): the HR frames of all recurrent
-    frames are BIT-identical to the step that runs every residual block as two tg_conv_forward launches, and the gradients
-    agree to the noise of their fp32 atomics (their operands are bit-identical)."""
+    """The latency-regime kernels inside the training step (bf16 mode, configs[1]-shaped crops).
+    (a) csrc/resblock_lat.hip alone: the HR frames of all recurrent frames are BIT-identical to the step that runs every residual
+        block as two tg_conv_forward launches, and the gradients agree to the noise of their fp32 atomics (bit-identical operands).
+    (b) with the HR-tail kernels as well (csrc/hr_fwd_lat.hip, hr_bwd_lat.hip: other accumulation orders than the generic kernels
+        they replace): frames and gradients to bf16 rounding."""
     from tecogan_amd.params import damp_values
     F = OT.frvsr_flags(batch_size=2, RNN_N=4, crop_size=32, num_resblock=3)
     x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
     res = []
-    for fused in (True, False):
+    for blocks, tails in ((True, False), (False, False), (True, True)):
         eng = TrainEngine(F, DEV, gan=False, act_dtype=torch.bfloat16, seed=7, use_graph=False)
         eng.ps.load(damp_values(eng.ps.state_dict()))
-        eng.G.resblock_lat = fused
+        eng.G.resblock_lat = blocks
+        eng.G.hr_fwd_lat = eng.G.hr_bwd_lat = tails
         eng.step(x.to(DEV), y.to(DEV))
         torch.cuda.synchronize()
-        assert eng.G._fused_blocks() is fused
+        assert eng.G._fused_blocks() is blocks
         res.append((eng.gen.clone(), eng.ps.grad.clone(), eng.G.seq["g_in"].clone()))
-    (ga, gra, gia), (gb, grb, gib) = res
+    (ga, gra, gia), (gb, grb, gib), (gc, grc, gic) = res
     assert torch.equal(ga, gb), "HR frames differ between the one-launch and the two-launch recurrence"
     assert torch.equal(gia.view(torch.int16), gib.view(torch.int16)) or rel_err(gia, gib) < 2e-2   # scatter atomics feed the BPTT
     assert rel_err(gra, grb) < 2e-2
+    assert rel_err(gc, gb) < 2e-3, rel_err(gc, gb)                       # HR frames (fp32 outputs of bf16 networks)
+    assert rel_err(grc, grb) < 3e-2 and rel_err(gic, gib) < 3e-2, (rel_err(grc, grb), rel_err(gic, gib))
 
 
 def test_tecogan_step_fp32_parity():
