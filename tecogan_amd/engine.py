@@ -153,7 +153,9 @@ class TrainEngine:
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
         # frames, 8 D's own-gradient passes, 32 the generator's weight gradients beside FNet's backward pass, 64 the VGG pass
         # of the late frames beside D's generator-side backward pass (before the BPTT)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
+        # (round 4: default 103, i.e. bit 8 off -- D's own-gradient passes on the MAIN stream, in the ~1.1 ms it would otherwise
+        #  wait for the last chunk's VGG pass, instead of beside the BPTT: 9.15 / 9.18 -> 9.07 / 9.09 ms, profiles/r04k_ab.txt)
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "103")) & 111) if self.overlap else 0
         # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Measured in
         # round 4 (same box, profiles/r04a_ab.txt): 10.97 -> 10.66 ms per TecoGAN step; TG_VGGT_DEDUP=0 is the A/B switch.
