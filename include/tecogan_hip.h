@@ -219,15 +219,6 @@ int tg_hr_tail_forward(const void* t1, const void* w_tran, const float* b_tran, 
 int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                 const void* aux1, const void* aux2, void* mid, void* out, int N, int H, int W, int C, int dtype,
                 int w_frag, void* stream);
-/* TWO consecutive residual blocks (or the input-gradient chain of two blocks) as ONE launch (csrc/resblock2_lat.hip): the four
- * convolutions w4[0..3] in the order they are applied, ALL in fragment order; b4 (nullable as a whole or per entry) their biases;
- * o4[0..3] the four results (o4[0..2] nullable: nothing kept), every tensor [N,H,W,64] bf16.
- *   mode 0: o0 = relu(conv(x, w0) + b0)   o1 = x + conv(o0, w1) + b1   o2 = relu(conv(o1, w2) + b2)   o3 = o1 + conv(o2, w3) + b3
- *   mode 1: o0 = convT(x, w0) * (aux1 > 0)   o1 = x + convT(o0, w1)   o2 = convT(o1, w2) * (aux3 > 0)
- *           o3 = (o1 + convT(o2, w3)) [* (aux4 > 0)]       (x = d(output of the later block); aux1 / aux3 = the saved ReLU outputs)
- * Bit-identical to two tg_resblock calls (hence to four tg_conv_forward launches). */
-int tg_resblock2(int mode, const void* x, const void* const* w4, const float* const* b4, const void* aux1, const void* aux3,
-                 const void* aux4, void* const* o4, int N, int H, int W, int C, int dtype, void* stream);
 /* Fragment-order bf16 copies of `count` 64 -> 64 3x3 weights (the residual-block convs of lib/frvsr.py:50-57) for tg_resblock:
  * copy[2 tap + kk][wave][lane][j] = W[tap][row = 16 wave + lane % 16][k = 32 kk + 8 (lane / 16) + j]; dst_t: row = output channel
  * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 2 x int64 per tensor -- offset of the

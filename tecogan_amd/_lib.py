@@ -50,7 +50,6 @@ SIGNATURES = {
     "tg_hr_tail_forward": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "tg_resblock": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tg_pack_weights_frag": [_P, _P, _P, _P, _I, _P],
-    "tg_resblock2": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tg_hr_tail_backward": [_P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_forward": [_P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_backward": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -217,18 +217,6 @@ def hr_tail_train(t1, w2_frag, b2, w3, b3, gen_in, t2, frame):
     return frame
 
 
-def resblock2(mode, x, w4, b4, aux1, aux3, aux4, o4):
-    """Two residual blocks (mode 0) / the input-gradient chain of two blocks (mode 1) as one launch (csrc/resblock2_lat.hip).
-    w4: four fragment-order weight tensors in application order; b4: four biases or None; o4: four outputs (the first three may
-    be None)."""
-    N, H, W, Cn = x.shape
-    wt = (C.c_void_p * 4)(*[_p(t) for t in w4])
-    bt = (C.c_void_p * 4)(*[_p(t) if t is not None else None for t in b4]) if b4 is not None else None
-    ot = (C.c_void_p * 4)(*[_p(t) if t is not None else None for t in o4])
-    check(lib().tg_resblock2(mode, _p(x), wt, bt, _p(aux1), _p(aux3), _p(aux4), ot, N, H, W, Cn, dt(x), _stream()), "tg_resblock2")
-    return o4[3]
-
-
 def pack_weights_frag(src_base, dst_t, dst_n, tab, count):
     check(lib().tg_pack_weights_frag(_p(src_base), _p(dst_t), _p(dst_n), _p(tab), count, _stream()), "tg_pack_weights_frag")
 

@@ -149,8 +149,6 @@ class Generator:
         # TG_RESBLOCK_LAT=0 is the A/B switch (two tg_conv_forward launches per block, bit-identical results)
         self.resblock_lat = os.environ.get("TG_RESBLOCK_LAT", "1") == "1"
         self.resblock_max_tiles = int(os.environ.get("TG_RESBLOCK_LAT_MAX_TILES", "1024"))
-        # two residual blocks per launch where the block count allows (csrc/resblock2_lat.hip); TG_RESBLOCK_PAIR=0: A/B switch
-        self.resblock_pair = os.environ.get("TG_RESBLOCK_PAIR", "1") == "1"
         # the BPTT's HR tail (frame gradient -> g_out -> g_t2 -> g_t1) as one launch; TG_HR_BWD_LAT=0 is the A/B switch
         self.hr_bwd_lat = os.environ.get("TG_HR_BWD_LAT", "1") == "1"
         # the forward HR tail: both transposed convs as latency-regime launches, the second fused with the output conv and the
@@ -231,14 +229,7 @@ class Generator:
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
                      out=q["a"][0][t], flags=cf)
         fused = self._fused_blocks()
-        i = 0
-        while fused and self.resblock_pair and i + 2 <= self.nres:          # two blocks per launch (csrc/resblock2_lat.hip)
-            n1, n2 = p + "resblock_%d/" % (i + 1), p + "resblock_%d/" % (i + 2)
-            names = [n1 + "conv_1/Conv/", n1 + "conv_2/Conv/", n2 + "conv_1/Conv/", n2 + "conv_2/Conv/"]
-            a = K.resblock2(0, a, [ps.packed_frag(nm + "weights", True) for nm in names], [ps.view(nm + "biases") for nm in names],
-                            None, None, None, [q["r"][i + 1][t], q["a"][i + 1][t], q["r"][i + 2][t], q["a"][i + 2][t]])
-            i += 2
-        for i in range(i + 1, self.nres + 1):
+        for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
             if fused:
                 a = K.resblock(0, a, ps.packed_frag(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
@@ -283,41 +274,21 @@ class Generator:
         if n == 0:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
         fused = self._fused_blocks()
-
-        def single(i, g):
+        for i in range(n, 0, -1):
             sc = p + "resblock_%d/" % i
             if fused:
                 # d r = bwd(conv_2)(g) * relu'(r) -> g_c1 (conv_1's weight gradient reads it); d a_{i-1} = bwd(conv_1)(d r) + g
-                return K.resblock(1, g, ps.packed_frag(sc + "conv_2/Conv/weights", False), None,
-                                  ps.packed_frag(sc + "conv_1/Conv/weights", False), None, q["r"][i][t],
-                                  q["a"][0][t] if i == 1 else None, q["g_c1"][i][t],
-                                  q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], w_frag=True)
+                g = K.resblock(1, g, ps.packed_frag(sc + "conv_2/Conv/weights", False), None,
+                               ps.packed_frag(sc + "conv_1/Conv/weights", False), None, q["r"][i][t],
+                               q["a"][0][t] if i == 1 else None, q["g_c1"][i][t],
+                               q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], w_frag=True)
+                continue
             dr = conv_bwd_data(ps, sc + "conv_2/Conv/weights", g, (h, w), 1, aux=q["r"][i][t], mask_act=ACT_RELU,
                                out=q["g_c1"][i][t], flags=cf)
             # d a_{i-1} = bwd(conv_1)(dr) + skip gradient; block 1's input is itself a ReLU output (masked here)
-            return conv_bwd_data(ps, sc + "conv_1/Conv/weights", dr, (h, w), 1, res=g,
-                                 aux=q["a"][0][t] if i == 1 else None, mask_act=ACT_RELU if i == 1 else ACT_NONE,
-                                 out=q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], flags=cf)
-
-        def pair(i, g):
-            # blocks i and i - 1 in one launch: d a_i -> d r_i -> d a_{i-1} -> d r_{i-1} -> d a_{i-2}
-            hi, lo = p + "resblock_%d/" % i, p + "resblock_%d/" % (i - 1)
-            w4 = [ps.packed_frag(hi + "conv_2/Conv/weights", False), ps.packed_frag(hi + "conv_1/Conv/weights", False),
-                  ps.packed_frag(lo + "conv_2/Conv/weights", False), ps.packed_frag(lo + "conv_1/Conv/weights", False)]
-            return K.resblock2(1, g, w4, None, q["r"][i][t], q["r"][i - 1][t], q["a"][0][t] if i - 1 == 1 else None,
-                               [q["g_c1"][i][t], q["g_c2"][i - 1][t], q["g_c1"][i - 1][t],
-                                q["g_c2"][i - 2][t] if i - 2 >= 1 else q["g_in"][t]])
-
-        i = n
-        if fused and self.resblock_pair:            # the forward pass pairs (1,2), (3,4), ...: an odd last block goes alone
-            if i % 2 == 1:
-                g = single(i, g)
-                i -= 1
-            while i >= 2:
-                g = pair(i, g)
-                i -= 2
-        for i in range(i, 0, -1):
-            g = single(i, g)
+            g = conv_bwd_data(ps, sc + "conv_1/Conv/weights", dr, (h, w), 1, res=g,
+                              aux=q["a"][0][t] if i == 1 else None, mask_act=ACT_RELU if i == 1 else ACT_NONE,
+                              out=q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t], flags=cf)
         if not need_dx:
             return None
         return conv_bwd_data(ps, p + "input_stage/conv/Conv/weights", g, (h, w), 1, out=q["dx_in"], flags=cf)

@@ -1384,37 +1384,3 @@ def test_deconv_latency_input_gradient_matches_autograd_and_the_generic_kernel(s
     gen = torch.empty_like(dx)
     K.conv_forward(d, dyd, w_t, None, None, auxd if mask else None, gen)
     close(dx, gen.float(), 1e-2, "deconv latency input gradient vs the gather-form engine %s" % (shape,))
-
-
-# ---- csrc/resblock2_lat.hip: two residual blocks per launch ----------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["fwd", "bwd", "bwd_mask4"])
-@pytest.mark.parametrize("shape", RB_SHAPES)
-def test_two_residual_blocks_in_one_launch_are_bit_identical_to_two_one_block_launches(shape, mode):
-    """tg_resblock2 (four levels, in-place skip update in LDS) against two tg_resblock calls -- themselves bit-identical to the
-    four tg_conv_forward launches of lib/frvsr.py:50-57 applied twice: every one of the four result tensors, bit for bit."""
-    N, H, W = shape
-    bf = torch.bfloat16
-    g = torch.Generator().manual_seed(11)
-    x = (torch.rand(N, H, W, 64, generator=g) * 2 - 1).to(DEV, bf)
-    ws = [((torch.rand(9, 64, 64, generator=g) * 2 - 1) * 0.1).to(DEV, bf) for _ in range(4)]
-    fr = [K.frag_order(w) for w in ws]
-    bs = [((torch.rand(64, generator=g) * 2 - 1) * 0.3).to(DEV) for _ in range(4)]
-    aux = [(torch.rand(N, H, W, 64, generator=g) * 2 - 1).to(DEV, bf) for _ in range(3)]
-    ref = [torch.full_like(x, 7.0) for _ in range(4)]
-    got = [torch.full_like(x, 5.0) for _ in range(4)]
-    if mode == "fwd":
-        K.resblock(0, x, fr[0], bs[0], fr[1], bs[1], None, None, ref[0], ref[1], w_frag=True)
-        K.resblock(0, ref[1], fr[2], bs[2], fr[3], bs[3], None, None, ref[2], ref[3], w_frag=True)
-        K.resblock2(0, x, fr, bs, None, None, None, got)
-    else:
-        a4 = aux[2] if mode == "bwd_mask4" else None
-        K.resblock(1, x, fr[0], None, fr[1], None, aux[0], None, ref[0], ref[1], w_frag=True)
-        K.resblock(1, ref[1], fr[2], None, fr[3], None, aux[1], a4, ref[2], ref[3], w_frag=True)
-        K.resblock2(1, x, fr, None, aux[0], aux[1], a4, got)
-    torch.cuda.synchronize()
-    for l in range(4):
-        assert torch.equal(got[l].view(torch.int16), ref[l].view(torch.int16)), "level %d differs (%s, %s)" % (l + 1, mode, shape)
-    if mode == "fwd":                                           # stateless form: only the last tensor is written
-        last = torch.full_like(x, 3.0)
-        K.resblock2(0, x, fr, bs, None, None, None, [None, None, None, last])
-        assert torch.equal(last.view(torch.int16), ref[3].view(torch.int16))

@@ -60,26 +60,6 @@ for N, H, W in ((4, 32, 32), (4, 24, 24), (1, 32, 32), (8, 32, 32)):
     def one_bwd(i):
         K.resblock(1, a[i], f2[i], None, f1[i], None, aux[i], None, gmid[i], a[i + 1], w_frag=True)
 
-    def pair_fwd(i):                  # blocks 2i, 2i + 1 in one launch (csrc/resblock2_lat.hip); called for i < NB / 2
-        j = 2 * i
-        K.resblock2(0, a[j], [f1[j], f2[j], f1[j + 1], f2[j + 1]], [b1[j]] * 4, None, None, None, [r[j], a[j + 1], r[j + 1], a[j + 2]])
-
-    def pair_bwd(i):
-        j = 2 * i
-        K.resblock2(1, a[j], [f2[j], f1[j], f2[j + 1], f1[j + 1]], None, aux[j], aux[j + 1], None,
-                    [gmid[j], a[j + 1], gmid[j + 1], a[j + 2]])
-
-    def chain_pairs(fn, iters=30):
-        for i in range(NB // 2):
-            fn(i)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(NB // 2):
-                fn(i)
-        return timeit(g.replay, iters, 5) / NB
-
     t2f, t1f, t2b, t1b = chain_time(two_fwd), chain_time(one_fwd), chain_time(two_bwd), chain_time(one_bwd)
-    tpf, tpb = chain_pairs(pair_fwd), chain_pairs(pair_bwd)
-    print("res block [%d,%d,%d,64] bf16, us per BLOCK in a %d-block graph chain: forward two launches %6.2f  one launch %6.2f  "
-          "one launch per TWO blocks %6.2f | input gradient %6.2f  %6.2f  %6.2f" % (N, H, W, NB, t2f, t1f, tpf, t2b, t1b, tpb), flush=True)
+    print("res block [%d,%d,%d,64] bf16, us per block in a %d-block graph chain: forward two launches %6.2f  one launch %6.2f | "
+          "input gradient two launches %6.2f  one launch %6.2f" % (N, H, W, NB, t2f, t1f, t2b, t1b), flush=True)
