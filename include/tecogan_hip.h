@@ -238,8 +238,11 @@ int tg_hr_tail_backward(const float* d_frame, float scale, const void* w_out, co
 /* generator_F's transposed convs in the latency regime of the training recurrence (csrc/hr_fwd_lat.hip; bf16, 64 channels), one
  * launch each (reference lib/frvsr.py:73-87):
  *   tg_deconv_lat_forward: y = relu(conv2d_transpose_k3s2(x, W) + b), x [N,H1,W1,64] -> y [N,2H1,2W1,64]
- *   tg_hr_tail_train:      t2 = relu(conv2d_transpose_k3s2(t1, W2) + b2) (stored: the backward pass needs it) and
- *                          frame = (conv3x3(t2, W3) + b3 + bicubic_four(LR)) * 2 - 1, frame [N,2H1,2W1,3] fp32
+ *   tg_hr_tail_train:      t2 = relu(conv2d_transpose_k3s2(t1, W2) + b2) (stored when t2 != NULL: the backward pass needs it) and
+ *                          frame = (conv3x3(t2, W3) + b3 + bicubic_four(LR)) * 2 - 1, frame [N,2H1,2W1,3] fp32;
+ *                          state = (frame + 1) / 2 (the inference loop's recurrent state, main.py:207); frame or state may be
+ *                          NULL.  From 2048 tiles of 8x16 outputs up (the 1080p inference frame) the launch is persistent: two
+ *                          workgroups per CU walk the tiles with both convs' weights resident in registers.
  * w_frag / w2_frag: the transposed conv's [tap][out][in] operand (TF's [kh,kw,Cout,Cin] as stored) in FRAGMENT order
  * (tg_pack_weights_frag, dst_n); w3 [9][3][64] = the output conv's [tap][out][in] copy; gen_in as in tg_bicubic_add_preprocess. */
 int tg_deconv_lat_forward(const void* x, const void* w_frag, const float* bias, void* y, int N, int H1, int W1, void* stream);
@@ -248,7 +251,8 @@ int tg_deconv_lat_forward(const void* x, const void* w_frag, const float* bias, 
  * (tg_pack_weights_frag, dst_t); aux nullable. */
 int tg_deconv_lat_backward(const void* dy, const void* w_frag, const void* aux, void* dx, int N, int H, int W, void* stream);
 int tg_hr_tail_train(const void* t1, const void* w2_frag, const float* b2, const void* w3, const float* b3, const void* gen_in,
-                     int Cpad, void* t2, float* frame, int N, int H1, int W1, void* stream);
+                     int Cpad, void* t2 /*nullable*/, float* frame /*nullable*/, float* state /*nullable*/, int N, int H1, int W1,
+                     void* stream);
 
 /* Pointwise activation gradient: d_in = scale * d_out * act'(y) with y the activation OUTPUT
  * (TANH: alpha - y*y/alpha ; SIGMOID: y(1-y) ; RELU/LRELU as the conv mask); y == NULL -> scale+cast.

@@ -53,7 +53,7 @@ SIGNATURES = {
     "tg_hr_tail_backward": [_P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_forward": [_P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_backward": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "tg_hr_tail_train": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
+    "tg_hr_tail_train": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "tg_act_backward": [_P, _P, _P, _I, _I, _L, _I, _F, _F, _P],
     "tg_concat2_pad": [_P, _I, _P, _I, _P, _I, _I, _L, _F, _P],
     "tg_lincomb": [_P, _P, _P, _L, _F, _F, _I, _P],

@@ -29,7 +29,8 @@ struct HfP {
   const void* w3;       // [9][3][64] bf16 output conv, [tap][out][in]
   const float* b3;      // [3]
   const void* gen_in;   // [N, H1/2, W1/2, Cpad] bf16: LR frame in channels 0..2
-  float* frame;         // [N, 2H1, 2W1, 3] fp32 in [-1,1]
+  float* frame;         // [N, 2H1, 2W1, 3] fp32 in [-1,1], nullable
+  float* state;         // same shape, (frame + 1) / 2 (the inference loop's recurrent state, main.py:207), nullable
   int Cpad;
   int N, H1, W1;
   int tiles_i, tiles_j, ntiles;
@@ -61,7 +62,11 @@ __device__ __forceinline__ void hf_static_for(F&& f) {
   }
 }
 
-template <bool FUSE>
+// PERSIST (the inference step's tail at 1080p: 16200 tiles): a workgroup walks tiles blockIdx.x, + gridDim.x, ... with BOTH convs'
+// weight fragments resident in registers (144 VGPRs) instead of re-streaming 91 KB per tile; two workgroups per CU hide each other's
+// region loads and barriers.  (Without it the per-tile kernel already beats hr_tail.hip at 1080p, 227 -> 164 us, profiles/r04m_ab.txt:
+// that kernel's output-conv loop serialises 18 dependent MFMAs and four dependent global loads per 16 pixels at one wave per SIMD.)
+template <bool FUSE, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
   // phase geometry: NA x NB pixels per phase; the fused tail also needs the one-pixel ring of t2 around its own block
   constexpr int NA = FUSE ? HF_TI + 1 : HF_TI, NB = FUSE ? HF_TJ + 1 : HF_TJ;
@@ -73,52 +78,43 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fg = lane >> 4;
-  if (p.prio) __builtin_amdgcn_s_setprio(3);
-  int b = blockIdx.x;
-  if ((p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);
-  const int tj = b % p.tiles_j, tq = b / p.tiles_j;
-  const int ti = tq % p.tiles_i, n = tq / p.tiles_i;
-  const int i0 = ti * HF_TI, j0 = tj * HF_TJ;
+  if (!PERSIST && p.prio) __builtin_amdgcn_s_setprio(3);
   const int Ho = 2 * p.H1, Wo = 2 * p.W1;
   const int cbyte = (wave * 16 + fg * 4) * 2;
 
   const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_frag), 0, 9 * 64 * 64 * 2, 0x00020000);
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? 256 : 0, 0x00020000);
-  const auto rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+  const auto rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? (int)p.y_bytes : 0, 0x00020000);
+  const auto rsW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(FUSE ? p.w3 : p.x), 0, 9 * 3 * 64 * 2, 0x00020000);
+  const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(FUSE ? p.gen_in : p.x), 0, (int)p.lr_bytes, 0x00020000);
+  const auto rsF = __builtin_amdgcn_make_buffer_rsrc(p.frame, 0, p.frame ? (int)p.f_bytes : 0, 0x00020000);
+  const auto rsS = __builtin_amdgcn_make_buffer_rsrc(p.state, 0, p.state ? (int)p.f_bytes : 0, 0x00020000);
 
-  // ---- global loads, in consumption order; none behind a branch ----------------------------------------------------------
   const u32x4f bq = __builtin_amdgcn_raw_buffer_load_b128(rsB, (wave * 16 + fg * 4) * 4, 0, 0);
-  constexpr int XITEMS = RI * RJ * 8, XL = (XITEMS + 255) / 256;         // 480 | 360 16-byte items
-  u32x4f xr[XL];
-#pragma unroll
-  for (int k = 0; k < XL; ++k) {
-    const int item = tid + k * 256;
-    const int pix = min(item >> 3, RI * RJ - 1), c = item & 7;
-    const int i = i0 - 1 + pix / RJ, j = j0 - 1 + pix % RJ;
-    const bool ok = item < XITEMS && (unsigned)i < (unsigned)p.H1 && (unsigned)j < (unsigned)p.W1;
-    xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H1 + i) * p.W1 + j) * 128 + c * 16) : HF_OOB), 0, 0);
-  }
   u32x4f wB[18];                                                        // indexed by STREAM position: tap hf_tap_order(s / 2), K-half s % 2
+  u32x4f w3f[FUSE ? 18 : 1];
   const int wlane = wave * 1024 + lane * 16;
-#define HF_WISSUE(i)                                                                                                   \
-  do {                                                                                                                 \
-    if constexpr ((i) < 18)                                                                                            \
-      wB[(i) < 18 ? (i) : 0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wlane, (hf_tap_order(((i) < 18 ? (i) : 0) >> 1) * 2 + ((i) & 1)) * 4096, 0); \
+#define HF_WLOAD(i) __builtin_amdgcn_raw_buffer_load_b128(rsW, wlane, (hf_tap_order(((i) < 18 ? (i) : 0) >> 1) * 2 + ((i) & 1)) * 4096, 0)
+#define HF_WISSUE(i)                                                  \
+  do {                                                                \
+    if constexpr (!PERSIST && (i) < 18) wB[(i) < 18 ? (i) : 0] = HF_WLOAD(i); \
   } while (0)
-  hf_static_for<0, HF_DIST>([&](auto i) { HF_WISSUE(decltype(i)::value); });
-  const float bv[4] = {__uint_as_float(bq.x), __uint_as_float(bq.y), __uint_as_float(bq.z), __uint_as_float(bq.w)};
-  __builtin_amdgcn_sched_barrier(0);
+  auto load_w3 = [&]() {
+    if constexpr (FUSE) {
 #pragma unroll
-  for (int k = 0; k < XL; ++k) {
-    const int item = tid + k * 256;
-    if (item < XITEMS) *reinterpret_cast<u32x4f*>(xs + (item >> 3) * HF_P + (item & 7) * 16) = xr[k];
+      for (int s = 0; s < 18; ++s)
+        w3f[s] = __builtin_amdgcn_raw_buffer_load_b128(rsW3, (int)(frow < 3 ? (unsigned)((((s >> 1) * 3 + frow) * 64 + (s & 1) * 32 + fg * 8) * 2) : HF_OOB), 0, 0);
+    }
+  };
+  if constexpr (PERSIST) {
+    hf_static_for<0, 18>([&](auto i) { wB[decltype(i)::value] = HF_WLOAD(decltype(i)::value); });
+    load_w3();
   }
-  __syncthreads();
-
-  // ---- the four phases: out[2a+py, 2b+px] ----------------------------------------------------------------------------------
-  // lane = pixel m = 16 t + frow of the phase: (pa, pb) = (m / NB, m % NB); a = i0 + pa - (FUSE and py), b likewise; the input
-  // pixel of tap (ky, kx) is (a - (ky == 2), b - (kx == 2)) = region position (pa + 1 - (FUSE and py) - (ky == 2), ...)
+  const float bv[4] = {__uint_as_float(bq.x), __uint_as_float(bq.y), __uint_as_float(bq.z), __uint_as_float(bq.w)};
+  const float b3[3] = {FUSE && p.b3 ? p.b3[0] : 0.f, FUSE && p.b3 ? p.b3[1] : 0.f, FUSE && p.b3 ? p.b3[2] : 0.f};
+  const int h = p.H1 >> 1, w = p.W1 >> 1;
+  // lane = pixel m = 16 t + frow of a phase: (pa, pb) = (m / NB, m % NB)
   int ppa[NT], ppb[NT];
   bool pok[NT];
 #pragma unroll
@@ -129,112 +125,151 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
     ppa[t] = mm / NB;
     ppb[t] = mm - ppa[t] * NB;
   }
-  hf_static_for<0, 4>([&](auto phv) {
-    constexpr int ph = decltype(phv)::value, py = ph >> 1, px = ph & 1;
-    constexpr int s0 = ph == 0 ? 0 : ph == 1 ? 8 : ph == 2 ? 12 : 16;       // first stream position of the phase
-    constexpr int ntap = ph == 0 ? 4 : ph == 3 ? 1 : 2;
-    f32x4 acc[NT];
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int b = tile;
+    if (!PERSIST && (p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);      // an XCD owns a contiguous range of tiles
+    const int tj = b % p.tiles_j, tq = b / p.tiles_j;
+    const int ti = tq % p.tiles_i, n = tq / p.tiles_i;
+    const int i0 = ti * HF_TI, j0 = tj * HF_TJ;
+
+    // ---- global loads of the tile, in consumption order; none behind a branch ------------------------------------------------
+    constexpr int XITEMS = RI * RJ * 8, XL = (XITEMS + 255) / 256;         // 480 | 360 16-byte items
+    u32x4f xr[XL];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    hf_static_for<0, ntap * 2>([&](auto qv) {
-      constexpr int q = decltype(qv)::value, s = s0 + q, tap = hf_tap_order(s >> 1), kk = s & 1, ky = tap / 3, kx = tap % 3;
-      constexpr int dy = 1 - (FUSE ? py : 0) - (ky == 2 ? 1 : 0), dx = 1 - (FUSE ? px : 0) - (kx == 2 ? 1 : 0);
-      HF_WISSUE(s + HF_DIST);
-      uint4 bf[NT];
+    for (int k = 0; k < XL; ++k) {
+      const int item = tid + k * 256;
+      const int pix = min(item >> 3, RI * RJ - 1), c = item & 7;
+      const int i = i0 - 1 + pix / RJ, j = j0 - 1 + pix % RJ;
+      const bool ok = item < XITEMS && (unsigned)i < (unsigned)p.H1 && (unsigned)j < (unsigned)p.W1;
+      xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H1 + i) * p.W1 + j) * 128 + c * 16) : HF_OOB), 0, 0);
+    }
+    hf_static_for<0, HF_DIST>([&](auto i) { HF_WISSUE(decltype(i)::value); });
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        bf[t] = *reinterpret_cast<const uint4*>(xs + ((ppa[t] + dy) * RJ + ppb[t] + dx) * HF_P + kk * 64 + fg * 16);
+    for (int k = 0; k < XL; ++k) {
+      const int item = tid + k * 256;
+      if (item < XITEMS) *reinterpret_cast<u32x4f*>(xs + (item >> 3) * HF_P + (item & 7) * 16) = xr[k];
+    }
+    __syncthreads();                               // (also: every wave has left the previous tile's output-conv reads of bs)
+
+    // ---- the four phases: out[2a+py, 2b+px]; a = i0 + pa - (FUSE and py), b likewise; the input pixel of tap (ky, kx) is
+    //      (a - (ky == 2), b - (kx == 2)) = region position (pa + 1 - (FUSE and py) - (ky == 2), ...) ------------------------------
+    hf_static_for<0, 4>([&](auto phv) {
+      constexpr int ph = decltype(phv)::value, py = ph >> 1, px = ph & 1;
+      constexpr int s0 = ph == 0 ? 0 : ph == 1 ? 8 : ph == 2 ? 12 : 16;       // first stream position of the phase
+      constexpr int ntap = ph == 0 ? 4 : ph == 3 ? 1 : 2;
+      f32x4 acc[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
-                                                         acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      hf_static_for<0, ntap * 2>([&](auto qv) {
+        constexpr int q = decltype(qv)::value, s = s0 + q, tap = hf_tap_order(s >> 1), kk = s & 1, ky = tap / 3, kx = tap % 3;
+        constexpr int dy = 1 - (FUSE ? py : 0) - (ky == 2 ? 1 : 0), dx = 1 - (FUSE ? px : 0) - (kx == 2 ? 1 : 0);
+        HF_WISSUE(s + HF_DIST);
+        uint4 bf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          bf[t] = *reinterpret_cast<const uint4*>(xs + ((ppa[t] + dy) * RJ + ppb[t] + dx) * HF_P + kk * 64 + fg * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
+                                                           acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // epilogue of the phase: bias, ReLU; own pixels -> HBM; fused tail: every pixel of the ring block -> LDS (zero outside the image)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int a = i0 + ppa[t] - (FUSE ? py : 0), bcol = j0 + ppb[t] - (FUSE ? px : 0);
+        const int Y = 2 * a + py, X = 2 * bcol + px;
+        const bool inimg = pok[t] && (unsigned)Y < (unsigned)Ho && (unsigned)X < (unsigned)Wo;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][r] + bv[r], 0.f);
+        u32x2f o;
+        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        if (!inimg) o = u32x2f{0u, 0u};
+        const bool own = inimg && Y >= 2 * i0 && Y < 2 * i0 + 2 * HF_TI && X >= 2 * j0 && X < 2 * j0 + 2 * HF_TJ;
+        __builtin_amdgcn_raw_buffer_store_b64(o, rsY, (int)(own ? (unsigned)(((n * Ho + Y) * Wo + X) * 128 + cbyte) : HF_OOB), 0, 0);
+        if constexpr (FUSE) {
+          const int pos = pok[t] ? (Y - (2 * i0 - 1)) * BW + X - (2 * j0 - 1) : BH * BW;      // (padding lanes: the dump position)
+          *reinterpret_cast<u32x2f*>(bs + pos * HF_P + cbyte) = o;
+        }
+      }
     });
-    // epilogue of the phase: bias, ReLU; own pixels -> HBM; fused tail: every pixel of the ring block -> LDS (zero outside the image)
+    if constexpr (FUSE) {
+      // ---- fused tail: output conv (64 -> 3) + bicubic_four(LR) skip + value range, as hr_tail.hip ----------------------------
+      if constexpr (!PERSIST) load_w3();
+      __syncthreads();                                   // the ring block is complete
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int a = i0 + ppa[t] - (FUSE ? py : 0), bcol = j0 + ppb[t] - (FUSE ? px : 0);
-      const int Y = 2 * a + py, X = 2 * bcol + px;
-      const bool inimg = pok[t] && (unsigned)Y < (unsigned)Ho && (unsigned)X < (unsigned)Wo;
-      float v[4];
+      for (int g = 0; g < 2; ++g) {                       // this wave's two rows of the own 8 x 16 block: lane frow = column
+        const int yl = wave * 2 + g;                     // own row -> block row yl + 1, block column frow + 1
+        // bicubic: 16-lane group fg gathers LR row clamp(yo / 4 - 1 + fg); the four loads are requested BEFORE the MFMA chain
+        const int yo = 2 * i0 + yl, xo = 2 * j0 + frow;
+        const bool mine = yo < Ho && xo < Wo;
+        const int yc = min(yo, Ho - 1), xc = min(xo, Wo - 1);
+        const int li = yc >> 2, lj = xc >> 2;
+        const int ry = min(max(li + fg - 1, 0), h - 1);
+        const float wy = kBicubicF[yc & 3][fg];
+        u32x2f lq[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][r] + bv[r], 0.f);
-      u32x2f o;
-      o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-      o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-      if (!inimg) o = u32x2f{0u, 0u};
-      const bool own = inimg && Y >= 2 * i0 && Y < 2 * i0 + 2 * HF_TI && X >= 2 * j0 && X < 2 * j0 + 2 * HF_TJ;
-      __builtin_amdgcn_raw_buffer_store_b64(o, rsY, (int)(own ? (unsigned)(((n * Ho + Y) * Wo + X) * 128 + cbyte) : HF_OOB), 0, 0);
-      if constexpr (FUSE) {
-        const int pos = pok[t] ? (Y - (2 * i0 - 1)) * BW + X - (2 * j0 - 1) : BH * BW;      // (padding lanes: the dump position)
-        *reinterpret_cast<u32x2f*>(bs + pos * HF_P + cbyte) = o;
+        for (int k = 0; k < 4; ++k) {
+          const int rx = min(max(lj + k - 1, 0), w - 1);
+          lq[k] = __builtin_amdgcn_raw_buffer_load_b64(rsL, ((n * h + ry) * w + rx) * p.Cpad * 2, 0, 0);
+        }
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* Bf = bs + (yl * BW + frow) * HF_P + fg * 16;
+        constexpr int CH = PERSIST ? 6 : 18;              // (resident weights leave room for one tap row of fragments at a time)
+#pragma unroll
+        for (int c0 = 0; c0 < 18; c0 += CH) {
+          uint4 bfr[CH];
+#pragma unroll
+          for (int s = 0; s < CH; ++s)
+            bfr[s] = *reinterpret_cast<const uint4*>(Bf + ((((c0 + s) >> 1) / 3) * BW + ((c0 + s) >> 1) % 3) * HF_P + (s & 1) * 64);
+#pragma unroll
+          for (int s = 0; s < CH; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w3f[c0 + s]), *reinterpret_cast<bf16x8*>(&bfr[s]), acc, 0, 0, 0);
+        }
+        // lanes fg == 0 hold channels 0..2 of pixel (yo, xo)
+        float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float wgt = wy * kBicubicF[xc & 3][k];
+          part[0] += wgt * __uint_as_float(lq[k].x << 16);
+          part[1] += wgt * __uint_as_float(lq[k].x & 0xffff0000u);
+          part[2] += wgt * __uint_as_float(lq[k].y << 16);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          part[c] += __shfl_xor(part[c], 16, 64);
+          part[c] += __shfl_xor(part[c], 32, 64);
+        }
+        const bool st = fg == 0 && mine;
+        const unsigned off = st ? (unsigned)((((n * Ho + yo) * Wo + xo) * 3) * 4) : HF_OOB;
+        const float f0 = (acc[0] + b3[0] + part[0]) * 2.f - 1.f, f1 = (acc[1] + b3[1] + part[1]) * 2.f - 1.f,
+                    f2 = (acc[2] + b3[2] + part[2]) * 2.f - 1.f;
+        const u32x3f o = {__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2)};
+        __builtin_amdgcn_raw_buffer_store_b96(o, rsF, (int)off, 0, 0);
+        const u32x3f os = {__float_as_uint(f0 * 0.5f + 0.5f), __float_as_uint(f1 * 0.5f + 0.5f), __float_as_uint(f2 * 0.5f + 0.5f)};
+        __builtin_amdgcn_raw_buffer_store_b96(os, rsS, (int)off, 0, 0);
       }
     }
-  });
-#undef HF_WISSUE
-  if constexpr (!FUSE) return;
-
-  // ---- fused tail: output conv (64 -> 3) + bicubic_four(LR) skip + value range, as hr_tail.hip -------------------------------
-  const auto rsW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, 9 * 3 * 64 * 2, 0x00020000);
-  const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gen_in), 0, (int)p.lr_bytes, 0x00020000);
-  const auto rsF = __builtin_amdgcn_make_buffer_rsrc(p.frame, 0, (int)p.f_bytes, 0x00020000);
-  u32x4f w3f[18];
-#pragma unroll
-  for (int s = 0; s < 18; ++s)
-    w3f[s] = __builtin_amdgcn_raw_buffer_load_b128(rsW3, (int)(frow < 3 ? (unsigned)((((s >> 1) * 3 + frow) * 64 + (s & 1) * 32 + fg * 8) * 2) : HF_OOB), 0, 0);
-  const float b3[3] = {p.b3 ? p.b3[0] : 0.f, p.b3 ? p.b3[1] : 0.f, p.b3 ? p.b3[2] : 0.f};
-  const int h = p.H1 >> 1, w = p.W1 >> 1;
-  __syncthreads();                                   // the ring block is complete
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {                       // this wave's two rows of the own 8 x 16 block: lane frow = column
-    const int yl = wave * 2 + g;                     // own row -> block row yl + 1, block column frow + 1
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* Bf = bs + (yl * BW + frow) * HF_P + fg * 16;
-    uint4 bfr[18];
-#pragma unroll
-    for (int s = 0; s < 18; ++s) bfr[s] = *reinterpret_cast<const uint4*>(Bf + (((s >> 1) / 3) * BW + (s >> 1) % 3) * HF_P + (s & 1) * 64);
-#pragma unroll
-    for (int s = 0; s < 18; ++s)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w3f[s]), *reinterpret_cast<bf16x8*>(&bfr[s]), acc, 0, 0, 0);
-    // lanes fg == 0 hold channels 0..2 of pixel (yo, xo); bicubic: 16-lane group fg gathers LR row clamp(yo / 4 - 1 + fg)
-    const int yo = 2 * i0 + yl, xo = 2 * j0 + frow;
-    const bool mine = yo < Ho && xo < Wo;
-    const int yc = min(yo, Ho - 1), xc = min(xo, Wo - 1);
-    const int li = yc >> 2, lj = xc >> 2;
-    const int ry = min(max(li + fg - 1, 0), h - 1);
-    const float wy = kBicubicF[yc & 3][fg];
-    float part[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rx = min(max(lj + k - 1, 0), w - 1);
-      const u32x2f qv = __builtin_amdgcn_raw_buffer_load_b64(rsL, ((n * h + ry) * w + rx) * p.Cpad * 2, 0, 0);
-      const float wgt = wy * kBicubicF[xc & 3][k];
-      part[0] += wgt * __uint_as_float(qv.x << 16);
-      part[1] += wgt * __uint_as_float(qv.x & 0xffff0000u);
-      part[2] += wgt * __uint_as_float(qv.y << 16);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      part[c] += __shfl_xor(part[c], 16, 64);
-      part[c] += __shfl_xor(part[c], 32, 64);
-    }
-    const bool st = fg == 0 && mine;
-    const u32x3f o = {__float_as_uint((acc[0] + b3[0] + part[0]) * 2.f - 1.f), __float_as_uint((acc[1] + b3[1] + part[1]) * 2.f - 1.f),
-                      __float_as_uint((acc[2] + b3[2] + part[2]) * 2.f - 1.f)};
-    __builtin_amdgcn_raw_buffer_store_b96(o, rsF, (int)(st ? (unsigned)((((n * Ho + yo) * Wo + xo) * 3) * 4) : HF_OOB), 0, 0);
+    if constexpr (!PERSIST) break;
   }
+#undef HF_WISSUE
+#undef HF_WLOAD
 }
 
 static int hf_launch(bool fuse, const void* x, const void* w_frag, const float* bias, void* y, const void* w3, const float* b3,
-                     const void* gen_in, int Cpad, float* frame, int N, int H1, int W1, void* stream) {
+                     const void* gen_in, int Cpad, float* frame, float* state, int N, int H1, int W1, void* stream) {
   const int64_t px = (int64_t)N * H1 * W1;
   TG_CHECK_ARG(px * 4 * 128 < ((int64_t)1 << 31), "tensor too large for 32-bit buffer offsets");
   HfP p;
-  p.x = x; p.w_frag = w_frag; p.bias = bias; p.y = y; p.w3 = w3; p.b3 = b3; p.gen_in = gen_in; p.frame = frame; p.Cpad = Cpad;
+  p.x = x; p.w_frag = w_frag; p.bias = bias; p.y = y; p.w3 = w3; p.b3 = b3; p.gen_in = gen_in; p.frame = frame; p.state = state; p.Cpad = Cpad;
   p.N = N; p.H1 = H1; p.W1 = W1;
   p.tiles_i = (H1 + HF_TI - 1) / HF_TI; p.tiles_j = (W1 + HF_TJ - 1) / HF_TJ;
   const int64_t nt = (int64_t)N * p.tiles_i * p.tiles_j;
-  TG_CHECK_ARG(nt < ((int64_t)1 << 24), "too many tiles: this is the latency-regime kernel");
+  TG_CHECK_ARG(nt < ((int64_t)1 << 24), "too many tiles");
   p.ntiles = (int)nt;
   p.x_bytes = (unsigned)(px * 128); p.y_bytes = (unsigned)(px * 4 * 128);
   p.lr_bytes = (unsigned)((int64_t)N * (H1 / 2) * (W1 / 2) * Cpad * 2); p.f_bytes = (unsigned)(px * 4 * 12);
@@ -242,9 +277,15 @@ static int hf_launch(bool fuse, const void* x, const void* w_frag, const float* 
   p.prio = prio;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double fl = 2.0 * px * 64 * 64 * 9.0;
-  if (fuse) TG_LAUNCH("hr_fwd_lat<tail>", fl + 2.0 * 4 * px * 9.0 * 64 * 3, px * 128.0 * 5 + 4.0 * px * 12 + 73728.0, (hr_fwd_lat_kernel<true>),
-                      dim3(p.ntiles), dim3(256), 0, st, p);
-  else TG_LAUNCH("hr_fwd_lat<deconv>", fl, px * 128.0 * 5 + 73728.0, (hr_fwd_lat_kernel<false>), dim3(p.ntiles), dim3(256), 0, st, p);
+  // throughput regime (the inference stream: thousands of tiles): persistent workgroups, two per CU, weights resident in registers
+  static const int persist_min = getenv("TG_HR_TAIL_PERSIST_MIN") ? atoi(getenv("TG_HR_TAIL_PERSIST_MIN")) : 2048;
+  if (fuse && p.ntiles >= persist_min)
+    TG_LAUNCH("hr_fwd_lat<tail,persistent>", fl + 2.0 * 4 * px * 9.0 * 64 * 3, px * 128.0 * (1 + 4 * (y != nullptr)) + 4.0 * px * 12 * ((frame != nullptr) + (state != nullptr)) + 73728.0,
+              (hr_fwd_lat_kernel<true, true>), dim3(512), dim3(256), 0, st, p);
+  else if (fuse)
+    TG_LAUNCH("hr_fwd_lat<tail>", fl + 2.0 * 4 * px * 9.0 * 64 * 3, px * 128.0 * 5 + 4.0 * px * 12 + 73728.0, (hr_fwd_lat_kernel<true, false>),
+              dim3(p.ntiles), dim3(256), 0, st, p);
+  else TG_LAUNCH("hr_fwd_lat<deconv>", fl, px * 128.0 * 5 + 73728.0, (hr_fwd_lat_kernel<false, false>), dim3(p.ntiles), dim3(256), 0, st, p);
   TG_CHECK_LAUNCH();
 }
 
@@ -253,16 +294,17 @@ static int hf_launch(bool fuse, const void* x, const void* w_frag, const float* 
 extern "C" int tg_deconv_lat_forward(const void* x, const void* w_frag, const float* bias, void* y, int N, int H1, int W1, void* stream) {
   TG_CHECK_ARG(x && w_frag && y && N > 0 && H1 > 0 && W1 > 0, "bad argument");
   TG_CHECK_ARG((((uintptr_t)x | (uintptr_t)w_frag | (uintptr_t)y) & 15) == 0, "alignment");
-  return hf_launch(false, x, w_frag, bias, y, nullptr, nullptr, nullptr, 0, nullptr, N, H1, W1, stream);
+  return hf_launch(false, x, w_frag, bias, y, nullptr, nullptr, nullptr, 0, nullptr, nullptr, N, H1, W1, stream);
 }
 
-// t2 = relu(conv2d_transpose_k3s2(t1, W2) + b2) (stored) and frame = (conv3x3(t2, W3) + b3 + bicubic_four(LR)) * 2 - 1 in one launch;
-// t1 [N,H1,W1,64] with H1, W1 even (twice the LR size); gen_in [N,H1/2,W1/2,Cpad] bf16 with the LR frame in channels 0..2
+// t2 = relu(conv2d_transpose_k3s2(t1, W2) + b2) (stored when t2 != NULL) and frame = (conv3x3(t2, W3) + b3 + bicubic_four(LR)) * 2 - 1,
+// state = (frame + 1) / 2 (either may be NULL) in one launch; t1 [N,H1,W1,64] with H1, W1 even (twice the LR size); gen_in
+// [N,H1/2,W1/2,Cpad] bf16 with the LR frame in channels 0..2
 extern "C" int tg_hr_tail_train(const void* t1, const void* w2_frag, const float* b2, const void* w3, const float* b3,
-                                const void* gen_in, int Cpad, void* t2, float* frame, int N, int H1, int W1, void* stream) {
-  TG_CHECK_ARG(t1 && w2_frag && w3 && gen_in && t2 && frame, "null pointer");
+                                const void* gen_in, int Cpad, void* t2, float* frame, float* state, int N, int H1, int W1, void* stream) {
+  TG_CHECK_ARG(t1 && w2_frag && w3 && gen_in && (frame || state), "null pointer");        // t2 == NULL: nothing kept (stateless forward)
   TG_CHECK_ARG(N > 0 && H1 > 0 && W1 > 0 && (H1 & 1) == 0 && (W1 & 1) == 0 && Cpad >= 4 && (Cpad & 3) == 0, "bad shape");
   TG_CHECK_ARG((((uintptr_t)t1 | (uintptr_t)w2_frag | (uintptr_t)w3 | (uintptr_t)t2) & 15) == 0 && ((uintptr_t)gen_in & 7) == 0 &&
-                   ((uintptr_t)frame & 3) == 0, "alignment");
-  return hf_launch(true, t1, w2_frag, b2, t2, w3, b3, gen_in, Cpad, frame, N, H1, W1, stream);
+                   (((uintptr_t)frame | (uintptr_t)state) & 3) == 0, "alignment");
+  return hf_launch(true, t1, w2_frag, b2, t2, w3, b3, gen_in, Cpad, frame, state, N, H1, W1, stream);
 }

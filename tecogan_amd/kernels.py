@@ -208,13 +208,15 @@ def deconv_lat_backward(dy, w_frag, aux, dx):
     return dx
 
 
-def hr_tail_train(t1, w2_frag, b2, w3, b3, gen_in, t2, frame):
-    """Second transposed conv (t2 stored) + output conv + bicubic skip + value range in one launch (training recurrence)."""
+def hr_tail_train(t1, w2_frag, b2, w3, b3, gen_in, t2, frame, state=None):
+    """Second transposed conv (t2 stored unless None) + output conv + bicubic skip + value range(s) in one launch: the training
+    recurrence's tail and, with thousands of tiles, the inference frame's (persistent launch)."""
     N, H1, W1, C = t1.shape
-    assert C == 64 and t1.dtype == torch.bfloat16 and gen_in.dtype == torch.bfloat16 and frame.dtype == torch.float32
+    assert C == 64 and t1.dtype == torch.bfloat16 and gen_in.dtype == torch.bfloat16
+    assert all(o is None or o.dtype == torch.float32 for o in (frame, state))
     check(lib().tg_hr_tail_train(_p(t1), _p(w2_frag), _p(b2), _p(w3), _p(b3), _p(gen_in), gen_in.shape[-1], _p(t2), _p(frame),
-                                 N, H1, W1, _stream()), "tg_hr_tail_train")
-    return frame
+                                 _p(state), N, H1, W1, _stream()), "tg_hr_tail_train")
+    return frame if frame is not None else state
 
 
 def pack_weights_frag(src_base, dst_t, dst_n, tab, count):

@@ -145,6 +145,7 @@ class Generator:
         # fused HR tail of the stateless (inference) forward (csrc/hr_tail.hip); TG_HR_TAIL=0 is the A/B switch
         # (1080p frame 1.103 -> 1.068 ms, profiles/r03a_ab.txt)
         self.hr_tail = os.environ.get("TG_HR_TAIL", "1") == "1"
+        self.hr_tail_lat = os.environ.get("TG_HR_TAIL_LAT", "1") == "1"        # A/B: 0 = csrc/hr_tail.hip in the stateless forward
         # one launch per residual block in the training recurrence (csrc/resblock_lat.hip: bf16 frames in the latency regime);
         # TG_RESBLOCK_LAT=0 is the A/B switch (two tg_conv_forward launches per block, bit-identical results)
         self.resblock_lat = os.environ.get("TG_RESBLOCK_LAT", "1") == "1"
@@ -178,8 +179,14 @@ class Generator:
             N, h2, w2, _ = t1.shape
             o = None if out is False else (torch.empty(N, 2 * h2, 2 * w2, 3, device=t1.device) if out is None else out)
             assert o is not None or state is not None
-            r = K.hr_tail_forward(t1, ps.packed(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
-                                  ps.view(bo), x_in, o, state)
+            if self.hr_tail_lat and ps.frag:
+                # the phase-form kernel of the training recurrence, persistent at this size (csrc/hr_fwd_lat.hip): 1080p tail
+                # 227 -> 164 us already as a per-tile launch (profiles/r04m_ab.txt)
+                r = K.hr_tail_train(t1, ps.packed_frag(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
+                                    ps.view(bo), x_in, None, o, state)
+            else:
+                r = K.hr_tail_forward(t1, ps.packed(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
+                                      ps.view(bo), x_in, o, state)
             return r, None
         t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU)
         c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1,

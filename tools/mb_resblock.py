@@ -29,7 +29,7 @@ def chain_time(step_fn, iters=30):
     return timeit(g.replay, iters, 5) / NB
 
 
-for N, H, W in ((4, 32, 32), (4, 24, 24), (1, 32, 32), (8, 32, 32)):
+for N, H, W in ((4, 32, 32), (4, 24, 24), (1, 32, 32), (8, 32, 32)) + (((1, 270, 480),) if "--big" in sys.argv else ()):
     bf = torch.bfloat16
     a = [torch.randn(N, H, W, 64, device=DEV).to(bf) * 0.5 for _ in range(NB + 1)]
     r = [torch.empty(N, H, W, 64, device=DEV, dtype=bf) for _ in range(NB)]
