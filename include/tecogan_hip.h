@@ -100,6 +100,14 @@ int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*
                     const float* bias /*nullable*/, const void* res /*nullable*/,
                     const void* aux /*nullable*/, void* out, void* stream);
 
+/* The throughput-regime 3x3 64 -> 64 bf16 convolution with the weight operand in FRAGMENT order (tg_pack_weights_frag, dst_t for
+ * the forward conv): out = act(conv3x3(x, W) + b) [+ res] -- the generator's residual-block convs at inference resolution
+ * (reference lib/frvsr.py:50-57 through main.py:204; 32 launches per 1080p frame).  Same kernel and arithmetic as
+ * tg_conv_forward takes for this shape (csrc/conv3x3_ws.hip), bit-identical results; the weight prologue reads whole cache lines.
+ * TG_EINVAL below 256 tiles of 8x16 pixels (latency regime: tg_resblock / tg_conv_forward).  act: TG_ACT_NONE/RELU/LRELU. */
+int tg_conv3x3_c64_frag(const void* x, const void* w_frag, const float* bias /*nullable*/, const void* res /*nullable*/, void* out,
+                        int N, int H, int W, int act, float act_alpha, void* stream);
+
 /* Weight gradient of the gather-form convolution described by `d`
  * (X = the tensor that is gathered, [N,Hin,Win,Cin]; Y = per-output-pixel tensor
  * [N,Hout,Wout,Cout]):   dW[tap][cx][cy] += sum_m X[m@tap][cx] * Y[m][cy]   (fp32 atomics)

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtecogan_hip.so")
+# TECOGAN_HIP_LIB: another build of the same library (A/B of compile-time layout constants, tools/build_variant.py)
+LIB_PATH = os.environ.get("TECOGAN_HIP_LIB") or os.path.join(_HERE, "libtecogan_hip.so")
 
 TG_F32, TG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
@@ -53,6 +54,7 @@ SIGNATURES = {
     "tg_hr_tail_backward": [_P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_forward": [_P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_backward": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "tg_conv3x3_c64_frag": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "tg_hr_tail_train": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "tg_act_backward": [_P, _P, _P, _I, _I, _L, _I, _F, _F, _P],
     "tg_concat2_pad": [_P, _I, _P, _I, _P, _I, _I, _L, _F, _P],

@@ -46,10 +46,19 @@ typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 namespace {
-constexpr int WS_TH = 8, WS_HALO = (WS_TH + 2) * 18, WS_ROWB = 144;
-constexpr int WS_SLOTS = WS_HALO * 9;                      // 16-byte slots of one halo tile (8 data + 1 pad per pixel)
+// Pixel pitch of the halo tile: WS_PS slots of 16 bytes (8 data + pad).  Under the gfx950 lane grouping of ds_read_b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) the model of tools/lds_layout_search.py calls a row of 16 pixels x 4 chunks at
+// pitch 144 2-way conflicted and at pitch 160 conflict-free.  Built and measured (-DWS_PS=10 via tools/build_variant.py,
+// profiles/r04o_ab.txt): no difference at any shape (16.3 / 96.8 us against 16.2 / 96.3 us) -- with 36 reads per 144 MFMAs
+// this kernel is not bound by its fragment reads; the smaller tile stays.
+#ifndef WS_PS
+#define WS_PS 9
+#endif
+constexpr int WS_TH = 8, WS_HALO = (WS_TH + 2) * 18, WS_ROWB = WS_PS * 16;
+constexpr int WS_SLOTS = WS_HALO * WS_PS;                  // 16-byte slots of one halo tile (8 data + pad per pixel)
 constexpr int WS_NDMA = (WS_SLOTS + 63) / 64;              // wave-wide DMA instructions per tile (26)
 constexpr int WS_BUF = WS_NDMA * 1024;                     // bytes per halo buffer (26624)
+constexpr int WS_WROWB = 144;                              // weight panel rows (read once per workgroup): 8 data + 1 pad slot
 constexpr int WS_KPW = (WS_NDMA + 3) / 4;                  // DMA instructions per wave (7)
 constexpr int WS_WINST = (9 * 64 * 9 + 63) / 64;           // weight panel: 576 rows x 9 slots (8 data + 1 pad) = 81 instructions
 constexpr int WS_WPANEL = WS_WINST * 1024;                 // 82944 bytes
@@ -76,7 +85,12 @@ extern "C" int tg_debug_ws_trace(unsigned long long* out) {
 // through the texture path (144 KB per workgroup, 10k cycles of the prologue, tools/trace_ws.py) -- for launches with one
 // workgroup per CU and a handful of tiles each (the 1080p inference convs: 4 tiles per CU), where the prologue is a
 // quarter of the kernel.  83 KB more LDS: not with TG_CONV_COEXIST (no room left for a chain workgroup).
-template <bool HAS_RES, bool HAS_AUX, bool WLDS>
+// WFRAG: p.w is the FRAGMENT-ORDER copy of a 64 -> 64 layer ([2 tap + kk][16-channel block][lane][8], tg_pack_weights_frag): each
+// of a wave's 36 weight loads is one contiguous KiB = 8 whole cache lines instead of 64 half lines (DESIGN lesson 17: 43 against
+// 19 B/clk/CU on the miss path), consumed in issue order by the peeled first tile.  The prologue shrinks enough (9.4k cycles of a
+// 32k-cycle launch at the 1080p inference convs, profiles/r04p_trace_ws.txt) for TWO workgroups per CU to pay off at 4 tiles per CU:
+// one workgroup's DMA issue and epilogue (1000 + 1500 of 5600 cycles per tile) run under the other's MFMA block.
+template <bool HAS_RES, bool HAS_AUX, bool WLDS, bool WFRAG = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF [+ WS_WPANEL]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -93,14 +107,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.out), 0, (int)p.out_bytes, 0x00020000);
 
   // ---- LDS-DMA slot descriptors of this lane (tile-independent): slot S = (wave + 4k)*64 + lane holds 16-byte chunk
-  //      c = S % 9 of halo pixel S / 9 (chunk 8 = row padding; chunks past Cin and slots past the tile read zeros).
+  //      c = S % WS_PS of halo pixel S / WS_PS (chunks >= 8 = row padding; chunks past Cin and slots past the tile read zeros).
   int code[WS_KPW];
 #pragma unroll
   for (int k = 0; k < WS_KPW; ++k) {
     const int S = (wave + 4 * k) * 64 + lane;
-    const int pix = S / 9, c = S - 9 * pix;
+    const int pix = S / WS_PS, c = S - WS_PS * pix;
     const int dy = pix / 18, dx = pix - 18 * dy;
-    const bool valid = S < WS_SLOTS && c * 8 < p.Cin;
+    const bool valid = S < WS_SLOTS && c < 8 && c * 8 < p.Cin;
     code[k] = dy | (dx << 8) | (c << 16) | (valid ? (1 << 24) : 0);
   }
 
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             wf[kh * 3 + kw][kk][j] = *reinterpret_cast<const u32x4w*>(
-                wp + ((kh * 3 + kw) * 64 + wn * 32 + j * 16 + frow) * WS_ROWB + kk * 64 + fg * 16);
+                wp + ((kh * 3 + kw) * 64 + wn * 32 + j * 16 + frow) * WS_WROWB + kk * 64 + fg * 16);
   } else {
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw)
@@ -173,10 +187,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
         const int wt = p.flip ? 8 - tap : tap;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
-          const bool ok = co < p.Cout && ci < p.Cin;
-          wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
-              rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
+          if constexpr (WFRAG) {
+            wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, lane * 16, ((wt * 2 + kk) * 4 + wn * 2 + j) * 1024, 0);
+          } else {
+            const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
+            const bool ok = co < p.Cout && ci < p.Cin;
+            wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
+                rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
+          }
         }
       }
   }
@@ -341,9 +359,9 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_ws_kernel(ConvWsP p) {
 #pragma unroll
   for (int k = 0; k < WS_KPW; ++k) {
     const int S = (wave + 4 * k) * 64 + lane;
-    const int pix = S / 9, c = S - 9 * pix;
+    const int pix = S / WS_PS, c = S - WS_PS * pix;
     const int dy = pix / 18, dx = pix - 18 * dy;
-    const bool valid = S < WS_SLOTS && c * 8 < p.Cin;
+    const bool valid = S < WS_SLOTS && c < 8 && c * 8 < p.Cin;
     code[k] = dy | (dx << 8) | (c << 16) | (valid ? (1 << 24) : 0);
   }
   auto issue_dma = [&](int tile, int buf) {
@@ -584,4 +602,46 @@ int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight,
   else if (aux) launch_ws<false, true>(p, st, coexist);
   else launch_ws<false, false>(p, st, coexist);
   return 1;
+}
+
+// The throughput-regime 64 -> 64 conv with the weights handed over in fragment order (the generator's res-block convs at inference
+// resolution, reference lib/frvsr.py:50-57 through main.py:204): out = act(conv3x3(x, W) + b) [+ res].  TG_EINVAL below 256 tiles
+// of 8x16 pixels (the latency regime: tg_resblock / tg_conv_forward).
+extern "C" int tg_conv3x3_c64_frag(const void* x, const void* w_frag, const float* bias, const void* res, void* out, int N, int H,
+                                   int W, int act, float act_alpha, void* stream) {
+  TG_CHECK_ARG(x && w_frag && out && N > 0 && H > 0 && W > 0, "bad argument");
+  TG_CHECK_ARG((((uintptr_t)x | (uintptr_t)w_frag | (uintptr_t)out | (uintptr_t)res) & 15) == 0, "alignment");
+  TG_CHECK_ARG(act == TG_ACT_NONE || act == TG_ACT_RELU || act == TG_ACT_LRELU, "activation");
+  const int64_t px = (int64_t)N * H * W;
+  TG_CHECK_ARG(px * 128 < ((int64_t)1 << 31), "tensor too large for 32-bit buffer offsets");
+  ConvWsP p;
+  p.in = x; p.w = w_frag; p.bias = bias; p.res = res; p.aux = nullptr; p.out = out;
+  p.N = N; p.H = H; p.W = W; p.Cin = 64; p.Cout = 64;
+  p.flip = 0;
+  p.nslope = act == TG_ACT_RELU ? 0.f : (act == TG_ACT_LRELU ? act_alpha : 1.f);
+  p.mslope = 1.f;
+  p.tiles_y = (H + WS_TH - 1) / WS_TH;
+  p.tiles_x = (W + 15) / 16;
+  const int64_t ntiles = (int64_t)N * p.tiles_y * p.tiles_x;
+  TG_CHECK_ARG(ntiles >= 256 && ntiles < ((int64_t)1 << 30), "fewer than 256 tiles: latency regime");
+  p.ntiles = (int)ntiles;
+  p.in_bytes = (unsigned)(px * 128); p.w_bytes = 9 * 64 * 64 * 2; p.out_bytes = (unsigned)(px * 128);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static const int per_cu = getenv("TG_C3WS_FRAG_PER_CU") ? atoi(getenv("TG_C3WS_FRAG_PER_CU")) : 2;      // A/B switch
+  int gx = p.ntiles;
+  if (gx > 256 * per_cu) gx = 256 * per_cu;
+  const int LDS = per_cu == 1 ? 2 * WS_BUF + 32768 : 2 * WS_BUF;
+  const double fl = 2.0 * px * 64 * 9.0 * 64, by = px * 128.0 * (2 + (res != nullptr)) + 73728.0;
+  if (res) {
+    auto kern = conv3x3_ws_kernel<true, false, false, true>;
+    static std::once_flag once;
+    std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_BUF + 32768); });
+    TG_LAUNCH("conv3x3_ws<res,frag>", fl, by, kern, dim3(gx, 1), dim3(256), LDS, st, p);
+  } else {
+    auto kern = conv3x3_ws_kernel<false, false, false, true>;
+    static std::once_flag once;
+    std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_BUF + 32768); });
+    TG_LAUNCH("conv3x3_ws<frag>", fl, by, kern, dim3(gx, 1), dim3(256), LDS, st, p);
+  }
+  TG_CHECK_LAUNCH();
 }

@@ -183,6 +183,20 @@ def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out, w_frag=False):
     return out
 
 
+def conv3x3_c64_frag_ok(N, H, W):
+    """The throughput regime of tg_conv3x3_c64_frag: at least 256 tiles of 8x16 pixels."""
+    return N * ((H + 7) // 8) * ((W + 15) // 16) >= 256
+
+
+def conv3x3_c64_frag(x, w_frag, bias, res, out, act=0, alpha=0.0):
+    """out = act(conv3x3(x, W) + b) [+ res], 64 -> 64 bf16, W in fragment order (csrc/conv3x3_ws.hip)."""
+    N, H, W, C = x.shape
+    assert C == 64 and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tuple(out.shape) == tuple(x.shape)
+    check(lib().tg_conv3x3_c64_frag(_p(x), _p(w_frag), _p(bias), _p(res), _p(out), N, H, W, act, alpha, _stream()),
+          "tg_conv3x3_c64_frag")
+    return out
+
+
 def hr_tail_backward(d_frame, scale, w_out, t2, w_tr_frag, t1, g_out, g_t2, g_t1):
     """Frame gradient -> g_out, g_t2, g_t1 in one launch (csrc/hr_bwd_lat.hip; bf16): see tg_hr_tail_backward."""
     N, H2, W2, C = t1.shape

@@ -145,6 +145,7 @@ class Generator:
         # fused HR tail of the stateless (inference) forward (csrc/hr_tail.hip); TG_HR_TAIL=0 is the A/B switch
         # (1080p frame 1.103 -> 1.068 ms, profiles/r03a_ab.txt)
         self.hr_tail = os.environ.get("TG_HR_TAIL", "1") == "1"
+        self.ws_frag = os.environ.get("TG_C3WS_FRAG", "1") == "1"             # A/B: 0 = tg_conv_forward with the row-major operand
         self.hr_tail_lat = os.environ.get("TG_HR_TAIL_LAT", "1") == "1"        # A/B: 0 = csrc/hr_tail.hip in the stateless forward
         # one launch per residual block in the training recurrence (csrc/resblock_lat.hip: bf16 frames in the latency regime);
         # TG_RESBLOCK_LAT=0 is the A/B switch (two tg_conv_forward launches per block, bit-identical results)
@@ -167,8 +168,16 @@ class Generator:
         # (one launch per residual block -- r kept in LDS, both convs on MFMA -- was built and measured in round 3: parity
         #  green, 35.2 us per block against 35.3 us for these two launches: bound by 2-way-conflicted LDS fragment reads under
         #  the gfx950 ds_read_b128 lane grouping; numbers and cycle stamps in profiles/r03p_resblock_ws.txt, kernel deleted)
+        wsf = self.ws_frag and ps.frag and a.dtype == torch.bfloat16 and K.conv3x3_c64_frag_ok(*a.shape[:3])
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
+            if wsf:
+                # same kernel, weights in fragment order: whole-line weight loads, two workgroups per CU (csrc/conv3x3_ws.hip)
+                r = K.conv3x3_c64_frag(a, ps.packed_frag(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"), None,
+                                       torch.empty_like(a), ACT_RELU)
+                a = K.conv3x3_c64_frag(r, ps.packed_frag(s + "conv_2/Conv/weights", True), ps.view(s + "conv_2/Conv/biases"), a,
+                                       torch.empty_like(a), ACT_NONE)
+                continue
             r = conv_fwd(ps, s + "conv_1/Conv/weights", s + "conv_1/Conv/biases", a, 1, ACT_RELU)
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"

@@ -880,6 +880,26 @@ def test_conv3x3_weights_in_registers_kernel(case, coexist):
 
 
 # ---- vectorised HBM-bound kernels of the inference step ---------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(1, 270, 480), (2, 128, 136), (1, 250, 130)])
+@pytest.mark.parametrize("has_res,act", [(False, ACT_RELU), (True, ACT_NONE)])
+def test_conv3x3_fragment_order_weights_entry_is_bit_identical(shape, has_res, act):
+    """tg_conv3x3_c64_frag (the inference step's res-block convs: weight operand in fragment order, two workgroups per CU)
+    against tg_conv_forward on the same kernel with the row-major operand: same MFMA order -> bit-identical."""
+    N, H, W = shape
+    x = rnd(N, H, W, 64, seed=1).bfloat16().to(DEV)
+    wt = rnd(9, 64, 64, seed=2, scale=0.1).bfloat16().to(DEV)            # [tap][Cout][Cin]
+    b = rnd(64, seed=3).to(DEV)
+    res = rnd(N, H, W, 64, seed=4).bfloat16().to(DEV) if has_res else None
+    ref = torch.full((N, H, W, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    out = torch.full_like(ref, 5.0)
+    d = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, act, 0.0)
+    K.conv_forward(d, x, wt, b, res, None, ref)
+    K.conv3x3_c64_frag(x, K.frag_order(wt), b, res, out, act)
+    assert torch.equal(out, ref)
+    with pytest.raises(Exception):
+        K.conv3x3_c64_frag(x[:, :32, :32].contiguous(), K.frag_order(wt), b, None, out[:, :32, :32].contiguous(), act)
+
 @pytest.mark.parametrize("B,h,w", [(1, 5, 9), (2, 33, 47), (1, 270, 480)])
 def test_warp_s2d_forward_bf16_vectorised_rows(B, h, w):
     """The LDS-assembled 16-byte-row form (bf16, Cpad 56) incl. pixel counts that are not multiples of 4 / of the grid and
