@@ -160,11 +160,16 @@ def run_inference(FLAGS):
 
 def _inference_loop(FLAGS, data, eng, writer, image_dir, max_iter):
     srtime = 0.0
+
+    def upload(i):
+        return torch.from_numpy(data.inputs[i].copy()).float()[None].cuda() if i < max_iter else None
+
+    nxt = upload(0)
     for i in range(max_iter):
-        frame = torch.from_numpy(data.inputs[i].copy()).float()[None].cuda()
+        frame, nxt = nxt, upload(i + 1)           # the clip is known up front: the engine computes frame i+1's flow beside frame i
         torch.cuda.synchronize()
         t0 = time.time()
-        out = eng.step(frame)
+        out = eng.step(frame, next_frame=nxt)
         torch.cuda.synchronize()
         srtime += time.time() - t0
         if i >= 5:

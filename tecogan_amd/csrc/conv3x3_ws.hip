@@ -106,6 +106,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_RES ? p.res : p.out), 0, (int)p.out_bytes, 0x00020000);
   const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_AUX ? p.aux : p.out), 0, (int)p.out_bytes, 0x00020000);
 
+  u32x4w wf[9][2][2];
+  // WFRAG: the weight stream starts before anything else (its addresses are lane * 16 + constants): the 12 fragments of the first
+  // tap column go out ahead of the halo tile's DMA descriptors (2.5k cycles of address arithmetic and DMA issue in the trace),
+  // the other 24 right after the DMA -- the first tile then waits for vmcnt(24): DMA and first column landed.
+  auto load_frag = [&](const int kw_lo, const int kw_hi) {
+#pragma unroll
+    for (int kw = kw_lo; kw < kw_hi; ++kw)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int tap = kh * 3 + kw;
+          const int wt = p.flip ? 8 - tap : tap;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, lane * 16, ((wt * 2 + kk) * 4 + wn * 2 + j) * 1024, 0);
+        }
+  };
+  if constexpr (WFRAG) {
+    if ((int)blockIdx.x >= p.ntiles) return;
+    load_frag(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
   // ---- LDS-DMA slot descriptors of this lane (tile-independent): slot S = (wave + 4k)*64 + lane holds 16-byte chunk
   //      c = S % WS_PS of halo pixel S / WS_PS (chunks >= 8 = row padding; chunks past Cin and slots past the tile read zeros).
   int code[WS_KPW];
@@ -147,8 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   //      while the rest are still streaming in (the compiler places the counted vmcnt waits), instead of draining all 36
   //      loads first -- at kernel start every wave of the chip pulls its 36 KB through the texture path at once and the
   //      full drain cost 13k of the 23k prologue cycles (tools/trace_ws.py).
-  u32x4w wf[9][2][2];
-  if constexpr (WLDS) {
+  if constexpr (WFRAG) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_frag(1, 3);
+  } else if constexpr (WLDS) {
     // panel row R = tap * 64 + channel (of this block), 144-byte pitch as the halo; slot S = instruction * 64 + lane
     unsigned char* wp = smem + 2 * WS_BUF;
 #pragma unroll
@@ -187,14 +213,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
         const int wt = p.flip ? 8 - tap : tap;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if constexpr (WFRAG) {
-            wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, lane * 16, ((wt * 2 + kk) * 4 + wn * 2 + j) * 1024, 0);
-          } else {
-            const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
-            const bool ok = co < p.Cout && ci < p.Cin;
-            wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
-                rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
-          }
+          const int co = cbase + j * 16 + frow, ci = kk * 32 + fg * 8;
+          const bool ok = co < p.Cout && ci < p.Cin;
+          wf[tap][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(
+              rsrcW, (int)(ok ? (unsigned)(((wt * p.Cout + co) * p.Cin + ci) * 2) : WS_OOB), 0, 0);
         }
       }
   }
@@ -213,7 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   // (vmcnt retires in issue order on gfx9-family parts) -- draining the stores too (vmcnt(0), or the vmcnt(0) that
   // __syncthreads() adds while a DMA is in flight) exposed a full store round trip per tile.  Hence also the raw s_barrier.
   WS_STAMP(2);                                              // weight loads issued
-  if constexpr (!WLDS) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // first tile: this wave's DMA slots (all but the 36 weight loads)
+  if constexpr (WFRAG) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // first tile: DMA slots + first tap column (all but the 24 later loads)
+  else if constexpr (!WLDS) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // first tile: this wave's DMA slots (all but the 36 weight loads)
   WS_STAMP(3);
   int buf = 0;
   [[maybe_unused]] int it = 0;

@@ -10,7 +10,15 @@ warp + space-to-depth kernel writes the generator input directly.  Per frame (ma
     pre_gen = deprocess(generator_F(x_in))
 The reference skips the FNet/warp on the first frame (pre_warp is still zero, main.py:257); running it is
 equivalent because warping the all-zero initial pre_gen yields zeros, so one graph serves every frame.
+
+Frame lookahead.  flow(t+1) depends on LR frames only (main.py:201-203: fnet sees pre_inputs and the new frame, never the HR
+state), and the reference's loop holds the whole clip before it starts (lib/dataloader.py:30-60).  `step(frame, next_frame=...)`
+therefore runs FNet for the NEXT frame on a second HIP stream beside this frame's generator (forked after the warp kernel, joined
+at the end of the step, both inside the one captured graph): the 14 small FNet convs (0.22 of a 1.0 ms 1080p frame,
+profiles/r03z_infer1080p_bf16_kernel_stats.txt) leave the frame's critical path.  The announced frame is a promise: the next call
+must pass that frame (TG_CHECK_LOOKAHEAD=1 verifies it); without `next_frame` the step computes its own flow first, as before.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -31,9 +39,15 @@ class InferenceEngine:
         self.ps.load(vals)
         self.G, self.Fn = Generator(self.ps, num_resblock), FNet(self.ps)
         self.frame = torch.zeros(batch, h, w, 3, device=self.dev)                 # static input (placeholder)
+        self.frame_next = torch.zeros(batch, h, w, 3, device=self.dev)            # the announced next frame
         self.pre_inputs = torch.zeros(batch, h, w, 3, device=self.dev)
         self.pre_gen = torch.zeros(batch, 4 * h, 4 * w, 3, device=self.dev)
-        self.use_graph, self.graph = use_graph, None
+        self.flow_next = torch.zeros(batch, h - h % 8, w - w % 8, 2, device=self.dev)   # flow(frame -> frame_next), side stream
+        self.lookahead = os.environ.get("TG_INFER_LOOKAHEAD", "1") == "1"         # A/B: 0 ignores next_frame
+        self.check_lookahead = os.environ.get("TG_CHECK_LOOKAHEAD", "0") == "1"
+        self._have_flow = False                                                    # flow_next belongs to the coming step
+        self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self.use_graph, self.graphs = use_graph, {}
 
     def load(self, values):
         """values: TF-variable-name -> tensor for the 'generator' and 'fnet' scopes (main.py:221-224)."""
@@ -42,39 +56,61 @@ class InferenceEngine:
     def reset(self):
         self.pre_inputs.zero_()
         self.pre_gen.zero_()
+        self._have_flow = False
 
-    def _program(self):
+    def _flow(self, prev, cur):
         B, h, w = self.B, self.h, self.w
-        fin = K.concat2_pad(self.pre_inputs, self.frame,
-                            torch.empty(B, h, w, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
-        flow, _ = self.Fn.forward(fin, keep=False)                                # [B, h-h%8, w-w%8, 2]
+        fin = K.concat2_pad(prev, cur, torch.empty(B, h, w, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
+        return self.Fn.forward(fin, keep=False)[0]                                 # [B, h-h%8, w-w%8, 2]
+
+    def _program(self, have_flow, ahead):
+        """have_flow: flow_next (computed beside the previous frame) is this frame's flow; ahead: compute the next one."""
+        B, h, w = self.B, self.h, self.w
+        flow = self.flow_next if have_flow else self._flow(self.pre_inputs, self.frame)
         x_in = torch.empty(B, h, w, GEN_CPAD, device=self.dev, dtype=self.act_dtype)
         K.warp_s2d_forward(self.pre_gen, flow, self.frame, x_in, 1.0, 0.0)        # state already in [0,1]
+        main = torch.cuda.current_stream()
+        if ahead:
+            self.side.wait_stream(main)                                            # the warp has consumed flow_next
+            with torch.cuda.stream(self.side):
+                self.flow_next.copy_(self._flow(self.frame, self.frame_next))
         # generator; the fused bicubic / preprocess epilogue writes deprocess(frame) straight into the recurrent state
         # (the warp kernel above has consumed the old state by then: stream order)
         self.G.forward(x_in, keep=False, out=False, state=self.pre_gen)
         self.pre_inputs.copy_(self.frame)
+        if ahead:
+            main.wait_stream(self.side)
 
-    def step(self, frame=None):
-        """frame: [B,h,w,3] fp32 in [0,1] (device tensor).  Returns the HR frame [B,4h,4w,3] in [0,1]
-        (a view of the recurrent state: copy it if you keep it across steps)."""
+    def step(self, frame=None, next_frame=None):
+        """frame: [B,h,w,3] fp32 in [0,1] (device tensor).  next_frame: the frame the NEXT call will pass (its flow is computed
+        beside this frame's generator).  Returns the HR frame [B,4h,4w,3] in [0,1] (a view of the recurrent state: copy it if
+        you keep it across steps)."""
         if frame is not None:
+            if self._have_flow and self.check_lookahead:
+                assert torch.equal(self.frame_next, frame.to(self.frame_next.device)), "step(): not the announced frame"
             self.frame.copy_(frame, non_blocking=True)
+        ahead = self.lookahead and next_frame is not None
+        if ahead:
+            self.frame_next.copy_(next_frame, non_blocking=True)
+        key = (self._have_flow, ahead)
         if not self.use_graph:
-            self._program()
+            self._program(*key)
         else:
-            if self.graph is None:
-                keep = (self.pre_inputs.clone(), self.pre_gen.clone())
+            if key not in self.graphs:
+                keep = (self.pre_inputs.clone(), self.pre_gen.clone(), self.flow_next.clone())
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
-                    self._program()
+                    self._program(*key)
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 self.pre_inputs.copy_(keep[0])
                 self.pre_gen.copy_(keep[1])
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._program()
-            self.graph.replay()
+                self.flow_next.copy_(keep[2])
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._program(*key)
+                self.graphs[key] = g
+            self.graphs[key].replay()
+        self._have_flow = ahead
         return self.pre_gen

@@ -10,15 +10,17 @@ ap.add_argument("--h", type=int, default=270); ap.add_argument("--w", type=int, 
 ap.add_argument("--frames", type=int, default=60); ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--nres", type=int, default=16)
 ap.add_argument("--no-graph", action="store_true")
+ap.add_argument("--no-lookahead", action="store_true")
 a = ap.parse_args()
 tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 eng = InferenceEngine(a.nres, a.h, a.w, "cuda", tdt, use_graph=not a.no_graph)
 frames = torch.rand(8, 1, a.h, a.w, 3, device="cuda")
+nx = (lambda i: None) if a.no_lookahead else (lambda i: frames[(i + 1) % 8])
 for i in range(a.warmup):
-    eng.step(frames[i % 8])
+    eng.step(frames[i % 8], next_frame=nx(i))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(a.frames):
-    eng.step(frames[i % 8])
+    eng.step(frames[(a.warmup + i) % 8], next_frame=nx(a.warmup + i))
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 gflop = 2 * (184.2 + 16.2) * (a.h * a.w) / (270 * 480) * (1 if a.nres == 16 else 0.7)
 print(json.dumps({"metric": "inference HR fps", "value": round(a.frames / dt, 2), "ms_per_frame": round(dt / a.frames * 1e3, 3),
