@@ -249,8 +249,7 @@ int tg_hr_tail_backward(const float* d_frame, float scale, const void* w_out, co
  *   tg_hr_tail_train:      t2 = relu(conv2d_transpose_k3s2(t1, W2) + b2) (stored when t2 != NULL: the backward pass needs it) and
  *                          frame = (conv3x3(t2, W3) + b3 + bicubic_four(LR)) * 2 - 1, frame [N,2H1,2W1,3] fp32;
  *                          state = (frame + 1) / 2 (the inference loop's recurrent state, main.py:207); frame or state may be
- *                          NULL.  From 2048 tiles of 8x16 outputs up (the 1080p inference frame) the launch is persistent: two
- *                          workgroups per CU walk the tiles with both convs' weights resident in registers.
+ *                          NULL.  With t2 == NULL this is also the inference frame's tail (main.py:195-216).
  * w_frag / w2_frag: the transposed conv's [tap][out][in] operand (TF's [kh,kw,Cout,Cin] as stored) in FRAGMENT order
  * (tg_pack_weights_frag, dst_n); w3 [9][3][64] = the output conv's [tap][out][in] copy; gen_in as in tg_bicubic_add_preprocess. */
 int tg_deconv_lat_forward(const void* x, const void* w_frag, const float* bias, void* y, int N, int H1, int W1, void* stream);

@@ -62,11 +62,12 @@ __device__ __forceinline__ void hf_static_for(F&& f) {
   }
 }
 
-// PERSIST (the inference step's tail at 1080p: 16200 tiles): a workgroup walks tiles blockIdx.x, + gridDim.x, ... with BOTH convs'
-// weight fragments resident in registers (144 VGPRs) instead of re-streaming 91 KB per tile; two workgroups per CU hide each other's
-// region loads and barriers.  (Without it the per-tile kernel already beats hr_tail.hip at 1080p, 227 -> 164 us, profiles/r04m_ab.txt:
-// that kernel's output-conv loop serialises 18 dependent MFMAs and four dependent global loads per 16 pixels at one wave per SIMD.)
-template <bool FUSE, bool PERSIST>
+// The same launch serves the inference frame (t2 == NULL, 16200 tiles at 1080p): 227 -> 164 us against csrc/hr_tail.hip, whose
+// output-conv loop serialises 18 dependent MFMAs and four dependent global loads per 16 pixels at one wave per SIMD.  A PERSISTENT
+// variant (two workgroups per CU walking the tiles with both convs' 36 weight fragments resident in 144 registers) was built,
+// bit-identical, and measured SLOWER (176 us, profiles/r04n_ab.txt): at two waves per SIMD nothing hides a wave's region loads and
+// barriers, while four small workgroups per CU re-streaming 91 KB of L2-resident weights per tile do; deleted.
+template <bool FUSE>
 __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
   // phase geometry: NA x NB pixels per phase; the fused tail also needs the one-pixel ring of t2 around its own block
   constexpr int NA = FUSE ? HF_TI + 1 : HF_TI, NB = FUSE ? HF_TJ + 1 : HF_TJ;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fg = lane >> 4;
-  if (!PERSIST && p.prio) __builtin_amdgcn_s_setprio(3);
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   const int Ho = 2 * p.H1, Wo = 2 * p.W1;
   const int cbyte = (wave * 16 + fg * 4) * 2;
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
 #define HF_WLOAD(i) __builtin_amdgcn_raw_buffer_load_b128(rsW, wlane, (hf_tap_order(((i) < 18 ? (i) : 0) >> 1) * 2 + ((i) & 1)) * 4096, 0)
 #define HF_WISSUE(i)                                                  \
   do {                                                                \
-    if constexpr (!PERSIST && (i) < 18) wB[(i) < 18 ? (i) : 0] = HF_WLOAD(i); \
+    if constexpr ((i) < 18) wB[(i) < 18 ? (i) : 0] = HF_WLOAD(i);             \
   } while (0)
   auto load_w3 = [&]() {
     if constexpr (FUSE) {
@@ -107,10 +108,6 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
         w3f[s] = __builtin_amdgcn_raw_buffer_load_b128(rsW3, (int)(frow < 3 ? (unsigned)((((s >> 1) * 3 + frow) * 64 + (s & 1) * 32 + fg * 8) * 2) : HF_OOB), 0, 0);
     }
   };
-  if constexpr (PERSIST) {
-    hf_static_for<0, 18>([&](auto i) { wB[decltype(i)::value] = HF_WLOAD(decltype(i)::value); });
-    load_w3();
-  }
   const float bv[4] = {__uint_as_float(bq.x), __uint_as_float(bq.y), __uint_as_float(bq.z), __uint_as_float(bq.w)};
   const float b3[3] = {FUSE && p.b3 ? p.b3[0] : 0.f, FUSE && p.b3 ? p.b3[1] : 0.f, FUSE && p.b3 ? p.b3[2] : 0.f};
   const int h = p.H1 >> 1, w = p.W1 >> 1;
@@ -126,9 +123,9 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
     ppb[t] = mm - ppa[t] * NB;
   }
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    int b = tile;
-    if (!PERSIST && (p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);      // an XCD owns a contiguous range of tiles
+  {
+    int b = blockIdx.x;
+    if ((p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);      // an XCD owns a contiguous range of tiles
     const int tj = b % p.tiles_j, tq = b / p.tiles_j;
     const int ti = tq % p.tiles_i, n = tq / p.tiles_i;
     const int i0 = ti * HF_TI, j0 = tj * HF_TJ;
@@ -151,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
       const int item = tid + k * 256;
       if (item < XITEMS) *reinterpret_cast<u32x4f*>(xs + (item >> 3) * HF_P + (item & 7) * 16) = xr[k];
     }
-    __syncthreads();                               // (also: every wave has left the previous tile's output-conv reads of bs)
+    __syncthreads();
 
     // ---- the four phases: out[2a+py, 2b+px]; a = i0 + pa - (FUSE and py), b likewise; the input pixel of tap (ky, kx) is
     //      (a - (ky == 2), b - (kx == 2)) = region position (pa + 1 - (FUSE and py) - (ky == 2), ...) ------------------------------
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
     });
     if constexpr (FUSE) {
       // ---- fused tail: output conv (64 -> 3) + bicubic_four(LR) skip + value range, as hr_tail.hip ----------------------------
-      if constexpr (!PERSIST) load_w3();
+      load_w3();
       __syncthreads();                                   // the ring block is complete
 #pragma unroll
       for (int g = 0; g < 2; ++g) {                       // this wave's two rows of the own 8 x 16 block: lane frow = column
@@ -219,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
         }
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned char* Bf = bs + (yl * BW + frow) * HF_P + fg * 16;
-        constexpr int CH = PERSIST ? 6 : 18;              // (resident weights leave room for one tap row of fragments at a time)
+        constexpr int CH = 18;
 #pragma unroll
         for (int c0 = 0; c0 < 18; c0 += CH) {
           uint4 bfr[CH];
@@ -254,7 +251,6 @@ __global__ __launch_bounds__(256, 2) void hr_fwd_lat_kernel(HfP p) {
         __builtin_amdgcn_raw_buffer_store_b96(os, rsS, (int)off, 0, 0);
       }
     }
-    if constexpr (!PERSIST) break;
   }
 #undef HF_WISSUE
 #undef HF_WLOAD
@@ -277,15 +273,11 @@ static int hf_launch(bool fuse, const void* x, const void* w_frag, const float* 
   p.prio = prio;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double fl = 2.0 * px * 64 * 64 * 9.0;
-  // throughput regime (the inference stream: thousands of tiles): persistent workgroups, two per CU, weights resident in registers
-  static const int persist_min = getenv("TG_HR_TAIL_PERSIST_MIN") ? atoi(getenv("TG_HR_TAIL_PERSIST_MIN")) : 2048;
-  if (fuse && p.ntiles >= persist_min)
-    TG_LAUNCH("hr_fwd_lat<tail,persistent>", fl + 2.0 * 4 * px * 9.0 * 64 * 3, px * 128.0 * (1 + 4 * (y != nullptr)) + 4.0 * px * 12 * ((frame != nullptr) + (state != nullptr)) + 73728.0,
-              (hr_fwd_lat_kernel<true, true>), dim3(512), dim3(256), 0, st, p);
-  else if (fuse)
-    TG_LAUNCH("hr_fwd_lat<tail>", fl + 2.0 * 4 * px * 9.0 * 64 * 3, px * 128.0 * 5 + 4.0 * px * 12 + 73728.0, (hr_fwd_lat_kernel<true, false>),
+  if (fuse)
+    TG_LAUNCH("hr_fwd_lat<tail>", fl + 2.0 * 4 * px * 9.0 * 64 * 3,
+              px * 128.0 * (1 + 4 * (y != nullptr)) + 4.0 * px * 12 * ((frame != nullptr) + (state != nullptr)) + 73728.0, hr_fwd_lat_kernel<true>,
               dim3(p.ntiles), dim3(256), 0, st, p);
-  else TG_LAUNCH("hr_fwd_lat<deconv>", fl, px * 128.0 * 5 + 73728.0, (hr_fwd_lat_kernel<false, false>), dim3(p.ntiles), dim3(256), 0, st, p);
+  else TG_LAUNCH("hr_fwd_lat<deconv>", fl, px * 128.0 * 5 + 73728.0, hr_fwd_lat_kernel<false>, dim3(p.ntiles), dim3(256), 0, st, p);
   TG_CHECK_LAUNCH();
 }
 
