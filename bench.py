@@ -43,8 +43,8 @@ def _newest(*names):
 
 
 # rocprofv3 --pmc passes summarised by tools/pmc_summary.py (newest session first)
-PMC_FILES = {"train": _newest("r03_pmc_train.json", "r02u_pmc_train.json", "r02g_pmc_train.json"),
-             "infer": _newest("r03_pmc_infer.json", "r02u_pmc_infer.json", "r02g_pmc_infer.json")}
+PMC_FILES = {"train": _newest("r04_pmc_train.json", "r03_pmc_train.json", "r02u_pmc_train.json"),
+             "infer": _newest("r04_pmc_infer.json", "r03_pmc_infer.json", "r02u_pmc_infer.json")}
 
 
 def parse():
@@ -227,7 +227,7 @@ def build_roofline(config, dtype, device, with_inference):
     r = roofline_entry(dom, nstep, dtype, pmc)
     r["share_of_profiled_kernel_time"] = round(dom["total_us"] / tot, 4)
     r["source"] = ("dispatch start/stop timestamps (hipExtLaunchKernel events on the launch stream) of every instrumented "
-                   "launch of %d eager steps of the timed workload; committed rocprofv3 summaries: profiles/r03_*_kernel_stats.txt" % nstep)
+                   "launch of %d eager steps of the timed workload; committed rocprofv3 summaries: profiles/r04_*_kernel_stats.txt" % nstep)
     r["top_kernels"] = [roofline_entry(e, nstep, dtype, pmc) for e in ents[1:6]]
     mf = [e for e in ents if e["flops"] > 0]
     r["all_mfma_kernels"] = {"flop_per_step": sum(e["flops"] for e in mf) / nstep,

@@ -9,10 +9,22 @@ def tg_name(k):
     if m:
         base = "conv3x3_tile<%s,%s,%s,%s" % (_T[m.group(1)], _T[m.group(2)], m.group(3), m.group(4))
         return base + (",pack%s>" % m.group(5) if m.group(5) and m.group(5) != "1" else ">")
-    m = re.search(r"conv3x3_ws_kernel<(true|false), (true|false)(?:, (?:true|false))?>", k)
+    m = re.search(r"conv3x3_ws_kernel<(true|false), (true|false)(?:, (?:true|false))?(?:, (true|false))?>", k)
     if m:
-        tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
+        tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2)), ("frag", m.group(3))) if on == "true"]
         return "conv3x3_ws<%s>" % ",".join(tags)
+    m = re.search(r"resblock_lat_kernel<(true|false), (true|false)", k)        # <HAS_AUX1, HAS_AUX2, FRAG, DIST>
+    if m:
+        return {("false", "false"): "resblock_lat<fwd>", ("true", "false"): "resblock_lat<bwd>",
+                ("false", "true"): "resblock_lat<mask2>", ("true", "true"): "resblock_lat<bwd,mask2>"}[m.groups()]
+    m = re.search(r"hr_fwd_lat_kernel<(true|false)>", k)
+    if m:
+        return "hr_fwd_lat<tail>" if m.group(1) == "true" else "hr_fwd_lat<deconv>"
+    m = re.search(r"deconv_bwd_lat_kernel<(true|false)>", k)
+    if m:
+        return "deconv_bwd_lat<aux>" if m.group(1) == "true" else "deconv_bwd_lat<>"
+    if "hr_bwd_lat_kernel" in k:
+        return "hr_bwd_lat"
     m = re.search(r"conv3x3_dma_kernel<(true|false), (true|false)(?:, (\d+))?>", k)
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
