@@ -160,7 +160,8 @@ class TrainEngine:
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Measured in
         # round 4 (same box, profiles/r04a_ab.txt): 10.97 -> 10.66 ms per TecoGAN step; TG_VGGT_DEDUP=0 is the A/B switch.
         self.vggt_dedup = os.environ.get("TG_VGGT_DEDUP", "1") == "1" and bool(F.pingpang) and self.T0 > 1
-        self.fnet_bwd_split = int(os.environ.get("TG_FNET_BWD_SPLIT", "0"))       # pair index k, 0 = off (see _program_compute)
+        self.bwd_cut = int(os.environ.get("TG_BWD_CUT", "0"))                      # frame index k, 0 = off (see _program_compute)
+        self.bwd_cut_parts = int(os.environ.get("TG_BWD_CUT_PARTS", "3"))
         # Target LOOKAHEAD (round 4).  The target features depend on the data only, and before the BPTT the side stream is the
         # step's critical path (target pass 1.4 ms + D real pass + 4 ms of VGG passes over the generated frames,
         # profiles/r04c_ab.txt) while it idles ~2 ms during the BPTT.  A caller that knows the NEXT batch's targets
@@ -379,12 +380,12 @@ class TrainEngine:
             self.D.set_scratch(None)
         if self._skip_update:
             return
-        after = ["down", "wgrad", "fnet_bwd_a"]
+        after = ["down", "wgrad", "early"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["down", "wgrad", "fnet_bwd_a", "ar_d", "ar_g", "ar_f"]
+            after = ["down", "wgrad", "early", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
 
@@ -585,10 +586,13 @@ class TrainEngine:
                 K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
                                         gd["off"], gd["merge"])
                 hold.append(dx)
-        # TG_FNET_BWD_SPLIT=k (round 4): FNet's backward pass in two batch slices -- the pairs [k, T-1), whose flow gradients are
-        # final once the BPTT has passed frame k+1, on the SIDE stream beside the BPTT of frames k..0 (the side stream idles there
-        # after the target lookahead); the pairs [0, k) after the BPTT as before.  Weight gradients accumulate (fp32 atomics).
-        fk = self.fnet_bwd_split if (split and (tail_split or gw_side) and 0 < self.fnet_bwd_split < T - 1) else 0
+        # TG_BWD_CUT=k (round 4, off by default): the BPTT in two segments, frames T-1..k+1 and k..0; what is final after the first
+        # one runs on the SIDE stream beside the second (the side stream idles there once the target lookahead is through):
+        #   TG_BWD_CUT_PARTS bit 1: FNet's backward pass of the pairs [k, T-1) (their flow gradients are complete),
+        #                    bit 2: the generator's weight gradients of the frames [k+1, T).
+        # The rest follows the BPTT as before.  Weight gradients accumulate (fp32 atomics), so the slices add up.
+        fk = self.bwd_cut if (split and (tail_split or gw_side) and 0 < self.bwd_cut < T - 1) else 0
+        f_early, w_early = bool(fk and self.bwd_cut_parts & 1), bool(fk and self.bwd_cut_parts & 2)
 
         def fnet_slice(a, b):
             sl = slice(a * B, b * B)
@@ -604,20 +608,23 @@ class TrainEngine:
                 self.Fn.backward(fsaved, d_flow)
         bwd_last = "bwd_b"
         if fk:
-            with seg("fnet_bwd_a", "S", ["bwd_b"]):
-                self.Fn.backward(*fnet_slice(fk, T - 1), flags=K.CONV_COEXIST)
+            with seg("early", "S", ["bwd_b"]):
+                if w_early:
+                    self.G.wgrad_sequence(fk + 1, T, flags=K.CONV_COEXIST)
+                if f_early:
+                    self.Fn.backward(*fnet_slice(fk, T - 1), flags=K.CONV_COEXIST)
             with seg("bwd_c", "M", []):
                 backward_frames(fk + 1, 0)
             bwd_last = "bwd_c"
         if tail_split or gw_side:
             with seg("wgrad", "S" if gw_side else "M", [bwd_last]):      # (bit 32: beside FNet's backward pass)
-                self.G.wgrad_sequence(0, T)
+                self.G.wgrad_sequence(0, fk + 1 if w_early else T)
             self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
             # (FNet's 14 weight gradients behind the generator's on the side stream, its input-gradient chain alone on the
             #  main stream: measured no gain -- 12.69 vs 12.73 ms, profiles/r03j_ab.txt -- the pieces serialise on each other)
             with seg("fnet_bwd"):
-                self.Fn.backward(*(fnet_slice(0, fk) if fk else (fsaved, d_flow)))
-            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd", "fnet_bwd_a"])
+                self.Fn.backward(*(fnet_slice(0, fk) if f_early else (fsaved, d_flow)))
+            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd", "early"])
 
     @staticmethod
     def _vgg_cuts(T):

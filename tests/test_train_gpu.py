@@ -207,18 +207,19 @@ def test_target_lookahead_equals_in_step_target_features():
 
 
 @pytest.mark.parametrize("gan", [True, False])
-def test_fnet_backward_in_two_batch_slices_equals_one_pass(gan, monkeypatch):
-    """TG_FNET_BWD_SPLIT=k: FNet's backward pass of the pairs [k, T-1) runs on the side stream beside the BPTT of frames k..0
-    (segments fnet_bwd_a / bwd_c), the pairs [0, k) after it; weight gradients accumulate.  Same gradients as the one-pass
-    schedule up to the order of the fp32 atomics; the update then sees both slices (weights equal after two steps)."""
+def test_bptt_cut_with_early_fnet_and_weight_gradient_slices_equals_one_pass(gan, monkeypatch):
+    """TG_BWD_CUT=k: the BPTT in two segments (bwd_b: frames T-1..k+1, bwd_c: k..0); FNet's backward pass of the pairs [k, T-1)
+    and the generator's weight gradients of the frames [k+1, T) run on the side stream beside the second one (segment `early`),
+    the rest after it; weight gradients accumulate.  Same gradients as the one-pass schedule up to the order of the fp32
+    atomics; the update then sees both slices."""
     F = OT.default_flags(batch_size=2, RNN_N=4, crop_size=16, num_resblock=2) if gan else \
         OT.frvsr_flags(batch_size=2, RNN_N=4, crop_size=16, num_resblock=2)
     x, y = (t.to(DEV) for t in make_batch(2, F.RNN_N, F.crop_size, seed=5))
-    monkeypatch.delenv("TG_FNET_BWD_SPLIT", raising=False)
+    monkeypatch.delenv("TG_BWD_CUT", raising=False)
     a = TrainEngine(F, DEV, gan=gan, act_dtype=torch.float32, seed=42, use_graph=True)
-    monkeypatch.setenv("TG_FNET_BWD_SPLIT", "3" if gan else "2")
+    monkeypatch.setenv("TG_BWD_CUT", "3" if gan else "2")
     b = TrainEngine(F, DEV, gan=gan, act_dtype=torch.float32, seed=42, use_graph=True)
-    assert a.fnet_bwd_split == 0 and b.fnet_bwd_split > 0
+    assert a.bwd_cut == 0 and b.bwd_cut > 0 and b.bwd_cut_parts == 3
     for i in range(2):
         a.step(x, y)
         b.step(x, y)
@@ -231,7 +232,7 @@ def test_fnet_backward_in_two_batch_slices_equals_one_pass(gan, monkeypatch):
         assert rel_err(b.gen, a.gen) < (1e-5 if i == 0 else 1e-3)
     names = [s_["name"] for s_ in b._segs]
     if len(names) > 1:                                # (a step without side-stream pieces is one flat graph: nothing to split)
-        assert "fnet_bwd_a" in names and "bwd_c" in names and "fnet_bwd_a" not in [s_["name"] for s_ in a._segs]
+        assert "early" in names and "bwd_c" in names and "early" not in [s_["name"] for s_ in a._segs]
     la, lb = a.losses(), b.losses()
     for k in la:
         assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(la[k])), (k, la[k], lb[k])

@@ -32,3 +32,20 @@ print("FNet backward N=%d multi=%s target=%s: %.1f us per pass; instrumented lau
 for e in ents:
     if e["name"].startswith("conv_wgrad"):
         print("   %-32s x%d %.0f us  %.1f MFLOP  %.2f MB" % (e["name"], e["calls"], e["total_us"], e["flops"] / 1e6, e["bytes"] / 1e6))
+tot = sum(e["total_us"] for e in ents)
+print("   all instrumented launches of one backward pass (%.0f us of kernel time in %d launches):" % (tot, sum(e["calls"] for e in ents)))
+for e in ents:
+    print("   %-40s x%-3d %7.1f us  (%5.1f us each)  %8.1f MFLOP" % (e["name"], e["calls"], e["total_us"], e["total_us"] / e["calls"], e["flops"] / 1e6))
+# forward pass, the same way
+for _ in range(3):
+    fn.forward(x)
+torch.cuda.synchronize()
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2):
+    fn.forward(x)
+t2 = timeit(g2.replay, 50, 5)
+K.prof_collect(); K.prof_enable(True); fn.forward(x); torch.cuda.synchronize(); K.prof_enable(False)
+ents = K.prof_collect()
+print("FNet forward N=%d: %.1f us per pass" % (N, t2))
+for e in ents:
+    print("   %-40s x%-3d %7.1f us  (%5.1f us each)  %8.1f MFLOP" % (e["name"], e["calls"], e["total_us"], e["total_us"] / e["calls"], e["flops"] / 1e6))
