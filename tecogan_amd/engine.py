@@ -160,8 +160,6 @@ class TrainEngine:
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Measured in
         # round 4 (same box, profiles/r04a_ab.txt): 10.97 -> 10.66 ms per TecoGAN step; TG_VGGT_DEDUP=0 is the A/B switch.
         self.vggt_dedup = os.environ.get("TG_VGGT_DEDUP", "1") == "1" and bool(F.pingpang) and self.T0 > 1
-        self.bwd_cut = int(os.environ.get("TG_BWD_CUT", "0"))                      # frame index k, 0 = off (see _program_compute)
-        self.bwd_cut_parts = int(os.environ.get("TG_BWD_CUT_PARTS", "3"))
         # Target LOOKAHEAD (round 4).  The target features depend on the data only, and before the BPTT the side stream is the
         # step's critical path (target pass 1.4 ms + D real pass + 4 ms of VGG passes over the generated frames,
         # profiles/r04c_ab.txt) while it idles ~2 ms during the BPTT.  A caller that knows the NEXT batch's targets
@@ -380,12 +378,12 @@ class TrainEngine:
             self.D.set_scratch(None)
         if self._skip_update:
             return
-        after = ["down", "wgrad", "early"]
+        after = ["down", "wgrad"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["down", "wgrad", "early", "ar_d", "ar_g", "ar_f"]
+            after = ["down", "wgrad", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
 
@@ -586,45 +584,28 @@ class TrainEngine:
                 K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
                                         gd["off"], gd["merge"])
                 hold.append(dx)
-        # TG_BWD_CUT=k (round 4, off by default): the BPTT in two segments, frames T-1..k+1 and k..0; what is final after the first
-        # one runs on the SIDE stream beside the second (the side stream idles there once the target lookahead is through):
-        #   TG_BWD_CUT_PARTS bit 1: FNet's backward pass of the pairs [k, T-1) (their flow gradients are complete),
-        #                    bit 2: the generator's weight gradients of the frames [k+1, T).
-        # The rest follows the BPTT as before.  Weight gradients accumulate (fp32 atomics), so the slices add up.
-        fk = self.bwd_cut if (split and (tail_split or gw_side) and 0 < self.bwd_cut < T - 1) else 0
-        f_early, w_early = bool(fk and self.bwd_cut_parts & 1), bool(fk and self.bwd_cut_parts & 2)
-
-        def fnet_slice(a, b):
-            sl = slice(a * B, b * B)
-            saved, net_last, o1, fl = fsaved
-            return ([(x[sl], c1[sl], c2[sl]) for x, c1, c2 in saved], net_last[sl], o1[sl], fl[sl]), d_flow[sl]
-
         with seg("bwd_b", "M", vgg_segs):
             if self.use_vgg:
                 K.lincomb(d_vgg, None, d_gen, 1.0, 0.0, accumulate=True)           # the chunks' perceptual-loss gradients
-            backward_frames(T, fk + 1 if fk else 0)
+            backward_frames(T, 0)
             if not tail_split and not gw_side:
                 self.G.wgrad_sequence(0, T)
                 self.Fn.backward(fsaved, d_flow)
-        bwd_last = "bwd_b"
-        if fk:
-            with seg("early", "S", ["bwd_b"]):
-                if w_early:
-                    self.G.wgrad_sequence(fk + 1, T, flags=K.CONV_COEXIST)
-                if f_early:
-                    self.Fn.backward(*fnet_slice(fk, T - 1), flags=K.CONV_COEXIST)
-            with seg("bwd_c", "M", []):
-                backward_frames(fk + 1, 0)
-            bwd_last = "bwd_c"
         if tail_split or gw_side:
-            with seg("wgrad", "S" if gw_side else "M", [bwd_last]):      # (bit 32: beside FNet's backward pass)
-                self.G.wgrad_sequence(0, fk + 1 if w_early else T)
+            with seg("wgrad", "S" if gw_side else "M", ["bwd_b"]):       # (bit 32: beside FNet's backward pass)
+                self.G.wgrad_sequence(0, T)
             self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
             # (FNet's 14 weight gradients behind the generator's on the side stream, its input-gradient chain alone on the
-            #  main stream: measured no gain -- 12.69 vs 12.73 ms, profiles/r03j_ab.txt -- the pieces serialise on each other)
+            #  main stream: measured no gain -- 12.69 vs 12.73 ms, profiles/r03j_ab.txt -- the pieces serialise on each other.
+            #  Round 4, commits f848561 / 8541e73 in the history: the BPTT cut at frame k, with FNet's backward pass of the pairs
+            #  above k and / or the generator's weight gradients of the frames above k on the idle side stream beside the BPTT of
+            #  the frames below -- FNet slice neutral (8.50 vs 8.50 ms: the pass is a latency-bound chain of 22 launches whose
+            #  length does not depend on the batch, 354 us alone, 0.8-1.0 ms beside the weight gradients), early weight
+            #  gradients a loss (9.20 -> 9.28-9.31 ms, FRVSR 2.50 -> 2.54-2.56: what they take from the BPTT beside them is
+            #  more than what they leave to FNet's pass; profiles/r04s_ab.txt, r04u_ab.txt).  Deleted.)
             with seg("fnet_bwd"):
-                self.Fn.backward(*(fnet_slice(0, fk) if f_early else (fsaved, d_flow)))
-            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd", "early"])
+                self.Fn.backward(fsaved, d_flow)
+            self._exchange_seg("ar_f", ["fnet"], ["fnet_bwd"])
 
     @staticmethod
     def _vgg_cuts(T):
