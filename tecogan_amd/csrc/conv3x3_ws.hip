@@ -90,6 +90,8 @@ extern "C" int tg_debug_ws_trace(unsigned long long* out) {
 // 19 B/clk/CU on the miss path), consumed in issue order by the peeled first tile.  The prologue shrinks enough (9.4k cycles of a
 // 32k-cycle launch at the 1080p inference convs, profiles/r04p_trace_ws.txt) for TWO workgroups per CU to pay off at 4 tiles per CU:
 // one workgroup's DMA issue and epilogue (1000 + 1500 of 5600 cycles per tile) run under the other's MFMA block.
+// (Then issuing the next tile's 7 DMA instructions one by one between the MFMA groups, as conv3x3_dma.hip does, is neutral:
+// 14.0 / 16.5 against 13.9 / 16.7 us, profiles/r04v_ab.txt -- the second workgroup already covers the issue gap.  Not kept.)
 template <bool HAS_RES, bool HAS_AUX, bool WLDS, bool WFRAG = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_ws_kernel(ConvWsP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x WS_BUF [+ WS_WPANEL]
