@@ -613,14 +613,15 @@ class TrainEngine:
         env = os.environ.get("TG_VGG_CUTS")
         if env is not None:
             return sorted({int(c) for c in env.split(",") if c.strip() and 0 < int(c) < T})
-        # ONE cut, a little before the middle (19 frames: 8 + 11).  Round 4 re-measured the alternatives with the shorter chain and
+        # ONE cut, a little before the middle (19 frames: 7 + 12).  Round 4 re-measured the alternatives with the shorter chain and
         # the target lookahead.  Several chunks (profiles/r04f_ab.txt, one box): 11 -> 9.19 ms; 6,12 -> 9.28; 7,14 -> 9.45;
         # 8,14 -> 9.53; 5,10,15 -> 10.03; 4,8,12,16 -> 10.48: a VGG pass has ~0.5 ms of fixed cost (60 launches, half of them
         # latency-bound; 1.26 / 1.41 / 1.84 / 2.64 ms alone for 20 / 32 / 44 / 76 images, profiles/r04g_ab.txt) and its small
         # layers need >= 32 images to fill the chip.  Where the one cut goes (r04g_ab.txt, another box): 6 -> 9.77 ms, 7 -> 9.73,
         # 8 -> 9.68, 9 -> 9.92, 11 -> 9.87 / 9.89, 13 -> 10.02: the side stream's VGG passes are the critical path up to the
-        # BPTT, so the first chunk should exist early -- and hold a multiple of 32 images (8 frames x 4).
-        return [min(max((2 * T + 2) // 5, 1), T - 1)] if T > 1 else []
+        # BPTT, so the first chunk should exist early.  Re-measured on the round's final kernels (the forward chain another
+        # 0.3 ms shorter; profiles/r04w_ab.txt, one box): 6 -> 8.50 ms, 7 -> 8.45 / 8.44, 8 -> 8.48 / 8.59 / 8.49 / 8.51, 9 -> 8.77.
+        return [min(max(int(0.37 * T + 0.5), 1), T - 1)] if T > 1 else []
 
     def _alloc_taps(self, Tu):
         """Persistent target-feature buffers: `_taps_t` [T*B,...] (what the VGG passes over the generated frames compare with)

@@ -296,7 +296,7 @@ TECO_SEGS = [("head", "M", []), ("vggt", "S", ["head"]), ("vggt_pre", "S", ["hea
 def test_vgg_chunk_cuts_default_and_override(monkeypatch):
     from tecogan_amd.engine import TrainEngine
     monkeypatch.delenv("TG_VGG_CUTS", raising=False)
-    assert TrainEngine._vgg_cuts(19) == [8] and TrainEngine._vgg_cuts(10) == [4] and TrainEngine._vgg_cuts(3) == [1]
+    assert TrainEngine._vgg_cuts(19) == [7] and TrainEngine._vgg_cuts(10) == [4] and TrainEngine._vgg_cuts(3) == [1]
     assert TrainEngine._vgg_cuts(1) == []
     monkeypatch.setenv("TG_VGG_CUTS", "5,10,15")
     assert TrainEngine._vgg_cuts(19) == [5, 10, 15] and TrainEngine._vgg_cuts(5) == []
