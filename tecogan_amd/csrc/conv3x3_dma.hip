@@ -102,7 +102,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;                  // 4 x 2 waves: 4 pixel rows x 32 channels each
   const int frow = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.y * 64;
+  // Packed tiles (8x8 / 4x4 images: VGG conv5, FNet's inner levels) are WEIGHT-heavy -- 4.7 MB of weights against 2 MB of
+  // activations at conv5 -- and with blockIdx.y = channel block every XCD (linear workgroup id % 8) met all channel blocks and
+  // pulled the whole panel into its own L2: 38.7 MB of HBM traffic for 8.7 MB of algorithmic bytes (profiles/r04_pmc_train.json).
+  // Here the CHANNEL BLOCK is the fast index of the linear id, so an XCD owns Cout / 64 / 8 of the panel and re-reads the
+  // (small) activations instead.  PK = 1 keeps blockIdx.y: its channel blocks of one pixel tile share an XCD's copy of the halo.
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y, nblk = gridDim.y;
+#ifdef DM_NO_XCD_REMAP
+  constexpr bool REMAP = false;
+#else
+  constexpr bool REMAP = PK != 1;
+#endif
+  const int bx = REMAP ? lin / nblk : (int)blockIdx.x, by = REMAP ? lin % nblk : (int)blockIdx.y;
+  const int n0 = by * 64;
   const int cbase = n0 + wn * 32;
   const int row_bytes = p.Cin * 2;
   const int nchunk = p.Cin >> 5;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   }
   // The 36 instructions of the weight panel are issued in an order ROTATED per workgroup: every workgroup of a channel
   // block streams the same 36 KB per stage (measured neutral against the fixed order, profiles/r02s_microbench.txt; kept).
-  const int rot = (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)DM_W_INST);
+  const int rot = (int)(((unsigned)bx * 7u + (unsigned)by * 3u) % (unsigned)DM_W_INST);
   int winst[DM_W_ROUNDS];
 #pragma unroll
   for (int k = 0; k < DM_W_ROUNDS; ++k) {
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     }
   };
 
-  int unit = blockIdx.x;
+  int unit = bx;
   if (unit >= nunits) return;
   DM_STAMP(0);
   dma_setup(unit, 0, 0);
