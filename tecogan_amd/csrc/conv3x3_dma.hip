@@ -60,10 +60,15 @@ template <int PK> struct DmGeo {
   static constexpr int HALO_BYTES = HALO_INST * 1024;               // 21504 / 25600 / 36864
   static_assert(HALO_BYTES % 512 == 0, "regions must start on a multiple of 8 rows (swizzle period)");
 };
-constexpr int DM_W_INST = 9 * 64 * 4 / 64;                                // 36
-constexpr int DM_W_ROUNDS = (DM_W_INST + 7) / 8;                          // 5 (the last: waves 0..3)
+// J = 16-channel groups per wave: the workgroup's channel block is CB = 32 J output channels.  J = 2 everywhere but on packed
+// launches that would leave most of the chip idle (J = 1: twice the workgroups, half the weight panel and MFMAs per stage).
+template <int J> struct DmW {
+  static constexpr int CB = 32 * J;
+  static constexpr int INST = 9 * CB * 4 / 64;                           // 36 / 18 wave-wide DMA instructions per stage
+  static constexpr int ROUNDS = (INST + 7) / 8;                          // 5 (the last: waves 0..3) / 3 (the last: waves 0..1)
+};
 constexpr unsigned DM_OOB = 0x80000000u;
-template <int PK> constexpr int dm_buf_bytes() { return DmGeo<PK>::HALO_BYTES + DM_W_INST * 1024; }   // 58368 / 62464 / 73728
+template <int PK, int J = 2> constexpr int dm_buf_bytes() { return DmGeo<PK>::HALO_BYTES + DmW<J>::INST * 1024; }   // 58368 / 62464 / 73728
 }  // namespace
 
 // Cycle stamps (tools/trace_dma.py builds a private -DTG_DMA_TRACE copy of the library; the product build has none of it).
@@ -89,18 +94,19 @@ extern "C" int tg_debug_dma_trace(unsigned long long* out) {
 // alone to tile quantisation (1044 vs 1143 TFLOP/s at [76,32,32,256], profiles/r02t_microbench.txt), and in round 3 also as
 // "whole rounds of pairs + a second launch of single tiles for the remainder" (78.8 -> 81.8 us, profiles/r03q_microbench.txt):
 // a pair stage costs ~1.65 x a single one, not the 1.35 x its byte count suggests -- the stage is not purely stream-bound.)
-template <bool HAS_RES, bool HAS_AUX, int PK>
+template <bool HAS_RES, bool HAS_AUX, int PK, int J = 2>
 __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   using G = DmGeo<PK>;
+  constexpr int CB = DmW<J>::CB, DM_W_INST = DmW<J>::INST, DM_W_ROUNDS = DmW<J>::ROUNDS;
   constexpr int NT = 1;
   constexpr int DM_HW = G::HW, DM_HALO = G::HALO, DM_HALO_INST = G::HALO_INST, DM_HALO_ROUNDS = G::HALO_ROUNDS;
   constexpr int DM_HALO_BYTES = G::HALO_BYTES;
-  constexpr int BUF = dm_buf_bytes<PK>(), WOFF = DM_HALO_BYTES;
+  constexpr int BUF = dm_buf_bytes<PK, J>(), WOFF = DM_HALO_BYTES;
   constexpr int ROUNDS = DM_HALO_ROUNDS + DM_W_ROUNDS;                      // 8 / 9 / 10 DMA rounds per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x BUF
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;                  // 4 x 2 waves: 4 pixel rows x 32 channels each
+  const int wm = wave >> 1, wn = wave & 1;                  // 4 x 2 waves: 4 pixel rows x 16 J channels each
   const int frow = lane & 15, fg = lane >> 4;
   // Packed tiles (8x8 / 4x4 images: VGG conv5, FNet's inner levels) are WEIGHT-heavy -- 4.7 MB of weights against 2 MB of
   // activations at conv5 -- and with blockIdx.y = channel block every XCD (linear workgroup id % 8) met all channel blocks and
@@ -114,8 +120,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   constexpr bool REMAP = PK != 1;
 #endif
   const int bx = REMAP ? lin / nblk : (int)blockIdx.x, by = REMAP ? lin % nblk : (int)blockIdx.y;
-  const int n0 = by * 64;
-  const int cbase = n0 + wn * 32;
+  const int n0 = by * CB;
+  const int cbase = n0 + wn * 16 * J;
   const int row_bytes = p.Cin * 2;
   const int nchunk = p.Cin >> 5;
   const int nunits = (p.ntiles + NT - 1) / NT;              // a work unit = NT consecutive tiles
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     winst[k] = (i0 + rot) % DM_W_INST;                      // the instruction (1 KB of the panel) this slot fetches
     const int S = winst[k] * 64 + lane;
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
-    const int tap = q >> 6, co = n0 + (q & 63);
+    const int tap = q / CB, co = n0 + (q % CB);
     const int wt = p.flip ? 8 - tap : tap;
     wrel[k] = (i0 < DM_W_INST && co < p.Cout) ? ((wt * p.Cout + co) * p.Cin) * 2 + ch * 16 : -1;
   }
@@ -220,9 +226,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   for (int r = 0; r < ROUNDS; ++r) dma_round(r);
   DM_STAMP(1);
 
-  float bv[2][4];
+  float bv[J][4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < J; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = cbase + j * 16 + fg * 4 + r;
@@ -239,9 +245,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
 #pragma unroll
   for (int d = 0; d < 8; ++d) abase[d] = Q0 * 64 + ((fg ^ ((((Q0 & 7) + d) >> 2 & 1) << 1)) << 4);
   // weight fragment (tap, j): row tap*64 + 32 wn + 16 j + frow -- the swizzle bit is (frow >> 2) & 1
-  const int bbase = WOFF + (wn * 32 + frow) * 64 + ((fg ^ (((frow >> 2) & 1) << 1)) << 4);
+  const int bbase = WOFF + (wn * 16 * J + frow) * 64 + ((fg ^ (((frow >> 2) & 1) << 1)) << 4);
 
-  f32x4 acc[NT][4][2];
+  f32x4 acc[NT][4][J];
   int chunk = 0, buf = 0;
   [[maybe_unused]] int it = 0;
   bool prev_epi = false;
@@ -254,7 +260,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
     // This wave's DMA slots of the stage have landed.  The VMEM queue holds (oldest first) the stage's DMA and, after an
     // epilogue, that unit's 8 NT stores: vmcnt retires in order, so a counted wait covers the DMA without draining the stores.
     if (prev_epi) {
-      if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if constexpr (NT == 1 && J == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < J; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const unsigned char* sb = smem + buf * BUF;
 #pragma unroll
@@ -290,16 +297,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
         }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        u32x4d bfr[2];
+        u32x4d bfr[J];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bfr[j] = *reinterpret_cast<const u32x4d*>(sb + bbase + ((kh * 3 + kw) * 64 + j * 16) * 64);
+        for (int j = 0; j < J; ++j)
+          bfr[j] = *reinterpret_cast<const u32x4d*>(sb + bbase + ((kh * 3 + kw) * CB + j * 16) * 64);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < J; ++j)
               acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
                                                                      __builtin_bit_cast(bf16x8, af[t][i + kh]), acc[t][i][j], 0, 0, 0);
           const int grp = (kw * 3 + kh) * NT + t;           // compile time: group of 8 MFMAs just issued
@@ -334,34 +341,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
           x = frow % G::S;
           ybase = (wm * 4) % G::S;
         }
-        unsigned offs[4][2];
+        unsigned offs[4][J];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int y = ybase + i;
           const bool pok = tile < p.ntiles && y < p.H && x < p.W && n < p.N;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < J; ++j) {
             const int co = cbase + j * 16 + fg * 4;
             offs[i][j] = (pok && co < p.Cout) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : DM_OOB;
           }
         }
-        u32x2d rr[HAS_RES ? 4 : 1][2], aa[HAS_AUX ? 4 : 1][2];
+        u32x2d rr[HAS_RES ? 4 : 1][J], aa[HAS_AUX ? 4 : 1][J];
         if constexpr (HAS_RES) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
+            for (int j = 0; j < J; ++j) rr[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][j], 0, 0);
         }
         if constexpr (HAS_AUX) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
+            for (int j = 0; j < J; ++j) aa[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][j], 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < J; ++j) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -397,15 +404,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(ConvDmaP p) {
   }
 }
 
-template <bool HAS_RES, bool HAS_AUX, int PK>
+template <bool HAS_RES, bool HAS_AUX, int PK, int J>
 static void launch_dma(const ConvDmaP& p, hipStream_t st) {
-  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX, PK>;
-  constexpr int LDS = 2 * dm_buf_bytes<PK>();
+  auto kern = conv3x3_dma_kernel<HAS_RES, HAS_AUX, PK, J>;
+  constexpr int LDS = 2 * dm_buf_bytes<PK, J>();
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
-  const int nt = p.Cout / 64;
+  const int nt = p.Cout / DmW<J>::CB;
   const int nunits = p.ntiles;
   // persistent over work units: one workgroup per CU; grid.x a multiple of 8 so that the channel blocks of one pixel tile
   // (workgroup ids x, x + grid.x, ...) land on the SAME XCD and share its L2 copy of the halo
@@ -425,12 +432,12 @@ static void launch_dma(const ConvDmaP& p, hipStream_t st) {
             LDS, st, p);
 }
 
-template <int PK>
+template <int PK, int J>
 static void launch_dma_pk(const ConvDmaP& p, bool res, bool aux, hipStream_t st) {
-  if (res && aux) launch_dma<true, true, PK>(p, st);
-  else if (res) launch_dma<true, false, PK>(p, st);
-  else if (aux) launch_dma<false, true, PK>(p, st);
-  else launch_dma<false, false, PK>(p, st);
+  if (res && aux) launch_dma<true, true, PK, J>(p, st);
+  else if (res) launch_dma<true, false, PK, J>(p, st);
+  else if (aux) launch_dma<false, true, PK, J>(p, st);
+  else launch_dma<false, false, PK, J>(p, st);
 }
 
 // Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
@@ -466,8 +473,14 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   if (ntiles * (p.Cout / 64) < (pk == 1 ? min_wg : min_wg_pack) || ntiles >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-  if (pk == 2) launch_dma_pk<2>(p, res != nullptr, aux != nullptr, st);
-  else if (pk == 4) launch_dma_pk<4>(p, res != nullptr, aux != nullptr, st);
-  else launch_dma_pk<1>(p, res != nullptr, aux != nullptr, st);
+  // packed launches that would fill less than the chip even with 32-channel blocks: twice the workgroups, each with half the
+  // weight panel and half the MFMAs per stage (VGG conv5 at 32 images: 64 -> 128 workgroups; TG_C3DMA_J1=0 switches it off)
+  static const bool j1_on = getenv("TG_C3DMA_J1") == nullptr || atoi(getenv("TG_C3DMA_J1")) != 0;
+  const bool j1 = j1_on && pk > 1 && ntiles * (p.Cout / 32) <= 256;
+  if (pk == 2 && j1) launch_dma_pk<2, 1>(p, res != nullptr, aux != nullptr, st);
+  else if (pk == 2) launch_dma_pk<2, 2>(p, res != nullptr, aux != nullptr, st);
+  else if (pk == 4 && j1) launch_dma_pk<4, 1>(p, res != nullptr, aux != nullptr, st);
+  else if (pk == 4) launch_dma_pk<4, 2>(p, res != nullptr, aux != nullptr, st);
+  else launch_dma_pk<1, 2>(p, res != nullptr, aux != nullptr, st);
   return 1;
 }

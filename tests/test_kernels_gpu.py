@@ -1002,6 +1002,10 @@ DMA_CASES = [
     (37, 8, 8, 128, 128, True, True, True, ACT_NONE),         # image count not a multiple of 4; input-gradient form, res + mask
     (70, 4, 4, 256, 256, False, True, False, ACT_LRELU),      # FNet's innermost level; count not a multiple of 16
     (65, 4, 4, 256, 256, True, False, True, ACT_NONE),
+    # round 4: packed launches below 256 workgroups of 32 channels take 32-channel blocks (J = 1); these are the training step's
+    (32, 8, 8, 512, 512, False, False, False, ACT_RELU),      # VGG conv5_x of the 8-frame chunk: 8 tiles x 16 blocks
+    (44, 8, 8, 512, 512, True, False, True, ACT_NONE),        # ... input gradient with ReLU mask, 11 tiles
+    (530, 4, 4, 256, 256, False, True, False, ACT_LRELU),     # 4 x 4 images in 64-channel blocks (34 tiles x 8 > 256)
 ]
 
 

@@ -25,7 +25,7 @@ def tg_name(k):
         return "deconv_bwd_lat<aux>" if m.group(1) == "true" else "deconv_bwd_lat<>"
     if "hr_bwd_lat_kernel" in k:
         return "hr_bwd_lat"
-    m = re.search(r"conv3x3_dma_kernel<(true|false), (true|false)(?:, (\d+))?>", k)
+    m = re.search(r"conv3x3_dma_kernel<(true|false), (true|false)(?:, (\d+))?(?:, \d+)?>", k)
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
         return "conv3x3_dma%s<%s>" % ({"2": "_pack2", "4": "_pack4"}.get(m.group(3), ""), ",".join(tags))
