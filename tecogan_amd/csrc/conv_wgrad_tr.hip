@@ -65,11 +65,25 @@ template <int YC> struct TrGeo {
 };
 }  // namespace
 
-// 8 consecutive K-values (pixels) of one channel for this lane: two transpose reads, 4 pixels (4 * pitch bytes) apart
-template <int PITCH>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+// LDS swizzle of the 128-byte pixels (round 4).  ds_read_b64_tr_b16 is served in two groups of 32 lanes, one LDS cycle each when
+// the 32 eight-byte accesses fall into distinct banks (64 banks x 4 B, MI355X_MICROARCH.md LDS table).  A group reads 32 bytes of
+// each of the pixels P .. P+3 and P+8 .. P+11; at a 128-byte pitch the even pixels all start at bank 0 and the odd ones at bank
+// 32: a 4-WAY conflict, 8 LDS cycles per instruction instead of 2 -- 4 waves x 40 reads x 8 = 1280 cycles per 32-pixel chunk
+// against 608 cycles of MFMA per SIMD.  Here the four 32-byte channel pairs of pixel q sit at pair position
+// cp ^ tr_swz(q), tr_swz(q) = bit 1 of q | bit 3 of q << 1: for every base pixel the eight pixels of a group then cover all 64
+// banks exactly once.  The permutation is applied on the GLOBAL side of the LDS-DMA (a lane picks which chunk it fetches);
+// the readers hold 16 lane bases per accumulator row (the swizzle bits of P = K + lane pixel depend on K mod 16 only).
+#ifdef TR_NO_SWZ                              // A/B build (tools/build_variant.py conv_wgrad_tr.hip -DTR_NO_SWZ): the round-3 layout
+__device__ __forceinline__ int tr_swz(int) { return 0; }
+#else
+__device__ __forceinline__ int tr_swz(int q) { return ((q >> 1) & 1) | ((q >> 2) & 2); }
+#endif
+
+// 8 consecutive K-values (pixels) of one channel for this lane: two transpose reads, 4 pixels apart (each at its own swizzled
+// address: pixel + 4 may differ from the pixel in swizzle bit 3)
+__device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* p, const unsigned char* p4) {
   const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
+  const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p4));
   typedef short s16x8t __attribute__((ext_vector_type(8)));
   const s16x8t v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return __builtin_bit_cast(bf16x8, v);
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
     const int S = (wave + 4 * k) * 64 + lane;
     const int q = S >> 3, c = S & 7;
     const int dy = q / (TR_W + 2), dx = q - (TR_W + 2) * dy;
-    xrel[k] = ((dy - 1) * p.W + dx - 1) * TR_PIX + c * 16;
+    xrel[k] = ((dy - 1) * p.W + dx - 1) * TR_PIX + ((((c >> 1) ^ tr_swz(q)) << 1) | (c & 1)) * 16;
     xcode[k] = dy | (dx << 8) | (S < TR_XSLOTS ? (1 << 16) : 0);
   }
   //      dY: slot S -> tile row S / YROW_SLOTS, 16-byte unit S % YROW_SLOTS of that row's 32 pixels
@@ -109,7 +123,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   for (int k = 0; k < G::YROUNDS; ++k) {
     const int S = (wave + 4 * k) * 64 + lane;
     const int r = S / G::YROW_SLOTS, o = S - r * G::YROW_SLOTS;
-    yrel[k] = (wave + 4 * k) < G::YINST ? r * p.W * YPIX + o * 16 : -1;
+    // YC = 64: unit o = pixel o / 8, chunk o % 8 of the row, swizzled like X (the tile's pixel index is 32 r + o / 8)
+    const int og = YC == 64 ? (o & ~7) | ((((o & 7) >> 1) ^ tr_swz(o >> 3)) << 1) | (o & 1) : o;
+    yrel[k] = (wave + 4 * k) < G::YINST ? r * p.W * YPIX + og * 16 : -1;
   }
   auto issue_dma = [&](int tile, int buf, int r0, int r1) {          // DMA rounds [r0, r1) of the stage (compile-time bounds)
     const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
@@ -146,8 +162,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   //      c0 + 4 (L % 4); everything else (image row, tap shift, 16-channel tile) is a compile-time offset.  (YC = 8: the
   //      lanes with L % 4 >= 2 point 16 / 24 bytes into the NEXT pixel -- they feed output columns 8..15, which are discarded.)
   const int lp = 8 * fg + (frow >> 2), lc = 4 * (frow & 3);
-  const int abase = lp * TR_PIX + (ci0 + lc) * 2;           // halo (row 0, column lp) = image (y0 - 1, x0 + lp - 1): tap (0, 0) of row 0
-  const int bbase = TR_YOFF + lp * YPIX + (co0 + lc) * 2;
+  // halo (row 0, column lp) = image (y0 - 1, x0 + lp - 1): tap (0, 0) of row 0; the fragment of halo pixel offset K is read at
+  // atab[i][K & 15] + K * TR_PIX (K compile time)
+  int atab[NI][16], bbase[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) atab[i][k] = lp * TR_PIX + (((ci0 >> 4) + i) ^ tr_swz(lp + k)) * 32 + lc * 2;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    bbase[j] = TR_YOFF + lp * YPIX + (YC == 64 ? (((co0 >> 4) + j) ^ tr_swz(lp)) * 32 + lc * 2 : (co0 + lc) * 2);
 
   f32x4 acc[9][NI][NJ];
   f32x4 accb[NJ];
@@ -176,7 +200,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
     for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
       bf16x8 bq[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bq[j] = tr_frag<YPIX>(sb + bbase + yy * TR_W * YPIX + j * 32);
+      for (int j = 0; j < NJ; ++j) {      // (dY: the lane's pixel has bit 2 clear, so pixel + 4 keeps its swizzle bits)
+        const unsigned char* q = sb + bbase[j] + yy * TR_W * YPIX;
+        bq[j] = tr_frag2(q, q + 4 * YPIX);
+      }
       if (do_bias) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
@@ -187,8 +214,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
         for (int kw = 0; kw < 3; ++kw) {
           bf16x8 aq[NI];
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
-            aq[i] = tr_frag<TR_PIX>(sb + abase + ((yy + kh) * (TR_W + 2) + kw) * TR_PIX + i * 32);   // image (y0+yy+kh-1, x0+lp+kw-1)
+          for (int i = 0; i < NI; ++i) {
+            const int K = (yy + kh) * (TR_W + 2) + kw;                                            // image (y0+yy+kh-1, x0+lp+kw-1)
+            aq[i] = tr_frag2(sb + atab[i][K & 15] + K * TR_PIX, sb + atab[i][(K + 4) & 15] + (K + 4) * TR_PIX);
+          }
 #pragma unroll
           for (int i = 0; i < NI; ++i)
 #pragma unroll
