@@ -27,6 +27,7 @@
 // tests/test_kernels_gpu.py) and default-on: the grouped trunk launch (32 layers x 76 images) 422.7 -> 353.1 us, 434 -> 520
 // TFLOP/s (profiles/r03b_mb_wgrad.txt).  TG_WGRAD_TR=0 is the A/B switch.
 #include "common.h"
+#include <type_traits>
 #include <mutex>
 #include <stdlib.h>
 
@@ -53,15 +54,16 @@ constexpr int TR_W = 32, TR_TH = 8, TR_PIX = 128;                      // tile w
 constexpr int TR_XSLOTS = (TR_TH + 2) * (TR_W + 2) * 8;               // 2720 16-byte slots of the X halo tile
 constexpr int TR_XINST = (TR_XSLOTS + 63) / 64;                       // 43 wave-wide DMA instructions
 constexpr int TR_YOFF = TR_XINST * 1024;                              // 44032
-constexpr int TR_XROUNDS = (TR_XINST + 3) / 4;                        // 11 DMA rounds of 4 waves
+constexpr int TR_NW = 8;                                              // waves per workgroup (two per SIMD)
+constexpr int TR_XROUNDS = (TR_XINST + TR_NW - 1) / TR_NW;            // 6 DMA rounds of 8 waves
 constexpr unsigned TR_OOB = 0x80000000u;
 template <int YC> struct TrGeo {
   static constexpr int YPIX = YC * 2;                                 // bytes per dY pixel
   static constexpr int YROW_SLOTS = TR_W * YPIX / 16;                 // 16-byte slots per tile row: 256 / 32
   static constexpr int YINST = TR_TH * YROW_SLOTS / 64;               // 32 / 4
-  static constexpr int YROUNDS = (YINST + 3) / 4;                     // 8 / 1
+  static constexpr int YROUNDS = (YINST + TR_NW - 1) / TR_NW;         // 4 / 1
   static constexpr int STAGE = (TR_XINST + YINST) * 1024;             // 76800 / 48128
-  static constexpr int ROUNDS = TR_XROUNDS + YROUNDS;                 // 19 / 12
+  static constexpr int ROUNDS = TR_XROUNDS + YROUNDS;                 // 10 / 7
 };
 }  // namespace
 
@@ -89,17 +91,23 @@ __device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* p, const unsigne
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Round 4: EIGHT waves.  With one wave per SIMD a wave's fragment reads (40 ds_read_b64_tr_b16 per 32-pixel chunk), its 38 MFMAs
+// and its share of the next stage's DMA issue ran one after the other (2700 cycles per chunk for 608 cycles of MFMA).  Waves w and
+// w + 4 share a SIMD and a 32 x 32 quadrant and split the nine taps 5 + 4: each reads the dY fragments and its own taps' X
+// fragments (24 / 20 reads for 20 / 16 MFMAs), so one wave's reads and DMA issue hide under the other's MFMAs; the accumulators
+// (80 / 64 registers) stay private and every weight-gradient element is still added by exactly one wave.
 template <int YC>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
+__global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   using G = TrGeo<YC>;
   constexpr int YPIX = G::YPIX;
   constexpr int NI = YC == 64 ? 2 : 1, NJ = YC == 64 ? 2 : 1;           // 16 x 16 accumulator tiles per wave (ci x co)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x STAGE (+ slack)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // YC = 64: waves = (ci half, co half) of the 64 x 64 block; YC = 8: waves = the four 16-channel ci tiles, one co tile
-  const int ci0 = YC == 64 ? 32 * (wave >> 1) : 16 * wave;
-  const int co0 = YC == 64 ? 32 * (wave & 1) : 0;
+  const int quad = wave & 3, tset = wave >> 2;              // tset 0: taps 0..4, 1: taps 5..8
+  // YC = 64: quadrants = (ci half, co half) of the 64 x 64 block; YC = 8: the four 16-channel ci tiles, one co tile
+  const int ci0 = YC == 64 ? 32 * (quad >> 1) : 16 * quad;
+  const int co0 = YC == 64 ? 32 * (quad & 1) : 0;
   const int frow = lane & 15, fg = lane >> 4;
   const int grp = blockIdx.x / p.nsplit, split = blockIdx.x - grp * p.nsplit;
   const u16* __restrict__ gx = p.xs[grp];
@@ -107,11 +115,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.xbytes, 0x00020000);
   const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.ybytes, 0x00020000);
 
-  // ---- DMA slot descriptors.  X: slot S = (wave + 4k)*64 + lane -> halo pixel S / 8 = (dy, dx), 16-byte channel chunk S % 8
+  // ---- DMA slot descriptors.  X: slot S = (wave + 8k)*64 + lane -> halo pixel S / 8 = (dy, dx), 16-byte channel chunk S % 8
   int xrel[TR_XROUNDS], xcode[TR_XROUNDS];
 #pragma unroll
   for (int k = 0; k < TR_XROUNDS; ++k) {
-    const int S = (wave + 4 * k) * 64 + lane;
+    const int S = (wave + TR_NW * k) * 64 + lane;
     const int q = S >> 3, c = S & 7;
     const int dy = q / (TR_W + 2), dx = q - (TR_W + 2) * dy;
     xrel[k] = ((dy - 1) * p.W + dx - 1) * TR_PIX + ((((c >> 1) ^ tr_swz(q)) << 1) | (c & 1)) * 16;
@@ -121,11 +129,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   int yrel[G::YROUNDS];
 #pragma unroll
   for (int k = 0; k < G::YROUNDS; ++k) {
-    const int S = (wave + 4 * k) * 64 + lane;
+    const int S = (wave + TR_NW * k) * 64 + lane;
     const int r = S / G::YROW_SLOTS, o = S - r * G::YROW_SLOTS;
     // YC = 64: unit o = pixel o / 8, chunk o % 8 of the row, swizzled like X (the tile's pixel index is 32 r + o / 8)
     const int og = YC == 64 ? (o & ~7) | ((((o & 7) >> 1) ^ tr_swz(o >> 3)) << 1) | (o & 1) : o;
-    yrel[k] = (wave + 4 * k) < G::YINST ? r * p.W * YPIX + og * 16 : -1;
+    yrel[k] = (wave + TR_NW * k) < G::YINST ? r * p.W * YPIX + og * 16 : -1;
   }
   auto issue_dma = [&](int tile, int buf, int r0, int r1) {          // DMA rounds [r0, r1) of the stage (compile-time bounds)
     const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
 #pragma unroll
     for (int r = r0; r < r1; ++r) {
       if (r < TR_XROUNDS) {
-        const int inst = wave + 4 * r;
+        const int inst = wave + TR_NW * r;
         if (r + 1 < TR_XROUNDS || inst < TR_XINST) {
           const int dy = xcode[r] & 255, dx = (xcode[r] >> 8) & 255;
           const bool ok = (xcode[r] >> 16) && (unsigned)(y0 + dy - 1) < (unsigned)p.H && (unsigned)(x0 + dx - 1) < (unsigned)p.W;
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
         }
       } else if (r < G::ROUNDS) {
         const int k = r - TR_XROUNDS;
-        const int inst = wave + 4 * k;
+        const int inst = wave + TR_NW * k;
         if (k + 1 < G::YROUNDS || inst < G::YINST) {
           const unsigned off = yrel[k] >= 0 ? (unsigned)(pix0 * YPIX + yrel[k]) : TR_OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_void_t*)(dst + TR_YOFF + inst * 1024), 16, (int)off, 0, 0, 0);
@@ -173,10 +181,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   for (int j = 0; j < NJ; ++j)
     bbase[j] = TR_YOFF + lp * YPIX + (YC == 64 ? (((co0 >> 4) + j) ^ tr_swz(lp)) * 32 + lc * 2 : (co0 + lc) * 2);
 
-  f32x4 acc[9][NI][NJ];
+  f32x4 acc[5][NI][NJ];                                      // this wave's taps: T0 + t
   f32x4 accb[NJ];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 5; ++t)
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -186,32 +194,34 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   typedef short s16x8o __attribute__((ext_vector_type(8)));
   const s16x8o ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
-  const bool do_bias = p.dbs[grp] != nullptr && ci0 == 0;   // wave-uniform
+  const bool do_bias = p.dbs[grp] != nullptr && ci0 == 0 && tset == 0;   // wave-uniform
 
-  int buf = 0;
-  while (true) {
-    const int ntile = tile + p.nsplit;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slots of the stage
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                           // everybody's; nobody still reads the other buffer
-    const bool has_next = ntile < p.ntiles;
-    const unsigned char* sb = smem + buf * G::STAGE;
+  // the stage loop for the taps [T0, T0 + NTAP) (compile time: the two tap sets are two copies of the loop, chosen per wave)
+  auto run = [&](auto t0c, auto ntc) {
+    constexpr int T0 = decltype(t0c)::value, NTAP = decltype(ntc)::value;
+    int buf = 0;
+    while (true) {
+      const int ntile = tile + p.nsplit;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's slots of the stage
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                           // everybody's; nobody still reads the other buffer
+      const bool has_next = ntile < p.ntiles;
+      const unsigned char* sb = smem + buf * G::STAGE;
 #pragma unroll
-    for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
-      bf16x8 bq[NJ];
+      for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
+        bf16x8 bq[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {      // (dY: the lane's pixel has bit 2 clear, so pixel + 4 keeps its swizzle bits)
-        const unsigned char* q = sb + bbase[j] + yy * TR_W * YPIX;
-        bq[j] = tr_frag2(q, q + 4 * YPIX);
-      }
-      if (do_bias) {
+        for (int j = 0; j < NJ; ++j) {      // (dY: the lane's pixel has bit 2 clear, so pixel + 4 keeps its swizzle bits)
+          const unsigned char* q = sb + bbase[j] + yy * TR_W * YPIX;
+          bq[j] = tr_frag2(q, q + 4 * YPIX);
+        }
+        if (do_bias) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
-      }
+          for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
+        }
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
+        for (int t = 0; t < NTAP; ++t) {
+          const int kh = (T0 + t) / 3, kw = (T0 + t) % 3;
           bf16x8 aq[NI];
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
@@ -222,33 +232,36 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
           for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[kh * 3 + kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[j], acc[kh * 3 + kw][i][j], 0, 0, 0);
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[j], acc[t][i][j], 0, 0, 0);
         }
-      // the next stage's DMA rounds spread over the 8 rows (an LDS-DMA instruction costs 60-180 issue cycles)
-      if (has_next) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (yy < 7) issue_dma(ntile, buf ^ 1, yy * 3, yy * 3 + 3 < G::ROUNDS ? yy * 3 + 3 : G::ROUNDS);
-        __builtin_amdgcn_sched_barrier(0);
+        // the next stage's DMA rounds spread over the rows (an LDS-DMA instruction costs 60-180 issue cycles)
+        if (has_next) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (yy * 2 < G::ROUNDS) issue_dma(ntile, buf ^ 1, yy * 2, yy * 2 + 2 < G::ROUNDS ? yy * 2 + 2 : G::ROUNDS);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      if (!has_next) break;
+      tile = ntile;
+      buf ^= 1;
     }
-    if (!has_next) break;
-    tile = ntile;
-    buf ^= 1;
-  }
 
-  // ---- split-K reduction: D row 4 fg + r = input channel, column frow = output channel
-  float* __restrict__ dw = p.dws[grp];
+    // ---- split-K reduction: D row 4 fg + r = input channel, column frow = output channel
+    float* __restrict__ dw = p.dws[grp];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ci = ci0 + 16 * i + 4 * fg + r, co = co0 + 16 * j + frow;
-          if (YC == 64 || co < p.cout) unsafeAtomicAdd(dw + (t * 64 + ci) * p.cout + co, acc[t][i][j][r]);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int ci = ci0 + 16 * i + 4 * fg + r, co = co0 + 16 * j + frow;
+            if (YC == 64 || co < p.cout) unsafeAtomicAdd(dw + ((T0 + t) * 64 + ci) * p.cout + co, acc[t][i][j][r]);
+          }
+  };
+  if (tset == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
   if (do_bias && fg == 0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -266,7 +279,7 @@ static void wgrad_tr_go(const WgradTrP& p, double flops, double bytes, hipStream
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_kernel<YC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   TG_LAUNCH(YC == 64 ? "conv_wgrad_tr" : "conv_wgrad_tr_out", flops, bytes, conv_wgrad_tr_kernel<YC>,
-            dim3((unsigned)(p.groups * p.nsplit)), dim3(256), LDS, st, p);
+            dim3((unsigned)(p.groups * p.nsplit)), dim3(512), LDS, st, p);
 }
 
 // returns 1 if launched, 0 otherwise.  Geometries: 3x3 s1 SAME, 64 input channels (ldx = 64), images H % 8 == 0, W % 32 == 0;
