@@ -960,7 +960,9 @@ extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t ro
   }
   if (bn_x8_ok(dtype, C, x, y, nullptr, nullptr)) {
     const int OC = C / 8, RP = 256 / OC;
-    const dim3 rg8(grid_1d(rows, RP * 16, 256)), eg8(grid_1d(rows * OC, 256, 2048));
+    // reductions: RP * 4 rows per workgroup (round 4; it was RP * 16 under a cap of 256 workgroups: D's [12,64,64,64] maps ran
+    // as 96 workgroups x 16 dependent trips, 20 us for 19 MB -- latency, not bandwidth)
+    const dim3 rg8(grid_1d(rows, RP * 4, 1024)), eg8(grid_1d(rows * OC, 256, 2048));
     hipLaunchKernelGGL((bn_stats_x8_kernel<0>), TG_DET_GRID(rg8), dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
     hipLaunchKernelGGL((bn_stats_x8_kernel<1>), TG_DET_GRID(rg8), dim3(256), 0, ST(stream), (const u16*)x, rows, C, stats);
     hipLaunchKernelGGL(bn_lrelu_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (u16*)y, rows, C, beta, stats,
@@ -992,7 +994,9 @@ extern "C" int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_
   }
   if (bn_x8_ok(dtype, C, x, y, d_y, d_x)) {
     const int OC = C / 8, RP = 256 / OC;
-    const dim3 rg8(grid_1d(rows, RP * 16, 256)), eg8(grid_1d(rows * OC, 256, 2048));
+    // reductions: RP * 4 rows per workgroup (round 4; it was RP * 16 under a cap of 256 workgroups: D's [12,64,64,64] maps ran
+    // as 96 workgroups x 16 dependent trips, 20 us for 19 MB -- latency, not bandwidth)
+    const dim3 rg8(grid_1d(rows, RP * 4, 1024)), eg8(grid_1d(rows * OC, 256, 2048));
     hipLaunchKernelGGL(bn_bwd_sums_x8_kernel, TG_DET_GRID(rg8), dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y, rows,
                        C, stats, eps, alpha, ws);
     hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (const u16*)y, (const u16*)d_y,
