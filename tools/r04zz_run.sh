@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 GPU session Z (validation): full GPU suite, PMC passes, the default bench line, rocprofv3 kernel stats, segment timeline.
+# Round-4 GPU session ZZ (final validation on the end state): full GPU suite, PMC passes, the default bench line, rocprofv3 kernel stats, segment timeline.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 export TMPDIR=/tmp
-( time timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=25 --durations=6 ) > $O/r04z_pytest_gpu.log 2>&1; grep -E "passed|failed" $O/r04z_pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O/r04z_pytest_gpu.log | cut -c1-200
-( time timeout 700 python bench.py ) > $O/r04z_bench.json 2> $O/r04z_bench.err; cut -c1-300 $O/r04z_bench.json; tail -3 $O/r04z_bench.err
+( time timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=25 --durations=6 ) > $O/r04zz_pytest_gpu.log 2>&1; grep -E "passed|failed" $O/r04zz_pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O/r04zz_pytest_gpu.log | cut -c1-200
+( time timeout 700 python bench.py ) > $O/r04zz_bench.json 2> $O/r04zz_bench.err; cut -c1-300 $O/r04zz_bench.json; tail -3 $O/r04zz_bench.err
 cd /tmp
 B="python $R/bench.py --no-sub --no-roofline --no-cpu-baseline"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_z_teco -o teco -- $B --steps 20 --warmup 3 > $O/prof_z_teco.log 2>&1
@@ -23,5 +23,5 @@ cd $R
 python tools/pmc_summary.py --json $O/r04_pmc_train.json $O/pmc_z_fetch $O/pmc_z_write $O/pmc_z_mfma > $O/r04_pmc_train.txt 2>&1; head -14 $O/r04_pmc_train.txt | cut -c1-200
 python tools/pmc_summary.py --json $O/r04_pmc_infer.json $O/pmc_z_ifetch $O/pmc_z_iwrite $O/pmc_z_imfma > $O/r04_pmc_infer.txt 2>&1; head -8 $O/r04_pmc_infer.txt | cut -c1-200
 rm -rf $O/pmc_z_*/
-timeout 200 python tools/seg_timeline.py --steps 30 2>&1 | grep -v "^ROCm\|^HIP\|^Host\|^Librccl\|^RCCL\|amdgpu.ids" | head -24 > $O/r04z_seg_timeline.txt
-cat $O/r04z_seg_timeline.txt
+timeout 200 python tools/seg_timeline.py --steps 30 2>&1 | grep -v "^ROCm\|^HIP\|^Host\|^Librccl\|^RCCL\|amdgpu.ids" | head -24 > $O/r04zz_seg_timeline.txt
+cat $O/r04zz_seg_timeline.txt
