@@ -26,5 +26,5 @@ for h2, w2 in ((540, 960), (288, 360)):
     ta = timeit(lambda: K.hr_tail_forward(t1, w2t, b, w3, b3, x_in, out, None), 50, 5)
     tb = timeit(lambda: K.hr_tail_train(t1, f2, b, w3, b3, x_in, None, out), 50, 5)
     tc = timeit(lambda: K.hr_tail_train(t1, f2, b, w3, b3, x_in, None, None, st), 50, 5)
-    print("HR tail, t1 [1,%d,%d,64]: hr_tail %7.1f us   hr_fwd_lat<tail> without t2 store %7.1f us (state only %7.1f us)  [TG_HR_TAIL_PERSIST_MIN=%s]"
-          % (h2, w2, ta, tb, tc, os.environ.get("TG_HR_TAIL_PERSIST_MIN", "2048")), flush=True)
+    print("HR tail, t1 [1,%d,%d,64]: hr_tail %7.1f us   hr_fwd_lat<tail> without t2 store %7.1f us (state only %7.1f us)"
+          % (h2, w2, ta, tb, tc), flush=True)
