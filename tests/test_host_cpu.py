@@ -494,3 +494,73 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "does not match WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+def test_wgrad_tr_lds_swizzle_is_consistent_and_conflict_free():
+    """csrc/conv_wgrad_tr.hip (round 4): the 128-byte pixels of the X halo tile and of the dY tile are stored with their four
+    32-byte channel pairs permuted by tr_swz(pixel) -- applied on the global side of the LDS-DMA -- and the fragment readers
+    address pair (cp ^ tr_swz(pixel)).  A Python mirror of both sides: every lane of every ds_read_b64_tr_b16 gets the pixel and
+    channels it wants, and the 32 lanes of a read group (MI355X_MICROARCH.md, LDS table) hit 64 distinct banks -- 4-way
+    conflicts without the swizzle."""
+    def swz(q):
+        return ((q >> 1) & 1) | ((q >> 2) & 2)
+
+    TRW, PIX = 32, 128
+    lds = {}                                                   # byte address -> (halo pixel, channel), as the DMA fills it
+    for q in range((8 + 2) * (TRW + 2)):
+        for c in range(8):
+            cg = (((c >> 1) ^ swz(q)) << 1) | (c & 1)           # the 16-byte global chunk this LDS slot receives
+            for b in range(0, 16, 2):
+                lds[q * PIX + c * 16 + b] = (q, cg * 8 + b // 2)
+
+    def group_conflicts(addrs):
+        worst = 0
+        for g in (range(0, 32), range(32, 64)):
+            banks = {}
+            for lane in g:
+                for w in (0, 4):
+                    banks.setdefault(((addrs[lane] + w) // 4) % 64, set()).add(addrs[lane] + w)
+            worst = max(worst, max(len(v) for v in banks.values()))
+        return worst
+
+    worst = 0
+    for quad in range(4):
+        ci0 = 32 * (quad >> 1)
+        for i in range(2):
+            for yy in range(8):
+                for tap in range(9):
+                    K0 = (yy + tap // 3) * (TRW + 2) + tap % 3
+                    for K in (K0, K0 + 4):                      # the two transpose reads of a fragment
+                        addrs = []
+                        for lane in range(64):
+                            frow, fg = lane & 15, lane >> 4
+                            lp, lc = 8 * fg + (frow >> 2), 4 * (frow & 3)
+                            a = lp * PIX + ((((ci0 >> 4) + i) ^ swz(lp + (K & 15))) * 32) + lc * 2 + K * PIX   # atab[i][K & 15] + K * PIX
+                            addrs.append(a)
+                            for e in range(4):
+                                assert lds[a + 2 * e] == (lp + K, ci0 + 16 * i + lc + e)
+                        worst = max(worst, group_conflicts(addrs))
+    assert worst == 1
+    plain = [(8 * (lane >> 4) + ((lane & 15) >> 2)) * PIX + 4 * (lane & 3) * 2 for lane in range(64)]
+    assert group_conflicts(plain) == 4
+    # dY tile (64 output channels): unit o of row r holds global unit og; the lane's pixel keeps its swizzle bits at pixel + 4
+    ldsy = {}
+    for r in range(8):
+        for o in range(256):
+            og = (o & ~7) | ((((o & 7) >> 1) ^ swz(o >> 3)) << 1) | (o & 1)
+            for b in range(0, 16, 2):
+                ldsy[(r * 256 + o) * 16 + b] = (r * 32 + (og >> 3), (og & 7) * 8 + b // 2)
+    for quad in range(4):
+        co0 = 32 * (quad & 1)
+        for j in range(2):
+            for yy in range(8):
+                for half in (0, 4):
+                    addrs = []
+                    for lane in range(64):
+                        frow, fg = lane & 15, lane >> 4
+                        lp, lc = 8 * fg + (frow >> 2), 4 * (frow & 3)
+                        a = lp * 128 + ((((co0 >> 4) + j) ^ swz(lp)) * 32) + lc * 2 + yy * 32 * 128 + half * 128
+                        addrs.append(a)
+                        for e in range(4):
+                            assert ldsy[a + 2 * e] == (yy * 32 + lp + half, co0 + 16 * j + lc + e)
+                    assert group_conflicts(addrs) == 1
