@@ -202,15 +202,6 @@ int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void*
                               float* out /*nullable if state*/, float* state /*nullable*/, int B, int h, int w,
                               void* stream);
 
-/* Fused HR tail of generator_F, bf16, throughput regime (lib/frvsr.py:73-87, main.py:207): second transposed conv + ReLU,
- * output conv 64 -> 3, bicubic_four(LR) skip, value ranges -- the 64-channel HR tensor stays on chip (csrc/hr_tail.hip).
- * t1 [N,h2,w2,64] bf16 (output of the first transposed conv), w_tran [9][64][64] in TF's [kh,kw,Cout,Cin] layout,
- * w_out [9][3][64]; gen_in as in tg_bicubic_add_preprocess; out / state as there (either may be NULL, not both).
- * Validated on hardware in round 3 (tests/test_kernels_gpu.py::test_hr_tail_*) and the default of the stateless generator
- * forward for bf16 tensors (TG_HR_TAIL=0 selects the three-kernel path). */
-int tg_hr_tail_forward(const void* t1, const void* w_tran, const float* b_tran, const void* w_out, const float* b_out,
-                       const void* gen_in, int Cpad, float* out, float* state, int N, int h2, int w2, void* stream);
-
 /* One residual block of generator_F (reference lib/frvsr.py:50-57: conv3x3 - ReLU - conv3x3 + skip) or the input-gradient
  * chain of the same block (tf.gradients, lib/Teco.py:441-449) as ONE launch -- the latency regime of the training recurrence
  * (csrc/resblock_lat.hip; bf16, C = 64; anything else: TG_EINVAL, run the block as two tg_conv_forward launches).  Every

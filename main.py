@@ -53,18 +53,34 @@ def save_checkpoint(eng, output_dir, step, avg=None):
     return path
 
 
+TESTWHILETRAIN_MAX_S = 600          # a try-out (10 frames of the calendar clip) that takes longer than this is hung
+
+
 def testWhileTrain(FLAGS, testno=0, lr_dir="./LR/calendar/"):
     """reference main.py:151-174: whenever a checkpoint has been saved, try it in `--mode inference` in a child process --
     the first 10 frames of the calendar clip, written as `<output_dir>/train/<step>_*.png`.  The reference hard-codes the
     clip folder and the interpreter; here the child runs under the same interpreter and is skipped (with a note) when the
     clip folder does not exist.  The child is its own process group so that Ctrl+C in the trainer does not reach it.
-    Returns the Popen object (None when skipped).  The previous try-out is reaped first (waited for if it is still
-    running: two children would share the GPU with the captured training step and each other), so no zombies pile up
-    over a long run; TG_TEST_WHILE_TRAIN=0 disables the try-outs (benchmark runs: the child competes for the GPU)."""
+    Returns the Popen object (None when skipped).  The previous try-out is reaped WITHOUT blocking (`poll()`): while it is
+    still running this try-out is skipped and logged -- the reference fires and forgets (main.py:151-180); waiting here would
+    stall rank 0 inside the training loop and, with several ranks, every other rank in its next all-reduce.  A
+    child that outlives TESTWHILETRAIN_MAX_S is killed (its process group) so that a hung one cannot block every later
+    try-out.  TG_TEST_WHILE_TRAIN=0 disables the try-outs (benchmark runs: the child competes for the GPU)."""
+    import signal
     import subprocess
     prev = getattr(testWhileTrain, "_child", None)
     if prev is not None:
-        prev.wait()
+        if prev.poll() is None:
+            age = time.time() - getattr(testWhileTrain, "_started", time.time())
+            if age < TESTWHILETRAIN_MAX_S:
+                print('[testWhileTrain] step %d: the previous try-out (pid %d) is still running, this one is skipped' % (testno, prev.pid))
+                return None
+            print('[testWhileTrain] the previous try-out (pid %d) exceeded %d s: killed' % (prev.pid, TESTWHILETRAIN_MAX_S))
+            try:
+                os.killpg(prev.pid, signal.SIGKILL)              # the child is its own process group (setpgrp below)
+            except OSError:
+                pass
+            prev.wait()
         testWhileTrain._child = None
     if os.environ.get("TG_TEST_WHILE_TRAIN", "1") == "0":
         return None
@@ -81,6 +97,7 @@ def testWhileTrain(FLAGS, testno=0, lr_dir="./LR/calendar/"):
         return None
     print(' '.join(cmd1))
     testWhileTrain._child = subprocess.Popen(cmd1, preexec_fn=os.setpgrp)
+    testWhileTrain._started = time.time()
     return testWhileTrain._child
 
 

@@ -48,7 +48,6 @@ SIGNATURES = {
     "tg_upsample2_forward": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tg_upsample2_backward": [_P, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P],
     "tg_bicubic_add_preprocess": [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P],
-    "tg_hr_tail_forward": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "tg_resblock": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tg_pack_weights_frag": [_P, _P, _P, _P, _I, _P],
     "tg_hr_tail_backward": [_P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -19,6 +19,9 @@ void tg_set_error(const char* fmt, ...);
 // three warp / D-input backward passes) as ONE wavefront.  Slow (the fp32 parity step: seconds instead of 60 ms) and only meant
 // for the parity tests: a regression is then distinguishable from summation-order noise (tools/c3_repeat.py).
 bool tg_det();
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached per device; 256 on MI355X): the persistent
+// kernels size their grids from it instead of a literal 256.
+int tg_num_cus();
 #define TG_DET_GRID(g) (tg_det() ? dim3(1) : dim3(g))
 #define TG_DET_WAVE(b) (tg_det() ? dim3(64) : dim3(b))
 

@@ -40,7 +40,7 @@ struct Conv3P {
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope (ReLU 0, LeakyReLU alpha, none 1)
   int tiles_y, tiles_x, ntiles;
   int direct_epi;     // per-lane stores instead of the LDS-staged rows
-  int prio;           // A/B switch (TG_C3_PRIO): s_setprio for the small-tile (latency-bound chain) instantiations
+  int prio;           // s_setprio 3 for the small-tile (latency-bound chain) instantiations
   unsigned in_bytes, w_bytes;   // extents of `in` / `w` for the bounds-checked buffer loads (< 2^31)
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -421,7 +421,7 @@ static void launch3(Conv3P p, hipStream_t st) {
   p.ntiles = ((p.N + PACK - 1) / PACK) * p.tiles_y * p.tiles_x;
   const int nt = (p.Cout + BN - 1) / BN;
   int gx = p.ntiles;
-  const int per = 256 / nt > 0 ? 256 / nt : 1;        // one workgroup per CU (LDS-bound residency)
+  const int per = tg_num_cus() / nt > 0 ? tg_num_cus() / nt : 1;        // one workgroup per CU (LDS-bound residency)
   if (gx > per) gx = per;
   static const char* const pname = [] {
     static char b[96];
@@ -662,8 +662,7 @@ int tg_conv3x3_try(const tg_conv_desc* d, const void* in, const void* weight, co
   p.direct_epi = direct;
   // default ON: with throughput kernels of the side stream on the same CU, the chain's waves at s_setprio 3 hide 75 % instead
   // of 48 % of a co-running VGG layer (tools/mb_forktax.py D: 5.14 vs 6.06 ms) and the TecoGAN step gains 2 %
-  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
-  p.prio = prio;
+  p.prio = 1;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   const bool coexist = (d->flags & TG_CONV_COEXIST) != 0;

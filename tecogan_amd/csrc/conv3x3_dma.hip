@@ -416,7 +416,7 @@ static void launch_dma(const ConvDmaP& p, hipStream_t st) {
   const int nunits = p.ntiles;
   // persistent over work units: one workgroup per CU; grid.x a multiple of 8 so that the channel blocks of one pixel tile
   // (workgroup ids x, x + grid.x, ...) land on the SAME XCD and share its L2 copy of the halo
-  int gx = 256 / nt;
+  int gx = tg_num_cus() / nt;
   if (gx < 8) gx = 8;
   gx &= ~7;
   if (gx > nunits) gx = nunits;
@@ -443,18 +443,16 @@ static void launch_dma_pk(const ConvDmaP& p, bool res, bool aux, hipStream_t st)
 // Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
 int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                        const void* aux, void* out, hipStream_t st) {
-  static const bool enabled = getenv("TG_NO_C3DMA") == nullptr;            // A/B switch
   // selection threshold in workgroup-units (tiles x channel blocks).  Round 2 set 96 ("below a third of the chip the 8 x 64
   // tiles fill it better"); re-measured in round 3, alternating runs on one box (profiles/r03s_ab.txt): the 1080p inference frame
   // 1.070 -> 1.042 ms with 24 (FNet's 33 x 60 / 66 x 120 levels: the tile kernel's K loop is the longer serial chain there),
   // the training steps unchanged (TecoGAN 12.09-12.15 ms with either)
-  static const int min_wg = getenv("TG_C3DMA_MIN_WG") ? atoi(getenv("TG_C3DMA_MIN_WG")) : 24;
-  if (!enabled) return 0;
+  constexpr int min_wg = 24;
   if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
   if (d->Cin % 32 != 0 || d->Cin < 64 || d->Cout % 64 != 0) return 0;
   if (d->act >= TG_ACT_TANH) return 0;
   // images of exactly 8 x 8 / 4 x 4 pixels: packed tiles (4 / 16 whole images per 16 x 16 tile); other small sizes: conv3x3.hip
-  static const int min_wg_pack = getenv("TG_C3DMA_MIN_WG_PACK") ? atoi(getenv("TG_C3DMA_MIN_WG_PACK")) : 16;
+  constexpr int min_wg_pack = 16;
   const int pk = (d->Hin == 8 && d->Win == 8) ? 2 : ((d->Hin == 4 && d->Win == 4) ? 4 : 1);
   if (pk == 1 && (d->Hin <= 8 || d->Win <= 8)) return 0;
   if ((((uintptr_t)in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15)) return 0;
@@ -474,9 +472,8 @@ int tg_conv3x3_dma_try(const tg_conv_desc* d, const void* in, const void* weight
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
   // packed launches that would fill less than the chip even with 32-channel blocks: twice the workgroups, each with half the
-  // weight panel and half the MFMAs per stage (VGG conv5 at 32 images: 64 -> 128 workgroups; TG_C3DMA_J1=0 switches it off)
-  static const bool j1_on = getenv("TG_C3DMA_J1") == nullptr || atoi(getenv("TG_C3DMA_J1")) != 0;
-  const bool j1 = j1_on && pk > 1 && ntiles * (p.Cout / 32) <= 256;
+  // weight panel and half the MFMAs per stage (VGG conv5 at 32 images: 64 -> 128 workgroups; conv5 at 28-48 images 28.1 -> 21.7 us, profiles/r04y_ab.txt)
+  const bool j1 = pk > 1 && ntiles * (p.Cout / 32) <= 256;
   if (pk == 2 && j1) launch_dma_pk<2, 1>(p, res != nullptr, aux != nullptr, st);
   else if (pk == 2) launch_dma_pk<2, 2>(p, res != nullptr, aux != nullptr, st);
   else if (pk == 4 && j1) launch_dma_pk<4, 1>(p, res != nullptr, aux != nullptr, st);

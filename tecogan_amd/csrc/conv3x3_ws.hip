@@ -535,7 +535,7 @@ int tg_deconv3x3s2_ws_try(const tg_conv_desc* d, const void* in, const void* wei
   });
   const int nt = p.Cout / 64;
   int gx = p.ntiles;
-  const int cap = 512 / nt > 0 ? 512 / nt : 1;
+  const int cap = 2 * tg_num_cus() / nt > 0 ? 2 * tg_num_cus() / nt : 1;
   if (gx > cap) gx = cap;
   TG_LAUNCH("deconv3x3s2_ws", 2.0 * (double)px * 9.0 * p.Cin * p.Cout, (double)px * (p.Cin * 2.0 + 4.0 * p.Cout * 2.0) + 18.0 * p.Cin * p.Cout,
             deconv3x3s2_ws_kernel, dim3(gx, nt), dim3(256), LDS, st, p);
@@ -552,7 +552,7 @@ static void launch_ws_wlds(const ConvWsP& p, hipStream_t st) {
   });
   const int nt = p.Cout / 64;
   int gx = p.ntiles;
-  const int cap = 256 / nt > 0 ? 256 / nt : 1;
+  const int cap = tg_num_cus() / nt > 0 ? tg_num_cus() / nt : 1;
   if (gx > cap) gx = cap;
   static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_ws<res,aux>" : "conv3x3_ws<res>")
                                            : (HAS_AUX ? "conv3x3_ws<aux>" : "conv3x3_ws<>");
@@ -574,19 +574,17 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
   // take 480 of the SIMD's 512 registers and lock the latency-bound chain kernel out of the CU
   // two workgroups per CU pay the weight prologue twice per CU: worth it from ~4 tiles per workgroup on
   // (measured at 1020 tiles: 16.4 us with one, 17.8 us with two; at 9728 tiles: 97 vs 95 us)
-  const int per_cu_env = 0;
-  const int per_cu = coexist ? 1 : (per_cu_env ? (per_cu_env < 2 ? 1 : 2) : (p.ntiles >= 2048 ? 2 : 1));
-  static const bool wlds = getenv("TG_C3WS_WLDS") == nullptr || atoi(getenv("TG_C3WS_WLDS")) != 0;   // A/B switch (=0: off)
+  const int per_cu = coexist ? 1 : (p.ntiles >= 2048 ? 2 : 1);
   // ... from two tiles per workgroup on (the 1080p inference convs: 4); with a single tile per workgroup (FNet's 64-channel
   // layers in the training steps) it measured neutral to slightly slower (12.20 -> 12.26 ms, profiles/r02zzzz_ab.txt)
-  if (wlds && per_cu == 1 && !coexist && p.ntiles >= 2 * (256 / (p.Cout / 64) > 0 ? 256 / (p.Cout / 64) : 1)) {
+  if (per_cu == 1 && !coexist && p.ntiles >= 2 * (tg_num_cus() / (p.Cout / 64) > 0 ? tg_num_cus() / (p.Cout / 64) : 1)) {
     launch_ws_wlds<HAS_RES, HAS_AUX>(p, st);
     return;
   }
   const int LDS = per_cu == 1 ? LDS_MAX : 2 * WS_BUF;
   const int nt = p.Cout / 64;
   int gx = p.ntiles;
-  const int cap = 256 * per_cu / nt > 0 ? 256 * per_cu / nt : 1;
+  const int cap = tg_num_cus() * per_cu / nt > 0 ? tg_num_cus() * per_cu / nt : 1;
   if (gx > cap) gx = cap;
   static const char* const pname = HAS_RES ? (HAS_AUX ? "conv3x3_ws<res,aux>" : "conv3x3_ws<res>")
                                            : (HAS_AUX ? "conv3x3_ws<aux>" : "conv3x3_ws<>");
@@ -599,9 +597,7 @@ static void launch_ws(const ConvWsP& p, hipStream_t st, bool coexist) {
 // Returns 1 if the descriptor was handled here, 0 otherwise (the halo-tile kernel of conv3x3.hip takes it).
 int tg_conv3x3_ws_try(const tg_conv_desc* d, const void* in, const void* weight, const float* bias, const void* res,
                       const void* aux, void* out, hipStream_t st) {
-  static const bool enabled = getenv("TG_NO_C3WS") == nullptr;            // A/B switch
   const int min_tiles = 256;
-  if (!enabled) return 0;
   if (d->in_dtype != TG_BF16 || d->out_dtype != TG_BF16) return 0;
   if (d->Cin % 8 != 0 || d->Cin > 64 || d->Cin < 16 || d->Cout % 64 != 0) return 0;
   if (d->act >= TG_ACT_TANH) return 0;
@@ -652,9 +648,9 @@ extern "C" int tg_conv3x3_c64_frag(const void* x, const void* w_frag, const floa
   p.ntiles = (int)ntiles;
   p.in_bytes = (unsigned)(px * 128); p.w_bytes = 9 * 64 * 64 * 2; p.out_bytes = (unsigned)(px * 128);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static const int per_cu = getenv("TG_C3WS_FRAG_PER_CU") ? atoi(getenv("TG_C3WS_FRAG_PER_CU")) : 2;      // A/B switch
+  constexpr int per_cu = 2;      // two workgroups per CU: 14.0 against 14.5 us with one (profiles/r04q_ab.txt)
   int gx = p.ntiles;
-  if (gx > 256 * per_cu) gx = 256 * per_cu;
+  if (gx > tg_num_cus() * per_cu) gx = tg_num_cus() * per_cu;
   const int LDS = per_cu == 1 ? 2 * WS_BUF + 32768 : 2 * WS_BUF;
   const double fl = 2.0 * px * 64 * 9.0 * 64, by = px * 128.0 * (2 + (res != nullptr)) + 73728.0;
   if (res) {

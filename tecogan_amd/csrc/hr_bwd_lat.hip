@@ -353,8 +353,7 @@ extern "C" int tg_deconv_lat_backward(const void* dy, const void* w_frag, const 
   TG_CHECK_ARG(nt < ((int64_t)1 << 24), "too many tiles: this is the latency-regime kernel");
   p.ntiles = (int)nt;
   p.dy_bytes = (unsigned)(px * 4 * 128); p.dx_bytes = (unsigned)(px * 128);
-  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
-  p.prio = prio;
+  p.prio = 1;                                   // s_setprio 3 in the chain kernels (measured in round 2, see conv3x3.hip)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double fl = 2.0 * px * 64 * 576, by = px * 128.0 * (5 + (aux != nullptr)) + 73728.0;
   if (aux) TG_LAUNCH("deconv_bwd_lat<aux>", fl, by, (deconv_bwd_lat_kernel<true>), dim3(p.ntiles), dim3(256), 0, st, p);
@@ -383,8 +382,7 @@ extern "C" int tg_hr_tail_backward(const float* d_frame, float scale, const void
   p.ntiles = (int)nt;
   p.hr64_bytes = (unsigned)(hr * 128); p.hr8_bytes = (unsigned)(hr * 16); p.dout_bytes = (unsigned)(hr * 12);
   p.t1_bytes = (unsigned)((int64_t)N * H2 * W2 * 128);
-  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
-  p.prio = prio;
+  p.prio = 1;                                   // s_setprio 3 in the chain kernels (measured in round 2, see conv3x3.hip)
   const double px2 = (double)hr, px1 = (double)N * H2 * W2;
   TG_LAUNCH("hr_bwd_lat", 2.0 * px2 * 64 * 27 + 2.0 * px1 * 64 * 576, px2 * (12 + 16 + 128 + 128) + px1 * 256 + 73728.0 + 9216.0,
             hr_bwd_lat_kernel, dim3(p.ntiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);

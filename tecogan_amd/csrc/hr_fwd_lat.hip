@@ -269,8 +269,7 @@ static int hf_launch(bool fuse, const void* x, const void* w_frag, const float* 
   p.ntiles = (int)nt;
   p.x_bytes = (unsigned)(px * 128); p.y_bytes = (unsigned)(px * 4 * 128);
   p.lr_bytes = (unsigned)((int64_t)N * (H1 / 2) * (W1 / 2) * Cpad * 2); p.f_bytes = (unsigned)(px * 4 * 12);
-  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
-  p.prio = prio;
+  p.prio = 1;                                   // s_setprio 3 in the chain kernels (measured in round 2, see conv3x3.hip)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double fl = 2.0 * px * 64 * 64 * 9.0;
   if (fuse)

@@ -313,8 +313,7 @@ extern "C" int tg_resblock(int mode, const void* x, const void* w1, const float*
   TG_CHECK_ARG(nt < ((int64_t)1 << 24), "too many tiles: this is the latency-regime kernel");
   p.ntiles = (int)nt;
   p.bytes = (unsigned)bytes;
-  static const int prio = getenv("TG_C3_PRIO") ? atoi(getenv("TG_C3_PRIO")) : 1;
-  p.prio = prio;
+  p.prio = 1;                                   // s_setprio 3 in the chain kernels (measured in round 2, see conv3x3.hip)
   p.wfrag = w_frag != 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double px = (double)N * H * W;

@@ -37,6 +37,18 @@ bool tg_det() {
   return on;
 }
 
+int tg_num_cus() {
+  static std::atomic<int> cached[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 bool tg_prof_slot(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
   if (!g_on.load(std::memory_order_relaxed)) return false;
   std::lock_guard<std::mutex> lk(g_mu);

@@ -353,8 +353,7 @@ extern "C" int tg_warp_s2d_backward(const void* d_out, int dtype, const float* p
   int grid = grid_1d(work, 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double by = (double)B * h * w * (Cpad * (dtype == TG_F32 ? 4.0 : 2.0) + 16.0 * 12.0 * 3.0 + 16.0);
-  static const bool merge_env = getenv("TG_WARP_BWD_MERGE") == nullptr || atoi(getenv("TG_WARP_BWD_MERGE")) != 0;   // A/B switch
-  const int merge = merge_env && (int64_t)B * h * w * 48 + (int64_t)w * 12 + 16 < ((int64_t)1 << 31);   // 32-bit tap offsets
+  const int merge = (int64_t)B * h * w * 48 + (int64_t)w * 12 + 16 < ((int64_t)1 << 31);   // 32-bit tap offsets
   if (dtype == TG_F32)
     TG_LAUNCH("warp_s2d_bwd<f32>", 0, by, (warp_s2d_bwd_kernel<float>), TG_DET_GRID(grid), TG_DET_WAVE(256), 0, st, (const float*)d_out, pre,
               flow_lr, d_pre, d_flow_lr, B, h, w, Cpad, scale, merge);

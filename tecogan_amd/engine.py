@@ -8,7 +8,6 @@ and each flow slab is a contiguous `[B, ...]` block.  Semantics that differ from
 purpose: all gradients are taken from the pre-update weights, then D (gate permitting), G and FNet
 are applied (the TF1 graph has an ordering race there).
 """
-import contextlib
 import os
 from collections import OrderedDict
 
@@ -16,8 +15,10 @@ import torch
 
 from . import kernels as K
 from .nets import FNET_CPAD, GEN_CPAD, VGG_CPAD, VGG_TAPS, Discriminator, FNet, Generator, VGG19
+from .parallel import ExchangeMixin
 from .params import (DIS_BLOCKS, ParamStore, discriminator_spec, fnet_spec, generator_spec, init_values, pad8,
                      vgg_spec)
+from .segments import SegmentRunner, plan_launch_order  # noqa: F401  (plan_launch_order: re-exported for tools/)
 
 LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_loss_3", "vgg_loss_4", "vgg_loss_5",
               "t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output", "t_discrim_fake_output",
@@ -25,45 +26,9 @@ LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_
 LI = {n: i for i, n in enumerate(LOSS_NAMES)}
 
 
-def plan_launch_order(segs, lazy=True):
-    """Host-side order in which a step's captured segments are launched: yields ("launch", seg) and ("wait", [names]).
-
-    Just-in-time launch of the side-stream (and communication-stream) segments.  A side segment enqueued ahead of time sits
-    in its hardware queue behind a barrier packet until the main stream reaches its dependency, and while it waits there EVERY
-    dispatch of the main stream's queue costs ~0.9 us more (the same tax a forked graph branch has; measured with device
-    stamps: the BPTT segment 6.22 ms with the next step's first side segment pending, 5.26 ms without,
-    profiles/r02o_seg_timeline.txt).  So the host enqueues the main-stream segments as far ahead as their dependencies allow,
-    and launches a side segment only once its dependencies have COMPLETED (a host wait on their events) -- the main stream
-    always has at least one whole segment queued behind the awaited one.  lazy=False: plain program order."""
-    if not lazy:
-        for seg in segs:
-            yield "launch", seg
-        return
-    done, todo = set(), list(segs)
-    while todo:
-        rest, blocked = [], False
-        for seg in todo:                                        # main-stream segments: as far ahead as possible
-            if seg["skey"] == "M" and not blocked and all(d in done for d in seg["deps"]):
-                done.add(seg["name"])
-                yield "launch", seg
-            else:
-                blocked = blocked or seg["skey"] == "M"
-                rest.append(seg)
-        todo = rest
-        for i, seg in enumerate(todo):                          # then the first side / communication segment, once its inputs exist
-            if seg["skey"] != "M":
-                assert all(d in done for d in seg["deps"]), "side segment %s depends on an unlaunched segment" % seg["name"]
-                if seg["deps"]:
-                    yield "wait", list(seg["deps"])
-                done.add(seg["name"])
-                yield "launch", seg
-                del todo[i]
-                break
-        else:
-            assert not todo, "main-stream segments %s wait for segments that are never launched" % [t["name"] for t in todo]
 
 
-class TrainEngine:
+class TrainEngine(SegmentRunner, ExchangeMixin):
     def __init__(self, flags, device="cuda", gan=True, act_dtype=torch.float32, seed=42, process_group=None,
                  use_graph=True, standin_world=0):
         """standin_world=W (tests, one GPU, no process group): run the W-rank program -- communication stream, captured
@@ -134,7 +99,7 @@ class TrainEngine:
         self.in_hr = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev)
         self.seq_idx = list(range(self.T0)) + (list(range(self.T0 - 2, -1, -1)) if F.pingpang else [])
         self._segs = None
-        self.lazy_side = os.environ.get("TG_LAZY_SIDE", "1") == "1"     # A/B switch: just-in-time side-stream launches
+        self.lazy_side = True             # just-in-time side-stream launches (segments.plan_launch_order; False: +1.4 ms, lesson 7)
         # measurement mode: device wall-clock stamps at every segment boundary (one-thread kernels, captured with the segment)
         self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=device) if os.environ.get("TG_SEG_STAMPS") else None
         self.seg_stamp_names = {}
@@ -166,19 +131,20 @@ class TrainEngine:
         # (`step(x, y, next_targets=...)`: the loaders prefetch anyway) gets them put through VGG-19 during THIS step's BPTT
         # phase (segment `vggt_next`); the next step then starts from the stored features (segment `vggt_pre`: one gather).
         # Every step still computes one batch of target features -- one step earlier.  Without `next_targets` the features are
-        # computed in-step as before (segment `vggt`).  TG_TARGET_LOOKAHEAD=0 disables the mechanism.
-        self.lookahead = os.environ.get("TG_TARGET_LOOKAHEAD", "1") == "1" and self.use_vgg
+        # computed in-step as before (segment `vggt`).  A caller that never announces anything never uses the mechanism.
+        self.lookahead = self.use_vgg
         self.in_hr_next = torch.zeros(self.B, self.T0, 4 * h, 4 * h, 3, device=self.dev) if self.lookahead else None
         self._taps_t, self._taps_next = None, None      # persistent feature buffers (outside the graph pools: they cross steps)
         self._next_ready = False                        # _taps_next holds the features of the batch the NEXT step() will get
         self._have_next = False                         # this step() was given next_targets
+        self._announced = None                          # (tensor, its _version) announced as next_targets: identity check in step()
         self._hold = []
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
         uses_side = (self.use_vgg and self.ov_parts & 69) or (gan and self.ov_parts & 10) or bool(self.ov_parts & 32)
-        self.segmented = bool(uses_side) or self.world > 1 or os.environ.get("TG_SEGMENTS") == "force"
+        self.segmented = bool(uses_side) or self.world > 1
         # the chain's own launches also take co-residency-friendly tiles when something runs beside them: the HR deconv
         # (56 KB LDS) and the output conv (67 KB) would otherwise not fit next to a resident <8,64> VGG workgroup (109 KB)
         # and each such node would wait for a CU to drain (~50 us, 27 + 19 nodes per step)
@@ -196,22 +162,30 @@ class TrainEngine:
     def step(self, r_inputs=None, r_targets=None, next_targets=None):
         """One training step.  next_targets (optional, [B,T0,4h,4w,3]): the targets of the batch the NEXT call will train on
         -- their VGG features are computed during this step's backward phase (target lookahead, see __init__); pass the
-        very tensor values the next call passes as r_targets (next_targets=True: the resident batch stays, as in bench.py)."""
+        very TENSOR OBJECT the next call passes as r_targets, unmodified (next_targets=True: the resident batch stays, as in
+        bench.py); a next call with any other tensor computes its target features in-step."""
         ready = self._next_ready
         if r_inputs is not None:
-            self.set_batch(r_inputs, r_targets)
-            if ready:
-                # the previous call announced this batch's targets and their features are stored: the targets of this step
-                # ARE the announced ones by construction (a caller passing something else would otherwise train against
-                # features of other images); TG_CHECK_LOOKAHEAD=1 verifies the caller's promise (costs a sync)
-                if os.environ.get("TG_CHECK_LOOKAHEAD") == "1":
-                    assert torch.equal(self.in_hr, self.in_hr_next), "step(): r_targets differ from the announced next_targets"
-                self.in_hr.copy_(self.in_hr_next, non_blocking=True)
-            self._next_ready = ready
+            # The previous call announced a batch and its target features are stored.  They are used only if THIS call's
+            # r_targets is provably the announced tensor: the same object, not modified in place since (torch's version
+            # counter) -- no device sync, no silent substitution of the caller's targets (ADVICE r4).  Anything else (a skipped
+            # or reshuffled batch, a resume, a fresh `.cuda()` copy of equal values) falls back to the in-step target pass.
+            ann = self._announced
+            kept = ready and ann is not None and r_targets is ann[0] and r_targets._version == ann[1]
+            self.set_batch(r_inputs, r_targets)                  # (clears _next_ready)
+            self._next_ready = kept
+        elif ready and self._announced is not None:
+            self._next_ready = False                             # a resident-batch step after a tensor announcement: not that batch
         self._have_next = self.lookahead and next_targets is not None
+        self._announced = None
         if self._have_next:
-            self.in_hr_next.copy_(self.in_hr if next_targets is True else next_targets, non_blocking=True)
+            if next_targets is True:                             # the resident batch is also the next one (bench.py)
+                self.in_hr_next.copy_(self.in_hr, non_blocking=True)
+            else:
+                self.in_hr_next.copy_(next_targets, non_blocking=True)
+                self._announced = (next_targets, next_targets._version)
         self.host_step += 1
+        self.used_stored_targets = bool(self._next_ready)      # (observable for tests / logs: this step starts from looked-ahead features)
         if not self.use_graph:
             self._run_program("eager")
         else:
@@ -237,139 +211,6 @@ class TrainEngine:
         return self.losses()
 
     # ------------------------------------------------------------------------------------------
-    # Execution model: a step is a DAG of SEGMENTS.  A segment is a run of launches on one of three streams -- "M" the
-    # caller's stream (the recurrent chain and everything ordered with it), "S" the side stream (throughput work that
-    # may run beside the chain), "C" the communication stream (RCCL) -- with explicit dependencies on earlier segments.
-    # Captured, every segment is its OWN single-stream hipGraph, replayed on its stream with event waits in between.
-    # Why not one multi-stream graph: on this stack a graph with ANY forked branch pays +0.9 us on every node (3.63 ->
-    # 4.53 us per chain node with one tiny forked kernel, tools/mb_forktax.py), +1.8 ms on the 3000-node TecoGAN step,
-    # more than the overlap returns; single-stream graphs on two streams overlap as well as a forked graph does and
-    # keep the 3.6 us node.  Memory: one graph pool per stream (segments of a stream replay in capture order, so reuse
-    # inside a pool is safe; tensors that cross streams stay referenced in self._hold).
-    def _seg_on(self, name, skey, cond):
-        """Conditional segments (`cond`: a host predicate evaluated per step): captured always, replayed -- or, in the eager
-        program, executed -- only when cond() holds; a skipped segment counts as done.  Use as
-        `if self._seg_on(name, skey, cond): with self._seg(name, skey, after, cond=cond): ...`."""
-        if self._mode in ("eager", "flat") and not cond():
-            self._done[name] = (None, skey)
-            return False
-        return True
-
-    @contextlib.contextmanager
-    def _seg(self, name, skey="M", after=(), cond=None):
-        deps = [d for d in after if d in self._done and self._done[d][1] != skey]
-        if self._mode == "flat":                       # one stream, one graph (or plain eager): nothing to do
-            self._done[name] = (None, "M")
-            yield
-            return
-        if self._mode == "eager":
-            st = self._main if skey == "M" else self.streams[skey]
-            for d in deps:
-                if self._done[d][0] is not None:       # (None: a skipped conditional segment)
-                    st.wait_event(self._done[d][0])
-            with torch.cuda.stream(st):
-                self._stamp(name, 0)
-                yield
-                self._stamp(name, 1)
-            ev = torch.cuda.Event()
-            ev.record(st)
-            self._done[name] = (ev, skey)
-            return
-        g = torch.cuda.CUDAGraph()                     # capture
-        with torch.cuda.graph(g, pool=self._pool(skey), capture_error_mode="thread_local"):
-            self._stamp(name, 0)
-            yield
-            self._stamp(name, 1)
-        seg = dict(name=name, skey=skey, deps=deps, graph=g, fn=None, event=torch.cuda.Event(), cond=cond)
-        self._segs.append(seg)
-        self._done[name] = (seg["event"], skey)
-
-    def _stamp(self, name, end):
-        """TG_SEG_STAMPS=1: device wall-clock stamps at the segment's first and last node (tools/seg_timeline.py)."""
-        if self.seg_stamps is None:
-            return
-        i = self.seg_stamp_names.setdefault(name, len(self.seg_stamp_names))
-        K.prof_stamp(self.seg_stamps[2 * i + end:2 * i + end + 1])
-
-    def _seg_call(self, name, skey, after, fn):
-        """A segment that cannot be captured (a gloo all-reduce): `fn` runs eagerly on the segment's stream every step."""
-        if self._mode != "capture":
-            with self._seg(name, skey, after):
-                fn()
-            return
-        deps = [d for d in after if d in self._done and self._done[d][1] != skey]
-        seg = dict(name=name, skey=skey, deps=deps, graph=None, fn=fn, event=torch.cuda.Event())
-        self._segs.append(seg)
-        self._done[name] = (seg["event"], skey)
-
-    def _pool(self, skey):
-        if skey not in self._pools:
-            self._pools[skey] = torch.cuda.graph_pool_handle()
-        return self._pools[skey]
-
-    def _run_program(self, mode):
-        self._mode = mode if self.segmented else "flat"
-        self._main = torch.cuda.current_stream()
-        self._done = {}
-        self.exchange_segments = []
-        self._program()
-
-    def _replay(self):
-        main = torch.cuda.current_stream()
-        evs = {}
-
-        def launch(seg):
-            if seg.get("cond") is not None and not seg["cond"]():
-                evs[seg["name"]] = None                 # skipped this step: nothing to wait for
-                return
-            st = main if seg["skey"] == "M" else self.streams[seg["skey"]]
-            for d in seg["deps"]:
-                if evs[d] is not None:
-                    st.wait_event(evs[d])
-            if st is main:
-                seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
-            else:
-                with torch.cuda.stream(st):
-                    seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
-            seg["event"].record(st)
-            evs[seg["name"]] = seg["event"]
-
-        for what, arg in plan_launch_order(self._segs, self.lazy_side):
-            if what == "wait":
-                for d in arg:
-                    if evs[d] is not None:
-                        evs[d].synchronize()
-            else:
-                launch(arg)
-
-    def _capture(self):
-        # warm-up run (allocator pools, lazy module loads, the real two-stream schedule), state restored afterwards
-        snap = [t.clone() for t in (self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper)]
-        moving = [m.clone() for m in self.D.moving] if self.gan else []
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self._run_program("eager")
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        for t, c in zip((self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper), snap):
-            t.copy_(c)
-        for m, c in zip(self.D.moving if self.gan else [], moving):
-            m.copy_(c)
-        self.ps.repack()
-        torch.cuda.synchronize()
-        # (a captured RCCL exchange that fails to capture is an ERROR: a silent eager fallback on an 8-GPU node would only
-        #  show up as a slower number.  TG_EXCHANGE=eager selects the eager-split exchange explicitly.)
-        self._segs = []
-        if self.segmented:
-            self._run_program("capture")
-        else:                                # one stream, no exchange: the whole step is ONE graph
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._run_program("flat")
-            self._segs.append(dict(name="step", skey="M", deps=[], graph=g, fn=None, event=torch.cuda.Event()))
-
-    # ------------------------------------------------------------------------------------------
     def _program(self):
         self._program_compute()
         if self.gan and self._mode in ("eager", "capture", "flat"):
@@ -378,42 +219,17 @@ class TrainEngine:
             self.D.set_scratch(None)
         if self._skip_update:
             return
-        after = ["down", "wgrad"]
+        # (vggt_next reads in_hr_next and writes _taps_next on the side stream: the next step()'s host-side copies into those
+        #  buffers are ordered on the MAIN stream, so the update segment joins it explicitly -- ADVICE r4: without overlap bit
+        #  32 nothing else did)
+        after = ["down", "wgrad", "vggt_next"]
         if self.exchange_mode == "eager-split":
             self._seg_call("exchange", "M", after, self._allreduce)
             after = ["exchange"]
         elif self.exchange_mode == "captured":
-            after = ["down", "wgrad", "ar_d", "ar_g", "ar_f"]
+            after = ["down", "wgrad", "vggt_next", "ar_d", "ar_g", "ar_f"]
         with self._seg("update", "M", after):
             self._program_update()
-
-    def _exchange_seg(self, name, scopes, after, with_balance=False):
-        """captured mode: all-reduce `scopes` of the flat gradient buffer as a segment of the communication stream,
-        ordered after the segments `after`; it overlaps whatever the compute streams do next, `update` joins."""
-        if self.exchange_mode != "captured" or self._skip_update:
-            # eval_losses (validation on ONE rank, main.py) must not issue collectives: an all-reduce from rank 0 alone would
-            # pair with the other ranks' next training step and shift every later collective by one
-            return
-        with self._seg(name, "C", after):
-            if with_balance and self.gan:            # every rank must take the same D-gate branch (lib/Teco.py:493-494)
-                tb = self.loss[LI["t_balance"]:LI["t_balance"] + 1]
-                self._sum_all_reduce(tb)
-                K.affine(tb, tb, 1.0 / self.world, 0.0)
-            for scope in scopes:
-                a, b = self.ps.scope_range[scope]
-                self._sum_all_reduce(self.ps.grad[a:b])
-        self.exchange_segments.append(name)
-
-    def _sum_all_reduce(self, t):
-        if self.standin > 1:                         # test stand-in: W identical ranks
-            K.affine(t, t, float(self.standin), 0.0)
-        else:
-            torch.distributed.all_reduce(t, group=self.pg)
-
-    def allreduce_bytes(self):
-        """Bytes every rank contributes to the gradient exchange of one step (fp32 flat buffers + the balance scalar)."""
-        n = sum(self.ps.scope_range[s][1] - self.ps.scope_range[s][0] for s in self.opt_scopes)
-        return 4 * n + (4 if self.gan else 0)
 
     def _program_compute(self):
         """Forward + backward of one step as segments on two streams.
@@ -658,11 +474,6 @@ class TrainEngine:
         ps.repack()
 
     # ------------------------------------------------------------------------------------------
-    def _allreduce(self):
-        from .parallel import exchange
-        tbv = self.loss[LI["t_balance"]:LI["t_balance"] + 1] if self.gan else None
-        exchange(self.ps.grad, self.ps.scope_range, self.opt_scopes, tbv, self.pg)
-
     def _slot(self, name):
         return self.loss[LI[name]:LI[name] + 1]
 

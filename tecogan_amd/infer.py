@@ -16,9 +16,9 @@ state), and the reference's loop holds the whole clip before it starts (lib/data
 therefore runs FNet for the NEXT frame on a second HIP stream beside this frame's generator (forked after the warp kernel, joined
 at the end of the step, both inside the one captured graph): the 14 small FNet convs (0.22 of a 1.0 ms 1080p frame,
 profiles/r03z_infer1080p_bf16_kernel_stats.txt) leave the frame's critical path.  The announced frame is a promise: the next call
-must pass that frame (TG_CHECK_LOOKAHEAD=1 verifies it); without `next_frame` the step computes its own flow first, as before.
+must pass that very tensor object, unmodified (checked by identity + torch's version counter: no sync; any other tensor makes
+the step compute its own flow first, as a call without `next_frame` does).
 """
-import os
 from collections import OrderedDict
 
 import torch
@@ -43,8 +43,8 @@ class InferenceEngine:
         self.pre_inputs = torch.zeros(batch, h, w, 3, device=self.dev)
         self.pre_gen = torch.zeros(batch, 4 * h, 4 * w, 3, device=self.dev)
         self.flow_next = torch.zeros(batch, h - h % 8, w - w % 8, 2, device=self.dev)   # flow(frame -> frame_next), side stream
-        self.lookahead = os.environ.get("TG_INFER_LOOKAHEAD", "1") == "1"         # A/B: 0 ignores next_frame
-        self.check_lookahead = os.environ.get("TG_CHECK_LOOKAHEAD", "0") == "1"
+        self.lookahead = True                                                      # False: next_frame ignored (FNet in line, one stream)
+        self._announced = None                                                     # (tensor, its _version) passed as next_frame
         self._have_flow = False                                                    # flow_next belongs to the coming step
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.use_graph, self.graphs = use_graph, {}
@@ -86,12 +86,19 @@ class InferenceEngine:
         beside this frame's generator).  Returns the HR frame [B,4h,4w,3] in [0,1] (a view of the recurrent state: copy it if
         you keep it across steps)."""
         if frame is not None:
-            if self._have_flow and self.check_lookahead:
-                assert torch.equal(self.frame_next, frame.to(self.frame_next.device)), "step(): not the announced frame"
+            # flow_next belongs to this frame only if it IS the announced tensor (same object, not written since): otherwise the
+            # stored flow is dropped and the step computes its own (a caller that skips or reorders frames stays correct)
+            ann = self._announced
+            if self._have_flow and not (ann is not None and frame is ann[0] and frame._version == ann[1]):
+                self._have_flow = False
             self.frame.copy_(frame, non_blocking=True)
+        elif self._have_flow:
+            self._have_flow = False                                                # re-running the resident frame: not the announced one
         ahead = self.lookahead and next_frame is not None
+        self._announced = None
         if ahead:
             self.frame_next.copy_(next_frame, non_blocking=True)
+            self._announced = (next_frame, next_frame._version)
         key = (self._have_flow, ahead)
         if not self.use_graph:
             self._program(*key)

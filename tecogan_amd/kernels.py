@@ -164,16 +164,6 @@ def bicubic_add_preprocess(conv_out, gen_in, out, state=None):
     return out if out is not None else state
 
 
-def hr_tail_forward(t1, w_tran, b_tran, w_out, b_out, gen_in, out, state=None):
-    """Fused second transposed conv + ReLU + output conv + bicubic skip + value ranges (csrc/hr_tail.hip; bf16 only).
-    t1 [N,h2,w2,64]; out / state fp32 [N,2 h2,2 w2,3] (either may be None)."""
-    N, h2, w2, C = t1.shape
-    assert C == 64 and t1.dtype == torch.bfloat16 and gen_in.dtype == torch.bfloat16
-    check(lib().tg_hr_tail_forward(_p(t1), _p(w_tran), _p(b_tran), _p(w_out), _p(b_out), _p(gen_in), gen_in.shape[-1], _p(out),
-                                   _p(state), N, h2, w2, _stream()), "tg_hr_tail_forward")
-    return out if out is not None else state
-
-
 def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out, w_frag=False):
     """One residual block (mode 0) / its input-gradient chain (mode 1) as one launch (csrc/resblock_lat.hip; bf16, C = 64).
     w_frag: w1 / w2 are fragment-order copies (pack_weights_frag / frag_order)."""

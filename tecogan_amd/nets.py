@@ -135,27 +135,24 @@ class Generator:
     def __init__(self, ps, num_resblock):
         self.ps, self.nres = ps, num_resblock
         self.seq = None
-        # one grouped weight-gradient launch for all res-block convs; TG_WGRAD_GROUPED=0 is the A/B switch
-        # (FRVSR step 4.25 -> 3.91 ms in the same session, profiles/r01o_grouped_wgrad_ab.txt)
-        self.grouped_wgrad = os.environ.get("TG_WGRAD_GROUPED", "1") == "1"
+        # Kernel-selection attributes (plain attributes, no environment switches: tests and tools/ flip them for A/Bs).
+        # grouped_wgrad : ONE grouped weight-gradient launch for all res-block convs (FRVSR step 4.25 -> 3.91 ms, profiles/r01o_*)
+        # hr_tail       : fused HR tail of the stateless (inference) forward for bf16 tensors -- the phase-form kernel of the
+        #                 training recurrence without its t2 store (csrc/hr_fwd_lat.hip; 1080p tail 227 -> 164 us against the
+        #                 round-3 kernel it replaced, profiles/r04m_ab.txt)
+        # ws_frag       : inference res-block convs with the weights in fragment order (csrc/conv3x3_ws.hip, profiles/r04q_ab.txt)
+        # resblock_lat / hr_fwd_lat / hr_bwd_lat : the latency-regime kernels of the training recurrence (one launch per residual
+        #                 block, per transposed conv / HR tail, per BPTT HR tail); off = the generic tg_conv_forward launches
+        #                 (bit-identical blocks: tests/test_train_gpu.py)
+        self.grouped_wgrad = True
+        self.hr_tail = True
+        self.ws_frag = True
+        self.resblock_lat = self.hr_fwd_lat = self.hr_bwd_lat = True
+        self.resblock_max_tiles = 1024          # 4x4-pixel tiles up to which one workgroup per tile is the latency-optimal shape
         # scheduling hint for the recurrence's own launches (forward_t / backward_t): K.CONV_COEXIST when throughput work
         # of another stream shares the chip, so that the chain's bigger launches (HR deconv, output conv) also pick tile
         # shapes that fit NEXT to a resident VGG workgroup instead of waiting for a CU to drain
         self.chain_flags = 0
-        # fused HR tail of the stateless (inference) forward (csrc/hr_tail.hip); TG_HR_TAIL=0 is the A/B switch
-        # (1080p frame 1.103 -> 1.068 ms, profiles/r03a_ab.txt)
-        self.hr_tail = os.environ.get("TG_HR_TAIL", "1") == "1"
-        self.ws_frag = os.environ.get("TG_C3WS_FRAG", "1") == "1"             # A/B: 0 = tg_conv_forward with the row-major operand
-        self.hr_tail_lat = os.environ.get("TG_HR_TAIL_LAT", "1") == "1"        # A/B: 0 = csrc/hr_tail.hip in the stateless forward
-        # one launch per residual block in the training recurrence (csrc/resblock_lat.hip: bf16 frames in the latency regime);
-        # TG_RESBLOCK_LAT=0 is the A/B switch (two tg_conv_forward launches per block, bit-identical results)
-        self.resblock_lat = os.environ.get("TG_RESBLOCK_LAT", "1") == "1"
-        self.resblock_max_tiles = int(os.environ.get("TG_RESBLOCK_LAT_MAX_TILES", "1024"))
-        # the BPTT's HR tail (frame gradient -> g_out -> g_t2 -> g_t1) as one launch; TG_HR_BWD_LAT=0 is the A/B switch
-        self.hr_bwd_lat = os.environ.get("TG_HR_BWD_LAT", "1") == "1"
-        # the forward HR tail: both transposed convs as latency-regime launches, the second fused with the output conv and the
-        # bicubic skip (csrc/hr_fwd_lat.hip); TG_HR_FWD_LAT=0 is the A/B switch
-        self.hr_fwd_lat = os.environ.get("TG_HR_FWD_LAT", "1") == "1"
 
     # ---- stateless forward -----------------------------------------------------------------------
     def forward(self, x_in, keep=False, out=None, state=None):
@@ -182,20 +179,15 @@ class Generator:
             a = conv_fwd(ps, s + "conv_2/Conv/weights", s + "conv_2/Conv/biases", r, 1, ACT_NONE, 0.0, res=a)
         s = p + "conv_tran2highres/conv_tran%d/Conv2d_transpose/"
         t1 = deconv_fwd(ps, s % 1 + "weights", s % 1 + "biases", a, ACT_RELU)
-        if self.hr_tail and t1.dtype == torch.bfloat16:
-            # fused HR tail (csrc/hr_tail.hip): the 64-channel HR tensor t2 is never written
+        if self.hr_tail and t1.dtype == torch.bfloat16 and ps.frag:
+            # fused HR tail: the phase-form kernel of the training recurrence, persistent at this size and without its t2 store
+            # (csrc/hr_fwd_lat.hip) -- the 64-channel HR tensor t2 is never written
             wo, bo = p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases"
             N, h2, w2, _ = t1.shape
             o = None if out is False else (torch.empty(N, 2 * h2, 2 * w2, 3, device=t1.device) if out is None else out)
             assert o is not None or state is not None
-            if self.hr_tail_lat and ps.frag:
-                # the phase-form kernel of the training recurrence, persistent at this size (csrc/hr_fwd_lat.hip): 1080p tail
-                # 227 -> 164 us already as a per-tile launch (profiles/r04m_ab.txt)
-                r = K.hr_tail_train(t1, ps.packed_frag(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
-                                    ps.view(bo), x_in, None, o, state)
-            else:
-                r = K.hr_tail_forward(t1, ps.packed(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
-                                      ps.view(bo), x_in, o, state)
+            r = K.hr_tail_train(t1, ps.packed_frag(s % 2 + "weights", False), ps.view(s % 2 + "biases"), ps.packed(wo, True),
+                                ps.view(bo), x_in, None, o, state)
             return r, None
         t2 = deconv_fwd(ps, s % 2 + "weights", s % 2 + "biases", t1, ACT_RELU)
         c = conv_fwd(ps, p + "output_stage/conv/Conv/weights", p + "output_stage/conv/Conv/biases", t2, 1,
@@ -366,7 +358,7 @@ class FNet:
 
     def __init__(self, ps):
         self.ps = ps
-        self.wgrad_multi = os.environ.get("TG_FNET_WGRAD_MULTI", "1") == "1"      # A/B switch
+        self.wgrad_multi = True        # the 14 weight gradients as ONE multi-geometry launch (651 -> 490 us, profiles/r03u_mb_fnet.txt)
 
     def forward(self, x, keep=True):
         """x [N,h,w,8] (prev LR | cur LR | 0-pad) -> flow [N,h',w',2] fp32 (h' = h - h%8)."""
@@ -391,7 +383,7 @@ class FNet:
 
     def backward(self, saved_all, d_flow, flags=0):
         """Backward pass: the input-gradient chain first, then the 14 weight gradients as ONE multi-geometry launch
-        (tg_conv_wgrad_multi; TG_FNET_WGRAD_MULTI=0: one launch per layer, interleaved with the chain as in round 2): as
+        (tg_conv_wgrad_multi; `wgrad_multi = False`: one launch per layer, interleaved with the chain as in round 2): as
         separate launches they are 14 x 17-35 us of launch, prologue and atomics tails for 37 GFLOP of work."""
         ps, p = self.ps, self.P
         saved, net_last, o1, flow = saved_all

@@ -1,0 +1,197 @@
+"""Segment machinery of the training engine: a step's program is written once (engine.TrainEngine._program) as a sequence of
+`with self._seg(name, stream, after): ...` blocks and executed three ways -- eagerly on the segment's stream, captured as one
+single-stream hipGraph per segment, or flat (one stream, one graph).  This module holds the host-side launch planner, the
+capture and the replay; it knows nothing about what the segments compute (reference: the whole of lib/Teco.py:77-517 is ONE
+sess.run there -- the schedule is this framework's own).
+"""
+import contextlib
+import time
+
+import torch
+
+from . import kernels as K
+
+
+def plan_launch_order(segs, lazy=True):
+    """Host-side order in which a step's captured segments are launched: yields ("launch", seg) and ("wait", [names]).
+
+    Just-in-time launch of the side-stream (and communication-stream) segments.  A side segment enqueued ahead of time sits
+    in its hardware queue behind a barrier packet until the main stream reaches its dependency, and while it waits there EVERY
+    dispatch of the main stream's queue costs ~0.9 us more (the same tax a forked graph branch has; measured with device
+    stamps: the BPTT segment 6.22 ms with the next step's first side segment pending, 5.26 ms without,
+    profiles/r02o_seg_timeline.txt).  So the host enqueues the main-stream segments as far ahead as their dependencies allow,
+    and launches a side segment only once its dependencies have COMPLETED (a host wait on their events) -- the main stream
+    always has at least one whole segment queued behind the awaited one.  lazy=False: plain program order."""
+    if not lazy:
+        for seg in segs:
+            yield "launch", seg
+        return
+    done, todo = set(), list(segs)
+    while todo:
+        rest, blocked = [], False
+        for seg in todo:                                        # main-stream segments: as far ahead as possible
+            if seg["skey"] == "M" and not blocked and all(d in done for d in seg["deps"]):
+                done.add(seg["name"])
+                yield "launch", seg
+            else:
+                blocked = blocked or seg["skey"] == "M"
+                rest.append(seg)
+        todo = rest
+        for i, seg in enumerate(todo):                          # then the first side / communication segment, once its inputs exist
+            if seg["skey"] != "M":
+                assert all(d in done for d in seg["deps"]), "side segment %s depends on an unlaunched segment" % seg["name"]
+                if seg["deps"]:
+                    yield "wait", list(seg["deps"])
+                done.add(seg["name"])
+                yield "launch", seg
+                del todo[i]
+                break
+        else:
+            assert not todo, "main-stream segments %s wait for segments that are never launched" % [t["name"] for t in todo]
+
+
+class SegmentRunner:
+    """Mixin of TrainEngine.  Expects: self.segmented, self.streams {"S": stream, "C": stream | None}, self.lazy_side,
+    self.seg_stamps / self.seg_stamp_names, self._pools, self._segs, self._done, self._mode, self._main, self._program(),
+    and the state tensors _capture() snapshots (self.ps, self.sched, self.hyper, self.D / self.gan)."""
+
+    # `launch_jitter`: None, or a callable(segment name) -> seconds of host sleep injected right before a just-in-time
+    # (side / communication stream) segment is launched.  Test hook for the multi-GPU design: with N ranks every collective
+    # segment sits behind a host-side wait of that rank, so per-rank host jitter lands in front of every all-reduce
+    # (tests/test_train_gpu.py::test_host_jitter_before_exchange_segments...).
+    launch_jitter = None
+
+    # Execution model: a step is a DAG of SEGMENTS.  A segment is a run of launches on one of three streams -- "M" the
+    # caller's stream (the recurrent chain and everything ordered with it), "S" the side stream (throughput work that
+    # may run beside the chain), "C" the communication stream (RCCL) -- with explicit dependencies on earlier segments.
+    # Captured, every segment is its OWN single-stream hipGraph, replayed on its stream with event waits in between.
+    # Why not one multi-stream graph: on this stack a graph with ANY forked branch pays +0.9 us on every node (3.63 ->
+    # 4.53 us per chain node with one tiny forked kernel, tools/mb_forktax.py), +1.8 ms on the 3000-node TecoGAN step,
+    # more than the overlap returns; single-stream graphs on two streams overlap as well as a forked graph does and
+    # keep the 3.6 us node.  Memory: one graph pool per stream (segments of a stream replay in capture order, so reuse
+    # inside a pool is safe; tensors that cross streams stay referenced in self._hold).
+    def _seg_on(self, name, skey, cond):
+        """Conditional segments (`cond`: a host predicate evaluated per step): captured always, replayed -- or, in the eager
+        program, executed -- only when cond() holds; a skipped segment counts as done.  Use as
+        `if self._seg_on(name, skey, cond): with self._seg(name, skey, after, cond=cond): ...`."""
+        if self._mode in ("eager", "flat") and not cond():
+            self._done[name] = (None, skey)
+            return False
+        return True
+
+    @contextlib.contextmanager
+    def _seg(self, name, skey="M", after=(), cond=None):
+        deps = [d for d in after if d in self._done and self._done[d][1] != skey]
+        if self._mode == "flat":                       # one stream, one graph (or plain eager): nothing to do
+            self._done[name] = (None, "M")
+            yield
+            return
+        if self._mode == "eager":
+            st = self._main if skey == "M" else self.streams[skey]
+            for d in deps:
+                if self._done[d][0] is not None:       # (None: a skipped conditional segment)
+                    st.wait_event(self._done[d][0])
+            with torch.cuda.stream(st):
+                self._stamp(name, 0)
+                yield
+                self._stamp(name, 1)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._done[name] = (ev, skey)
+            return
+        g = torch.cuda.CUDAGraph()                     # capture
+        with torch.cuda.graph(g, pool=self._pool(skey), capture_error_mode="thread_local"):
+            self._stamp(name, 0)
+            yield
+            self._stamp(name, 1)
+        seg = dict(name=name, skey=skey, deps=deps, graph=g, fn=None, event=torch.cuda.Event(), cond=cond)
+        self._segs.append(seg)
+        self._done[name] = (seg["event"], skey)
+
+    def _stamp(self, name, end):
+        """TG_SEG_STAMPS=1: device wall-clock stamps at the segment's first and last node (tools/seg_timeline.py)."""
+        if self.seg_stamps is None:
+            return
+        i = self.seg_stamp_names.setdefault(name, len(self.seg_stamp_names))
+        K.prof_stamp(self.seg_stamps[2 * i + end:2 * i + end + 1])
+
+    def _seg_call(self, name, skey, after, fn):
+        """A segment that cannot be captured (a gloo all-reduce): `fn` runs eagerly on the segment's stream every step."""
+        if self._mode != "capture":
+            with self._seg(name, skey, after):
+                fn()
+            return
+        deps = [d for d in after if d in self._done and self._done[d][1] != skey]
+        seg = dict(name=name, skey=skey, deps=deps, graph=None, fn=fn, event=torch.cuda.Event())
+        self._segs.append(seg)
+        self._done[name] = (seg["event"], skey)
+
+    def _pool(self, skey):
+        if skey not in self._pools:
+            self._pools[skey] = torch.cuda.graph_pool_handle()
+        return self._pools[skey]
+
+    def _run_program(self, mode):
+        self._mode = mode if self.segmented else "flat"
+        self._main = torch.cuda.current_stream()
+        self._done = {}
+        self.exchange_segments = []
+        self._program()
+
+    def _replay(self):
+        main = torch.cuda.current_stream()
+        evs = {}
+
+        def launch(seg):
+            if seg.get("cond") is not None and not seg["cond"]():
+                evs[seg["name"]] = None                 # skipped this step: nothing to wait for
+                return
+            st = main if seg["skey"] == "M" else self.streams[seg["skey"]]
+            for d in seg["deps"]:
+                if evs[d] is not None:
+                    st.wait_event(evs[d])
+            if st is main:
+                seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
+            else:
+                with torch.cuda.stream(st):
+                    seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
+            seg["event"].record(st)
+            evs[seg["name"]] = seg["event"]
+
+        for what, arg in plan_launch_order(self._segs, self.lazy_side):
+            if what == "wait":
+                for d in arg:
+                    if evs[d] is not None:
+                        evs[d].synchronize()
+            else:
+                jitter = getattr(self, "launch_jitter", None)
+                if jitter is not None and arg["skey"] != "M":
+                    time.sleep(max(0.0, float(jitter(arg["name"]))))
+                launch(arg)
+
+    def _capture(self):
+        # warm-up run (allocator pools, lazy module loads, the real two-stream schedule), state restored afterwards
+        snap = [t.clone() for t in (self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper)]
+        moving = [m.clone() for m in self.D.moving] if self.gan else []
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._run_program("eager")
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, c in zip((self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper), snap):
+            t.copy_(c)
+        for m, c in zip(self.D.moving if self.gan else [], moving):
+            m.copy_(c)
+        self.ps.repack()
+        torch.cuda.synchronize()
+        # (a captured RCCL exchange that fails to capture is an ERROR: a silent eager fallback on an 8-GPU node would only
+        #  show up as a slower number.  TG_EXCHANGE=eager selects the eager-split exchange explicitly.)
+        self._segs = []
+        if self.segmented:
+            self._run_program("capture")
+        else:                                # one stream, no exchange: the whole step is ONE graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._run_program("flat")
+            self._segs.append(dict(name="step", skey="M", deps=[], graph=g, fn=None, event=torch.cuda.Event()))

@@ -452,12 +452,18 @@ def test_test_while_train_spawns_the_reference_inference_command(tmp_path, monke
     seen = {}
 
     class FakePopen:
+        pid = 999999
+
         def __init__(self, cmd, preexec_fn=None):
             seen["cmd"], seen["preexec"] = cmd, preexec_fn
             seen["spawned"] = seen.get("spawned", 0) + 1
 
+        def poll(self):                                          # non-blocking reap (never wait() in the training loop)
+            seen["polled"] = seen.get("polled", 0) + 1
+            return None if seen.get("running") else 0
+
         def wait(self):
-            seen["reaped"] = seen.get("reaped", 0) + 1
+            seen["waited"] = seen.get("waited", 0) + 1
 
     monkeypatch.setattr(subprocess, "Popen", FakePopen)
     child = M.testWhileTrain(F, 500)
@@ -470,11 +476,20 @@ def test_test_while_train_spawns_the_reference_inference_command(tmp_path, monke
     assert opts["--output_dir"] == opts["--summary_dir"] == os.path.join(str(tmp_path / "out"), "train/")
     assert opts["--input_dir_LR"] == "./LR/calendar/" and opts["--output_pre"] == "" and opts["--output_name"] == "000000500"
     FL.parse(cmd[2:])                                            # the child's command line parses with the same flag table
-    # the previous try-out is reaped before the next one starts (no zombies, no two children on the GPU at once)
+    # the previous try-out is reaped without blocking before the next one starts (no zombies, no two children on the GPU at
+    # once); while it is still running the new try-out is SKIPPED, never waited for (the reference fires and forgets)
     M.testWhileTrain(F, 1000)
-    assert seen["spawned"] == 2 and seen["reaped"] == 1
+    assert seen["spawned"] == 2 and seen["polled"] == 1 and "waited" not in seen
+    seen["running"] = True
+    assert M.testWhileTrain(F, 1250) is None and seen["spawned"] == 2 and "waited" not in seen
+    monkeypatch.setattr(M, "TESTWHILETRAIN_MAX_S", -1)           # ... unless it is hung: killed (its process group), then reaped
+    killed = []
+    monkeypatch.setattr(os, "killpg", lambda pid, sig: killed.append(pid))
+    M.testWhileTrain(F, 1300)
+    assert killed == [999999] and seen["waited"] == 1 and seen["spawned"] == 3
+    seen["running"] = False
     monkeypatch.setenv("TG_TEST_WHILE_TRAIN", "0")
-    assert M.testWhileTrain(F, 1500) is None and seen["spawned"] == 2 and seen["reaped"] == 2
+    assert M.testWhileTrain(F, 1500) is None and seen["spawned"] == 3
 
 
 def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():

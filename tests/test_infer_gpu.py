@@ -65,13 +65,24 @@ def test_inference_frame_lookahead_is_bit_identical(act_dtype, use_graph):
     seq = [torch.rand(1, h, w, 3, generator=g).cuda() for _ in range(12)]
     a = InferenceEngine(nres, h, w, "cuda", act_dtype, use_graph=use_graph)
     b = InferenceEngine(nres, h, w, "cuda", act_dtype, use_graph=use_graph)
-    b.check_lookahead = True
     assert b.lookahead
     for i, f in enumerate(seq):
         nxt = seq[i + 1] if i + 1 < len(seq) and i not in (4, 5, 8) else None    # frames 5, 6 and 9 arrive unannounced
         fa = a.step(f).clone()
-        fb = b.step(f, next_frame=nxt).clone()
+        # frame 3: a BROKEN promise -- frame 2's call announced seq[3], this call passes another tensor (equal values, so the
+        # reference stream is unchanged): the stored flow must be dropped (identity check, no sync), not silently used
+        fb = b.step(f.clone() if i == 3 else f, next_frame=nxt)
         assert torch.equal(fa, fb), "frame %d" % i
+    b2 = InferenceEngine(nres, h, w, "cuda", act_dtype, use_graph=False)
+    b2.step(seq[0], next_frame=seq[1])
+    assert b2._have_flow
+    other = seq[2]
+    b2.step(other)                                   # not the announced frame
+    assert not b2._have_flow
+    b2.step(seq[3], next_frame=seq[4])
+    seq[4].add_(0.0)                                 # announced tensor written in place afterwards: version counter moved
+    b2.step(seq[4])
+    assert not b2._have_flow
     if use_graph:
         assert len(b.graphs) == 4 and len(a.graphs) == 1
 
@@ -130,12 +141,13 @@ def test_inference_270x480_120_frame_stream_fp32_parity():
     eng = InferenceEngine(nres, h, w, "cuda", torch.float32, use_graph=True)
     eng.load(P)
     worst, checked = 0.0, 0
+    dev = [f.cuda() for f in seq]
     for i, f in enumerate(seq):
         free = i < 8
         forced = i >= 8 and i % 16 == 15
         if forced:                                   # the oracle's state := the engine's state before this frame
             st.pre_inputs, st.pre_gen, st.first = eng.pre_inputs.cpu().clone(), eng.pre_gen.cpu().clone(), False
-        out = eng.step(f.cuda(), next_frame=seq[i + 1].cuda() if i + 1 < len(seq) else None)
+        out = eng.step(dev[i], next_frame=dev[i + 1] if i + 1 < len(dev) else None)    # (the same tensor objects: the promise is checked by identity)
         if free or forced:
             ref = OT.inference_step(P, st, f, nres)
             worst = max(worst, assert_close_per_elem(out.cpu(), ref, 1e-3, 1e-3, what="270x480 stream frame %d" % i))

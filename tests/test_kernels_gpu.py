@@ -1063,36 +1063,6 @@ def test_deconv3x3s2_weights_in_registers_kernel(case):
     assert (err <= 8e-3 * ref.abs() + 2e-2).all(), "%s: max err %g" % (case, err.max().item())
 
 
-# ---- csrc/hr_tail.hip: fused transposed conv + output conv + bicubic skip -----------------------------------------------
-@pytest.mark.parametrize("shape", [(1, 14, 30), (2, 22, 36), (1, 64, 64), (1, 540, 960)])
-def test_hr_tail_fused_matches_the_three_kernel_path(shape):
-    """t1 -> relu(conv2d_transpose) -> conv 64->3 -> + bicubic_four(LR) -> *2-1 (lib/frvsr.py:73-87) and the recurrent state
-    (main.py:207): the fused kernel against the oracle (the staged HR tensor is rounded to bf16 exactly where the unfused path
-    stores it as bf16)."""
-    N, h2, w2 = shape
-    h, w = h2 // 2, w2 // 2
-    t1 = rnd(N, h2, w2, 64, seed=1).bfloat16()
-    wt = rnd(3, 3, 64, 64, seed=2, scale=0.06).bfloat16()                # TF conv2d_transpose layout [kh,kw,Cout,Cin]
-    bt = rnd(64, seed=3, scale=0.1)
-    wo = rnd(3, 3, 64, 3, seed=4, scale=0.06).bfloat16()                 # HWIO
-    bo = rnd(3, seed=5, scale=0.1)
-    gen_in = rnd(N, h, w, 56, seed=6).bfloat16()
-    t2 = torch.relu(O.conv2_tran(t1.float(), wt.float(), bt, 2)).bfloat16().float()
-    c = O.conv2(t2, wo.float(), bo, 1)
-    ref = O.preprocess(c + O.bicubic_four(gen_in[..., :3].float()))
-    w_tran = wt.reshape(9, 64, 64).contiguous().to(DEV)                   # [tap][Cout][Cin]
-    w_out = wo.permute(0, 1, 3, 2).reshape(9, 3, 64).contiguous().to(DEV)  # [tap][Cout][Cin]
-    out = torch.full((N, 2 * h2, 2 * w2, 3), 7.0, device=DEV)
-    state = torch.full_like(out, 7.0)
-    K.hr_tail_forward(t1.to(DEV), w_tran, bt.to(DEV), w_out, bo.to(DEV), gen_in.to(DEV), out, state)
-    err = (out.cpu() - ref).abs()
-    assert (err <= 2e-3 * ref.abs() + 2e-3).all(), "hr_tail %s: max err %g" % (shape, err.max().item())
-    assert torch.allclose(state.cpu(), out.cpu() * 0.5 + 0.5, atol=1e-6)
-    state2 = torch.full_like(out, 7.0)
-    K.hr_tail_forward(t1.to(DEV), w_tran, bt.to(DEV), w_out, bo.to(DEV), gen_in.to(DEV), None, state2)
-    assert torch.equal(state2.cpu(), state.cpu())
-
-
 # ---- csrc/conv_wgrad_tr.hip: weight gradients with transpose reads -------------------------------------------------------
 @pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") == "0", reason="TG_WGRAD_TR=0 switches the transpose-read kernel off")
 @pytest.mark.parametrize("case", [(1, 2, 8), (3, 5, 32), (32, 76, 32)])
@@ -1361,7 +1331,7 @@ def test_deconv_latency_kernel_matches_oracle_and_the_generic_kernel(shape):
     close(out, gen.float(), 1e-2, "deconv latency kernel vs transposed-mode engine %s" % (shape,))
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 64), (1, 14, 30), (2, 22, 36), (1, 4, 8), (3, 6, 10)])
+@pytest.mark.parametrize("shape", [(4, 64, 64), (1, 14, 30), (2, 22, 36), (1, 4, 8), (3, 6, 10), (1, 540, 960)])
 def test_hr_tail_training_kernel_matches_oracle(shape):
     """t1 -> t2 = relu(conv2d_transpose) (stored) -> conv 64 -> 3 -> + bicubic_four(LR) -> *2-1 (lib/frvsr.py:73-87) in one
     launch for the training recurrence: t2 to bf16 rounding, the frame as the inference kernel is held (the staged t2 is rounded
@@ -1406,9 +1376,6 @@ def test_hr_tail_outputs_are_optional_and_consistent(shape):
     st2 = torch.full_like(ref, 7.0)
     K.hr_tail_train(t1, f2, bt, w3, bo, gen_in, None, None, st2)
     assert torch.equal(st2, st)
-    whole = torch.empty_like(ref)
-    K.hr_tail_forward(t1, w2t, bt, w3, bo, gen_in, whole, None)                # the round-3 throughput kernel, same operands
-    assert ((fr - whole).abs() <= 2e-3 * whole.abs() + 2e-3).all()
 
 
 @pytest.mark.parametrize("mask", [False, True])

@@ -188,10 +188,11 @@ def test_target_lookahead_equals_in_step_target_features():
     b = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True)
     assert b.lookahead
     ran = []
+    dev = [tuple(t.to(DEV) for t in bt) for bt in batches]              # the announcement is checked by tensor IDENTITY
     for i in range(3):
-        x, y = (t.to(DEV) for t in batches[i])
+        x, y = dev[i]
         a.step(x, y)
-        announce = batches[i + 1][1].to(DEV) if i != 1 else None        # step 1 announces nothing: step 2 computes in-step
+        announce = dev[i + 1][1] if i != 1 else None                    # step 1 announces nothing: step 2 computes in-step
         if i == 1:
             b.eval_losses(vx.to(DEV), vy.to(DEV))                       # validation between two training steps
         b.step(x, y, next_targets=announce)
@@ -202,6 +203,15 @@ def test_target_lookahead_equals_in_step_target_features():
         for k in ("vgg_loss_2", "vgg_loss_5", "l2_content_loss", "t_discrim_loss"):
             assert abs(la[k] - lb[k]) <= 1e-4 * max(1.0, abs(la[k])), (i, k, la[k], lb[k])
     assert ran == [(True,), (False,), (True,)]
+    # the promise is checked, not trusted: step 2 announced dev[3][1]; a call that passes ANOTHER tensor (here an equal
+    # copy) must compute its target features in-step instead of using the stored ones; the announced object itself may use them
+    x, y = dev[3]
+    b.step(x, y.clone())
+    assert b.used_stored_targets is False
+    b.step(x, y, next_targets=dev[0][1])
+    b.step(*dev[0])
+    assert b.used_stored_targets is True
+    torch.cuda.synchronize()
     names = [s["name"] for s in b._segs]
     assert "vggt" in names and "vggt_pre" in names and "vggt_next" in names
 

@@ -27,7 +27,7 @@ t = timeit(g.replay, 50, 5)
 K.prof_collect(); K.prof_enable(True); fn.backward(saved, dflow); torch.cuda.synchronize(); K.prof_enable(False)
 ents = K.prof_collect()
 print("FNet backward N=%d multi=%s target=%s: %.1f us per pass; instrumented launches: %s" % (
-    N, os.environ.get("TG_FNET_WGRAD_MULTI", "1"), "-", t,
+    N, "1", "-", t,
     ", ".join("%s x%d %.0f us" % (e["name"], e["calls"], e["total_us"]) for e in ents[:6])))
 for e in ents:
     if e["name"].startswith("conv_wgrad"):

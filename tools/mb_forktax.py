@@ -115,7 +115,7 @@ def two_graphs_prio():
 
 
 tP = timeit(two_graphs_prio)
-print("TG_C3_PRIO=%s  D' two graphs, chain on a high-priority stream %.3f ms" % (os.environ.get("TG_C3_PRIO", "0"), tP))
+print("D' two graphs, chain on a high-priority stream %.3f ms" % tP)
 print("A chain(%d) %.3f ms (%.2f us/node) | B +1 forked tiny kernel %.3f ms (%.2f us/node) | E big(%d) %.3f ms | "
       "C forked graph %.3f ms | D two graphs %.3f ms | sum %.3f max %.3f" %
       (N, tA, tA * 1e3 / N, tB, tB * 1e3 / N, M, tE, tC, tD, tA + tE, max(tA, tE)))

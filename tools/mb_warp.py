@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """The fused warp kernels alone (graph-chained launches): forward at the 1080p inference shape and the training shape,
-backward (scatter) at the training shape with smooth / FNet-like / random flows.  TG_WARP_BWD_MERGE=0 switches the
-neighbour hand-over of the scatter off."""
+backward (scatter, with the neighbour hand-over) at the training shape with smooth / FNet-like / random flows."""
 import os
 import sys
 
@@ -31,4 +30,4 @@ for kind, flow in (("smooth", torch.full((B, h, w, 2), 0.31, device=DEV) + 0.02 
     d_pre = torch.zeros(B, 4 * h, 4 * w, 3, device=DEV)
     d_flow = torch.zeros(B, h, w, 2, device=DEV)
     t = graph_timeit(lambda: K.warp_s2d_backward(g, pre, flow, d_pre, d_flow, 0.5), chain=20)
-    print("warp_s2d_bwd [%d,%d,%d] %-9s merge=%s %7.2f us" % (B, h, w, kind, os.environ.get("TG_WARP_BWD_MERGE", "1"), t), flush=True)
+    print("warp_s2d_bwd [%d,%d,%d] %-9s merge=%s %7.2f us" % (B, h, w, kind, "1", t), flush=True)

@@ -29,4 +29,4 @@ for N, H, W in ((1, 270, 480), (76, 128, 128), (20, 128, 128)):
         td = graph_timeit(lambda: K.conv3x3_c64_frag(x, wfr, b, r, out, ACT_NONE))
     fl = 2.0 * N * H * W * 64 * 64 * 9
     print("[%s] conv 64->64 [%d,%d,%d]: relu %6.1f us (%4.0f TFLOP/s)   +residual %6.1f us | fragment-order weights (per CU %s): %6.1f us  +residual %6.1f us"
-          % (tag, N, H, W, ta, fl / ta * 1e-6, tb, os.environ.get("TG_C3WS_FRAG_PER_CU", "2"), tc, td), flush=True)
+          % (tag, N, H, W, ta, fl / ta * 1e-6, tb, "2", tc, td), flush=True)
