@@ -138,6 +138,34 @@ def time_steps(eng, steps, warmup, fence):
     return time.perf_counter() - t0
 
 
+def exchange_timeline(eng, steps=6):
+    """N > 1: where the gradient exchange sits in a replayed step, from device wall-clock stamps at the segment boundaries (the
+    program is re-captured with stamp nodes AFTER the timed region; every rank runs the same `steps` steps -- they contain the
+    collectives).  Per exchange segment (captured RCCL: ar_d / ar_g / ar_f on the communication stream; eager-split: `exchange`
+    on the main stream): start, duration, and how much of it ran under the compute segments it is meant to hide behind
+    (ar_d under the BPTT `bwd_b`, ar_g and ar_f under FNet's backward pass `fnet_bwd` / the weight gradients `wgrad`), so that
+    the first 8-GPU run explains itself.  A failure is reported in place of the table."""
+    try:
+        kw = {"next_targets": True} if getattr(eng, "lookahead", False) else {}
+        eng.enable_seg_stamps()
+        for _ in range(steps):
+            eng.step(**kw)
+        torch.cuda.synchronize()
+        rows = eng.read_seg_stamps()
+        comp = {n: r for n, r in rows.items() if r[2] != "C" and n != "exchange"}
+        out = {"step_ms": round(max(e for _, e, _ in rows.values()), 4), "segments": {}}
+        for n, (s, e, k) in sorted(rows.items(), key=lambda kv: kv[1][0]):
+            if k == "C" or n == "exchange":
+                under = {m: round(max(0.0, min(e, ce) - max(s, cs)), 4) for m, (cs, ce, _) in comp.items()
+                         if m in ("bwd_b", "fnet_bwd", "wgrad", "bwd", "update") and min(e, ce) > max(s, cs)}
+                out["segments"][n] = {"stream": k, "start_ms": round(s, 4), "ms": round(e - s, 4), "under_ms": under,
+                                      "exposed_ms": round(max(0.0, (e - s) - sum(under.values())), 4) if under else round(e - s, 4)}
+        out["compute"] = {n: [round(s, 3), round(e, 3), k] for n, (s, e, k) in sorted(comp.items(), key=lambda kv: kv[1][0])}
+        return out
+    except Exception as e:                                       # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
 def err_stats(a, b):
     """Error of `a` against `b`: max-norm relative and the per-pixel criterion of the parity tests."""
     a, b = a.float(), b.float()
@@ -219,6 +247,46 @@ def profile_inference(device, h=270, w=480, frames=6):
     return K.prof_collect(), frames
 
 
+FAMILIES = (                  # kernel-name prefix -> family (what the launch is FOR in the step), first match wins
+    ("resblock_lat", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
+    ("hr_fwd_lat", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
+    ("hr_bwd_lat", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
+    ("deconv_bwd_lat", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
+    ("warp_s2d", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
+    ("conv3x3_tile<bf16,bf16,4,16", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
+    ("conv3x3_dma_pack", "VGG-19 conv5 / FNet inner levels (packed 8x8 / 4x4 images)"),
+    ("conv3x3_dma", "VGG-19 wide layers conv2_2..conv4_4 + FNet wide levels (LDS-DMA conv)"),
+    ("conv3x3_ws", "64-channel throughput convs (VGG conv1_2 / conv2_1, D input conv, FNet 64-ch levels)"),
+    ("conv3x3_c8", "8-channel input convs (VGG conv1_1, padded 3-channel tensors)"),
+    ("conv4x4s2", "discriminator stride-2 4x4 convs (forward / input gradient)"),
+    ("conv_igemm", "generic implicit-GEMM convs (dense layer, leftovers)"),
+    ("conv_wgrad", "weight gradients"),
+    ("conv3x3_tile", "other 3x3 tile-kernel launches"),
+)
+
+
+def kernel_families(ents, nstep, dtype):
+    """Time share and achieved fraction of the MFMA peak per kernel FAMILY of the profiled step (the chain node's
+    0.05 must sit beside the dominant kernel's 0.3)."""
+    tot = sum(e["total_us"] for e in ents)
+    fam = {}
+    for e in ents:
+        name = next((f for p, f in FAMILIES if e["name"].startswith(p)), "other instrumented launches")
+        a = fam.setdefault(name, {"us": 0.0, "flops": 0.0, "launches": 0})
+        a["us"] += e["total_us"]
+        a["flops"] += e["flops"]
+        a["launches"] += e["calls"]
+    out = []
+    for name, a in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
+        row = {"family": name, "launches_per_step": round(a["launches"] / nstep, 1), "us_per_step": round(a["us"] / nstep, 1),
+               "share": round(a["us"] / tot, 4)}
+        if a["flops"] > 0:
+            row["TFLOPs"] = round(a["flops"] / a["us"] / 1e6, 1)
+            row["frac"] = round(a["flops"] / a["us"] / 1e6 / PEAK_TFLOPS[dtype], 4)
+        out.append(row)
+    return out
+
+
 def build_roofline(config, dtype, device, with_inference):
     pmc = load_pmc()
     ents, nstep = profile_training(config, dtype, device)
@@ -242,6 +310,7 @@ def build_roofline(config, dtype, device, with_inference):
             h["workload"] = "configs[4] inference 480x270 -> 1920x1080, the fused warp + space-to-depth kernel"
             r["hbm_kernel"] = h
         r["inference_top_kernels"] = [roofline_entry(e, nfr, "bf16", pmc) for e in ients[:5]]
+    r["families"] = kernel_families(ents, nstep, dtype)          # (last: the driver keeps the END of the line)
     return r
 
 
@@ -455,6 +524,38 @@ def sub_records(device, fence):
     return out
 
 
+def parity_summary(sub):
+    """What the timed bf16 mode is worth against the fp32 parity mode, in one short object: first-step gradient error per optimiser
+    scope (relative L2), HR frames, and the loss-trajectory deviations beside the perturbed-fp32 control (`vs_control` ~ 1: the
+    bf16 mode moves the trajectory as far as a one-time 2^-9 perturbation of fp32 does)."""
+    out = {}
+    bv = sub.get("bf16_vs_fp32", {}) if isinstance(sub, dict) else {}
+    g = bv.get("C3_tecogan_gradients", {})
+    out["C3_first_step_grad_rel_l2"] = {k: v.get("rel_l2") for k, v in g.items()} if isinstance(g, dict) else None
+    fr = bv.get("C3_tecogan_gen_outputs", {})
+    out["C3_frames_max_rel"] = fr.get("max_rel_to_max") if isinstance(fr, dict) else None
+    tr = bv.get("C3_tecogan_loss_trajectory", {})
+    if isinstance(tr, dict) and "error" not in tr:
+        out["trajectory_steps"] = tr.get("steps")
+        for n in ("content_loss", "warp_loss", "t_discrim_loss"):
+            c = tr.get(n)
+            if isinstance(c, dict):
+                out[n] = {"max_rel_dev": c["max_rel_dev"], "control": c["control_max_rel_dev"], "vs_control": c["vs_control"],
+                          "tail_mean_rel_dev": c["tail_mean_rel_dev"], "control_tail": c["control_tail_mean_rel_dev"]}
+    elif isinstance(tr, dict):
+        out["trajectory_error"] = tr.get("error")
+    out["offline_3seed_table"] = "profiles/r05_bf16_trajectory.txt (tools/bf16_trajectory.py: 2000 steps x 8 pan-clip batches x 3 seeds)"
+    return out
+
+
+def sub_summary(sub):
+    g = lambda k, f: (sub.get(k) or {}).get(f) if isinstance(sub.get(k), dict) else None     # noqa: E731
+    mp = sub.get("main_py_image_per_sec") or {}
+    return {"frvsr_ms_per_step": g("frvsr", "ms_per_step"), "fp32_parity_mode_ms_per_step": g("fp32_parity_mode", "ms_per_step"),
+            "inference_1080p_fps": g("inference_fps", "value"), "inference_ms_per_frame": g("inference_fps", "ms_per_frame"),
+            "main_py_steady_image_per_sec": {k: v.get("steady_image_per_sec") for k, v in mp.items() if isinstance(v, dict)}}
+
+
 def cpu_baseline(config, budget_s):
     """The CPU oracle (torch restatement of the reference TF1 path; the reference itself needs TF1) timed on this box's
     host cores on the FULL timed workload (configs[2]: B=4 x 19 frames; configs[1]: B=4 x 10 frames), same seeded batch and
@@ -581,6 +682,7 @@ def main():
         idle.append((time.perf_counter() - t0) * 1e3)
     eng.lazy_side = lazy
     torch.cuda.synchronize()
+    xtl = exchange_timeline(eng) if world > 1 else None          # (after the timed region; all ranks: the steps hold collectives)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -601,6 +703,7 @@ def main():
             cfg["exchange"] = eng.exchange_mode if capture_failure is None else \
                 "eager-split (FALLBACK: the captured RCCL exchange failed: %s)" % capture_failure
             cfg["exchange_segments"] = list(eng.exchange_segments)
+            cfg["exchange_timeline"] = xtl
         line = {"metric": "4x SR train frames/sec (G+D step)" if a.config == "tecogan" else "4x SR train frames/sec (FRVSR step, no D)",
                 "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -620,6 +723,13 @@ def main():
             line["roofline"] = build_roofline(a.config, a.dtype, device, with_inference=(world == 1 and not a.no_sub))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_seconds)
+        if "sub" in line:
+            # compact digests of the sub-records: in `config` (the driver's parsed record keeps that object) and once more as the
+            # LAST keys of the line (the driver's log keeps the end of stdout) -- VERDICT r4 item 5
+            ps = parity_summary(line["sub"])
+            line["config"]["parity_summary"] = ps
+            line["parity_summary"] = ps
+            line["sub_summary"] = sub_summary(line["sub"])
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

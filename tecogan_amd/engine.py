@@ -14,6 +14,7 @@ from collections import OrderedDict
 import torch
 
 from . import kernels as K
+from . import promise
 from .nets import FNET_CPAD, GEN_CPAD, VGG_CPAD, VGG_TAPS, Discriminator, FNet, Generator, VGG19
 from .parallel import ExchangeMixin
 from .params import (DIS_BLOCKS, ParamStore, discriminator_spec, fnet_spec, generator_spec, init_values, pad8,
@@ -162,18 +163,17 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
     def step(self, r_inputs=None, r_targets=None, next_targets=None):
         """One training step.  next_targets (optional, [B,T0,4h,4w,3]): the targets of the batch the NEXT call will train on
         -- their VGG features are computed during this step's backward phase (target lookahead, see __init__); pass the
-        very TENSOR OBJECT the next call passes as r_targets, unmodified (next_targets=True: the resident batch stays, as in
-        bench.py); a next call with any other tensor computes its target features in-step."""
+        very tensor (or a view of the same memory) the next call passes as r_targets, unmodified (next_targets=True: the
+        resident batch stays, as in bench.py); a next call with any other tensor computes its target features in-step."""
         ready = self._next_ready
         if r_inputs is not None:
             # The previous call announced a batch and its target features are stored.  They are used only if THIS call's
-            # r_targets is provably the announced tensor: the same object, not modified in place since (torch's version
-            # counter) -- no device sync, no silent substitution of the caller's targets (ADVICE r4).  Anything else (a skipped
+            # r_targets is provably the announced tensor: the same memory, not modified in place since (tecogan_amd/promise.py)
+            # -- no device sync, no silent substitution of the caller's targets (ADVICE r4).  Anything else (a skipped
             # or reshuffled batch, a resume, a fresh `.cuda()` copy of equal values) falls back to the in-step target pass.
-            ann = self._announced
-            kept = ready and ann is not None and r_targets is ann[0] and r_targets._version == ann[1]
+            is_kept = ready and promise.kept(self._announced, r_targets)
             self.set_batch(r_inputs, r_targets)                  # (clears _next_ready)
-            self._next_ready = kept
+            self._next_ready = is_kept
         elif ready and self._announced is not None:
             self._next_ready = False                             # a resident-batch step after a tensor announcement: not that batch
         self._have_next = self.lookahead and next_targets is not None
@@ -183,7 +183,7 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
                 self.in_hr_next.copy_(self.in_hr, non_blocking=True)
             else:
                 self.in_hr_next.copy_(next_targets, non_blocking=True)
-                self._announced = (next_targets, next_targets._version)
+                self._announced = promise.announce(next_targets)
         self.host_step += 1
         self.used_stored_targets = bool(self._next_ready)      # (observable for tests / logs: this step starts from looked-ahead features)
         if not self.use_graph:

@@ -16,14 +16,15 @@ state), and the reference's loop holds the whole clip before it starts (lib/data
 therefore runs FNet for the NEXT frame on a second HIP stream beside this frame's generator (forked after the warp kernel, joined
 at the end of the step, both inside the one captured graph): the 14 small FNet convs (0.22 of a 1.0 ms 1080p frame,
 profiles/r03z_infer1080p_bf16_kernel_stats.txt) leave the frame's critical path.  The announced frame is a promise: the next call
-must pass that very tensor object, unmodified (checked by identity + torch's version counter: no sync; any other tensor makes
-the step compute its own flow first, as a call without `next_frame` does).
+must pass that very memory, unmodified (checked by tecogan_amd/promise.py: data pointer, layout and torch's version counter, no
+sync; any other tensor makes the step compute its own flow first, as a call without `next_frame` does).
 """
 from collections import OrderedDict
 
 import torch
 
 from . import kernels as K
+from . import promise
 from .nets import FNET_CPAD, GEN_CPAD, FNet, Generator
 from .params import ParamStore, fnet_spec, generator_spec, init_values
 
@@ -88,8 +89,7 @@ class InferenceEngine:
         if frame is not None:
             # flow_next belongs to this frame only if it IS the announced tensor (same object, not written since): otherwise the
             # stored flow is dropped and the step computes its own (a caller that skips or reorders frames stays correct)
-            ann = self._announced
-            if self._have_flow and not (ann is not None and frame is ann[0] and frame._version == ann[1]):
+            if self._have_flow and not promise.kept(self._announced, frame):
                 self._have_flow = False
             self.frame.copy_(frame, non_blocking=True)
         elif self._have_flow:
@@ -98,7 +98,7 @@ class InferenceEngine:
         self._announced = None
         if ahead:
             self.frame_next.copy_(next_frame, non_blocking=True)
-            self._announced = (next_frame, next_frame._version)
+            self._announced = promise.announce(next_frame)
         key = (self._have_flow, ahead)
         if not self.use_graph:
             self._program(*key)

@@ -115,6 +115,25 @@ class SegmentRunner:
         i = self.seg_stamp_names.setdefault(name, len(self.seg_stamp_names))
         K.prof_stamp(self.seg_stamps[2 * i + end:2 * i + end + 1])
 
+    def enable_seg_stamps(self):
+        """Switch the boundary stamps on for an engine that was built without TG_SEG_STAMPS: the program is re-captured with one
+        stamp node at each segment's start and end (bench.py --gpus N reads the exchange segments' timing this way after its
+        timed region; the timed graphs themselves carry no stamps)."""
+        if self.seg_stamps is None:
+            self.seg_stamps = torch.zeros(128, dtype=torch.int64, device=self.dev)
+            self.seg_stamp_names = {}
+            self._segs = None                   # next step(): warm-up + capture again, now with stamps
+
+    def read_seg_stamps(self):
+        """{segment: (start_ms, end_ms, stream key)} of the last step, relative to the earliest start (100 MHz device clock)."""
+        t = self.seg_stamps.cpu().tolist()
+        skey = {s["name"]: s["skey"] for s in (self._segs or [])}
+        rows = {n: (t[2 * i], t[2 * i + 1]) for n, i in self.seg_stamp_names.items() if t[2 * i] and t[2 * i + 1]}
+        if not rows:
+            return {}
+        t0 = min(s for s, _ in rows.values())
+        return {n: ((s - t0) / 1e5, (e - t0) / 1e5, skey.get(n, "M")) for n, (s, e) in rows.items()}
+
     def _seg_call(self, name, skey, after, fn):
         """A segment that cannot be captured (a gloo all-reduce): `fn` runs eagerly on the segment's stream every step."""
         if self._mode != "capture":
@@ -122,7 +141,13 @@ class SegmentRunner:
                 fn()
             return
         deps = [d for d in after if d in self._done and self._done[d][1] != skey]
-        seg = dict(name=name, skey=skey, deps=deps, graph=None, fn=fn, event=torch.cuda.Event())
+
+        def stamped():                          # (the eager segment carries the same boundary stamps as a captured one)
+            self._stamp(name, 0)
+            fn()
+            self._stamp(name, 1)
+        seg = dict(name=name, skey=skey, deps=deps, graph=None, fn=stamped if self.seg_stamps is not None else fn,
+                   event=torch.cuda.Event())
         self._segs.append(seg)
         self._done[name] = (seg["event"], skey)
 

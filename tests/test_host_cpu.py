@@ -579,3 +579,22 @@ def test_wgrad_tr_lds_swizzle_is_consistent_and_conflict_free():
                         for e in range(4):
                             assert ldsy[a + 2 * e] == (yy * 32 + lp + half, co0 + 16 * j + lc + e)
                     assert group_conflicts(addrs) == 1
+
+
+def test_lookahead_promise_is_checked_by_memory_identity_and_version():
+    """tecogan_amd/promise.py: an announced next input counts as kept only for the same memory (any view of it),
+    unmodified since the announcement; equal values elsewhere, an in-place write, or None do not count."""
+    import torch
+
+    from tecogan_amd import promise
+    seq = torch.rand(8, 1, 4, 4, 3)
+    a = promise.announce(seq[1])
+    assert promise.kept(a, seq[1]) and promise.kept(a, seq[1:2][0])           # new view objects of the announced memory
+    assert not promise.kept(a, seq[2]) and not promise.kept(a, seq[1].clone()) and not promise.kept(a, None)
+    assert not promise.kept(None, seq[1])
+    assert not promise.kept(a, seq[1, :, :2])                                  # another shape
+    seq[1].mul_(1.0)                                                           # in-place write (values equal): version moved
+    assert not promise.kept(a, seq[1])
+    b = promise.announce(seq[3])
+    seq[5].zero_()                                                             # views share the storage's counter: conservative
+    assert not promise.kept(b, seq[3])

@@ -293,16 +293,36 @@ def check_full_config(F, gan, tag):
     if S0.vgg is not None:
         S32.vgg = type(S0.vgg)((k, v.float()) for k, v in S0.vgg.items())
     x32, y32 = make_batch(F.batch_size, F.RNN_N, F.crop_size)
+    P_init = type(S32.P)((k, v.clone()) for k, v in S32.P.items())     # (train_step applies Adam to S32.P in place)
     R32 = OT.train_step(S32, x32, y32)
     FACTOR, L2_FLOOR, MX_FLOOR = 1.5, 1e-3, 2e-3
+    # The max-norm of a gradient tensor is an extreme-value statistic of ONE summation order (the fp32 atomics add in a
+    # run-dependent order): the GAN configuration is therefore stepped by THREE fresh engines from the same weights and the
+    # max-norm line is held by the per-tensor MEDIAN of the three (round 4 had widened the allowance from 2 to 4
+    # outlier tensors after one run showed three; the bound is back at 2, the statistic is robust instead).  The L2 bound is
+    # checked on every run.
+    runs = [{n: eng.ps.gview(n).detach().cpu().double() for n in R["grads"]}]
+    for _ in range(2 if gan else 0):
+        e2 = TrainEngine(F, DEV, gan=gan, act_dtype=torch.float32, seed=7, use_graph=False)
+        e2.ps.load(P_init)
+        if e2.use_vgg:
+            e2.vps.load(S32.vgg)
+        e2.step(x32.to(DEV), y32.to(DEV))
+        torch.cuda.synchronize()
+        runs.append({n: e2.ps.gview(n).detach().cpu().double() for n in R["grads"]})
+        del e2
+        torch.cuda.empty_cache()
     stats, mask_flips, table = [], [], []
     for name, g in R["grads"].items():
-        mine = eng.ps.gview(name).detach().cpu().double()
+        mine = runs[0][name]
         ref = g.detach().double()
         o32 = R32["grads"][name].detach().double()
         nrm = ref.norm().clamp_min(1e-30)
         l2, l2_o = ((mine - ref).norm() / nrm).item(), ((o32 - ref).norm() / nrm).item()
-        mx, mx_o = max_rel_err(mine, ref), max_rel_err(o32, ref)
+        for other in runs[1:]:
+            l2 = max(l2, ((other[name] - ref).norm() / nrm).item())
+        mxs = sorted(max_rel_err(r[name], ref) for r in runs)
+        mx, mx_o = mxs[len(mxs) // 2], max_rel_err(o32, ref)
         table.append((l2 / max(L2_FLOOR, FACTOR * l2_o), name, l2, l2_o, mx, mx_o))
         assert l2 <= max(L2_FLOOR, FACTOR * l2_o), "%s gradient %s: relative L2 error %.3g vs the fp64 oracle, fp32 oracle's own %.3g" % (
             tag, name, l2, l2_o)
@@ -317,12 +337,13 @@ def check_full_config(F, gan, tag):
     print("\n[%s] closest to the derived L2 bound (ratio, tensor, L2 hip, L2 fp32-oracle, max hip, max fp32-oracle):" % tag)
     for row in table[:4]:
         print("    %.2f %s %.2e %.2e %.2e %.2e" % row)
-    # The MAX-norm is an extreme-value statistic of one summation order against another (fp32 atomics in a run-dependent order
-    # here, a fixed but different order in the fp32 oracle): tensors may leave the 1.5x line, but only discriminator tensors
-    # (LeakyReLU / batch-norm backward behind 1e5-pixel sums), only a few of them, and never beyond 3x what the fp32 oracle itself
-    # shows on that tensor.  Observed over the rounds' runs: 0-2 tensors (rounds 2-3), three in round 4's validation run at
-    # 1.8x / 1.7x / 1.55x of the fp32 oracle's own max-norm error (9.3e-3, 9.4e-3, 4.8e-3; profiles/r04z_pytest_gpu.log).
-    assert len(mask_flips) <= 4 and all(n.startswith("tdiscriminator") and mx <= max(MX_FLOOR, 3.0 * mx_o) for n, mx, mx_o in mask_flips), \
+    # The MAX-norm compares one summation order with another (fp32 atomics in a run-dependent order here, a fixed but different
+    # order in the fp32 oracle): by the median of three runs at most TWO tensors may leave the 1.5x line (round 3's bound), only
+    # discriminator tensors (LeakyReLU / batch-norm backward behind 1e5-pixel sums: a mask flip the fp32 oracle may or may not
+    # share), and never beyond 3x what the fp32 oracle itself shows on that tensor.  Single runs showed 0-2 such tensors in rounds
+    # 2-3 and three in one run of round 4 (1.8x / 1.7x / 1.55x; profiles/r04z_pytest_gpu.log).
+    print("[%s] max-norm beyond the derived line (median of %d runs): %s" % (tag, len(runs), [(n.split("/")[-3:], "%.2e" % a, "%.2e" % b) for n, a, b in mask_flips]))
+    assert len(mask_flips) <= 2 and all(n.startswith("tdiscriminator") and mx <= max(MX_FLOOR, 3.0 * mx_o) for n, mx, mx_o in mask_flips), \
         "%s: max-norm beyond the derived bound on %s" % (tag, mask_flips)
     print("\n[%s] gen per-pixel err %.2e; %d gradient tensors vs the fp64 oracle: worst L2 %.2e (%d above 1e-3), worst max-norm "
           "%.2e, worst per-element (floor 2e-2) %.2e" %
@@ -393,6 +414,51 @@ def test_bf16_mode_error_at_baseline_config_C3():
             assert abs(lb[k] - v) <= 1e-2 * abs(v), (k, lb[k], v)
     assert e_scope["generator"] < 2e-2 and e_scope["fnet"] < 1e-1 and e_scope["tdiscriminator"] < 1.6e-1, e_scope
     assert e_last < 1e-2, e_last
+
+
+def test_bf16_latency_kernels_on_vs_off_at_baseline_config_C3():
+    """the TIMED code path under a tight test at the BASELINE size.  The fp32 parity tests above cannot run the
+    latency-regime kernels (csrc/resblock_lat.hip, hr_fwd_lat.hip, hr_bwd_lat.hip are bf16-only), so at configs[2] (B=4, 19
+    frames, num_resblock=16, D + VGG + ping-pong) the bf16 engine runs one step three times from identical damped weights:
+      A  all latency kernels ON (the timed configuration);
+      B  residual blocks ON, HR tails on the generic kernels;
+      C  everything on the generic tg_conv_forward launches -- the code the fp32 C3 parity test exercises (in fp32).
+    B vs C: the one-launch block is built to be BIT-identical to its two launches -> all 19 HR frames bit-equal, the recurrent
+    input-gradient buffer bit-equal or within scatter-atomics noise, gradients within fp32-atomics noise.
+    A vs C: the HR-tail kernels accumulate in another order -> frames to bf16 rounding (2e-3 of the frame range, relative L2
+    1e-3), every loss scalar within 0.5 %, gradients per optimiser scope within the decision-flip bounds stated below (a
+    1e-3 forward difference flips ReLU / LeakyReLU / max-pool decisions in VGG-19 and D: the mechanism of
+    test_bf16_mode_error_at_baseline_config_C3 at a tenth of its forward difference)."""
+    from tecogan_amd.params import damp_values
+    F = OT.default_flags()
+    x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
+    res = {}
+    for tag, blocks, tails in (("A", True, True), ("B", True, False), ("C", False, False)):
+        eng = TrainEngine(F, DEV, gan=True, act_dtype=torch.bfloat16, seed=7, use_graph=False)
+        eng.ps.load(damp_values(eng.ps.state_dict()))
+        eng.G.resblock_lat = blocks
+        eng.G.hr_fwd_lat = eng.G.hr_bwd_lat = tails
+        eng.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        assert eng.G._fused_blocks() is blocks
+        res[tag] = (eng.gen.clone(), eng.losses(), {sc: eng.ps.scope_slice(sc, eng.ps.grad).double().cpu() for sc in eng.ps.scope_range},
+                    eng.G.seq["g_in"].clone())
+        del eng
+        torch.cuda.empty_cache()
+    rl2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))     # noqa: E731
+    (ga, la, gra, gia), (gb, lb, grb, gib), (gc, lc, grc, gic) = res["A"], res["B"], res["C"]
+    assert torch.equal(gb, gc), "C3: HR frames differ between the one-launch and the two-launch residual blocks"
+    e_bc = {sc: rl2(grb[sc], grc[sc]) for sc in grc}
+    e_ac = {sc: rl2(gra[sc], grc[sc]) for sc in grc}
+    print("\n[C3 bf16 latency kernels] blocks only vs generic: frames bit-equal, gradients %s; all ON vs generic: frames max %.2e / L2 %.2e, "
+          "gradients %s" % ({k: "%.1e" % v for k, v in e_bc.items()}, rel_err(ga, gc), rl2(ga, gc), {k: "%.1e" % v for k, v in e_ac.items()}))
+    assert torch.equal(gib.view(torch.int16), gic.view(torch.int16)) or rel_err(gib, gic) < 2e-2
+    assert all(v < 2e-2 for v in e_bc.values()), e_bc
+    assert rel_err(ga, gc) < 2e-3 and rl2(ga, gc) < 1e-3, (rel_err(ga, gc), rl2(ga, gc))
+    for k, v in lc.items():
+        if k in la and abs(v) > 1e-6 and k not in ("t_balance", "t_balance_now"):
+            assert abs(la[k] - v) <= 5e-3 * abs(v), (k, la[k], v)
+    assert e_ac["generator"] < 2e-2 and e_ac["fnet"] < 6e-2 and e_ac["tdiscriminator"] < 1e-1, e_ac
 
 
 def test_tecogan_temporal_only_discriminator_Dt_mergeDs_false():
@@ -511,6 +577,75 @@ def test_captured_exchange_segments_carry_nodes_standin_world2():
         assert d <= 1e-3 * w.abs().max().item() + 6.0 * F.learning_rate, (name, d)
 
 
+def test_host_jitter_before_exchange_segments_standin_world8():
+    """VERDICT r4 item 7 / Weak 7: the exchange segments are launched JUST IN TIME -- the host waits for their dependencies and
+    only then enqueues them -- so on an 8-GPU node every collective sits behind a host-side wait of its rank, and per-rank host
+    jitter lands in front of every all-reduce.  The untested part of the design, made to bite on one GPU: the 8-rank program
+    (TrainEngine(standin_world=8): communication stream, captured ar_d / ar_g / ar_f segments, 1/8 folded into Adam) at the
+    TIMED size (configs[2], bf16) with a random 0-200 us host sleep injected before every communication-segment launch
+    (SegmentRunner.launch_jitter).  ar_d is issued after D's own-gradient passes and has the whole BPTT (2.3 ms) to hide
+    under, ar_g / ar_f FNet's backward pass: the step time must stay within 3 % (+20 us), the result unchanged."""
+    import random
+    import time
+    from tecogan_amd.params import damp_values
+    F = OT.default_flags()
+    x, y = (t.to(DEV) for t in make_batch(F.batch_size, F.RNN_N, F.crop_size))
+
+    def build():
+        e = TrainEngine(F, DEV, gan=True, act_dtype=torch.bfloat16, seed=7, use_graph=True, standin_world=8)
+        e.ps.load(damp_values(e.ps.state_dict()))
+        e.set_batch(x, y)
+        return e
+
+    def timed(e, steps=20, blocks=4):
+        best = 1e9
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                e.step(next_targets=True)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+        return best
+
+    a, b = build(), build()
+    for e in (a, b):
+        for _ in range(3):
+            e.step(next_targets=True)
+    torch.cuda.synchronize()
+    assert b.exchange_segments == ["ar_d", "ar_g", "ar_f"] and b.world == 8
+    # the RESULT first: one step with the maximal sleep before every exchange segment against one plain step, both engines in
+    # the same state (three steps in) -- equal to the noise of the fp32 atomics
+    b.launch_jitter = lambda name: 200e-6 if name.startswith("ar_") else 0.0
+    a.step(next_targets=True)
+    b.step(next_targets=True)
+    b.launch_jitter = None
+    torch.cuda.synchronize()
+    assert rel_err(b.gen, a.gen) < 5e-3, rel_err(b.gen, a.gen)
+    la, lb = a.losses(), b.losses()
+    for k in ("l2_content_loss", "l2_warp_loss", "t_discrim_loss", "vgg_loss_3"):
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(abs(la[k]), 1e-6), (k, la[k], lb[k])
+    assert rel_err(b.ps.grad, a.ps.grad) < 5e-2
+    t_plain = min(timed(a), timed(b))
+    rng, slept = random.Random(1), []
+
+    def jitter(name):
+        assert name.startswith("ar_") or name in ("vggt", "vggt_pre", "dreal", "vgg_0", "vgg_1", "vggt_next", "wgrad"), name
+        if not name.startswith("ar_"):
+            return 0.0
+        slept.append(rng.uniform(0.0, 200e-6))
+        return slept[-1]
+    b.launch_jitter = jitter
+    t_jit = timed(b)
+    b.launch_jitter = None
+    per_step = sum(slept) / max(len(slept), 1) * 3
+    print("\n[stand-in world 8, configs[2] bf16] step %.3f ms plain, %.3f ms with 0-200 us host jitter before each of the 3 exchange "
+          "segments (%.0f us of sleep per step)" % (t_plain, t_jit, per_step * 1e6))
+    assert len(slept) >= 3 * 80
+    assert t_jit <= 1.03 * t_plain + 0.02, (t_plain, t_jit)
+    assert all(v == v for v in b.losses().values())
+
+
 def test_validation_pass_issues_no_collective_and_leaves_training_state_untouched():
     """ADVICE r3 (main.py validation on rank 0, reference main.py:391-402): `eval_losses` runs the step's program without the
     update segment -- and, in the captured multi-rank program, without ANY exchange segment: an all-reduce issued by one rank
@@ -560,6 +695,11 @@ def test_bench_gpus_2_on_one_device_runs_two_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["global_batch"] == 8
     assert line["config"]["exchange"].startswith("eager-split") and line["config"]["allreduce_bytes_per_step"] > 0
+    # the N > 1 line explains its exchange: per-segment timing from device stamps
+    tl = line["config"]["exchange_timeline"]
+    assert "error" not in tl, tl
+    assert set(tl) >= {"step_ms", "segments", "compute"} and "exchange" in tl["segments"], tl
+    assert {"start_ms", "ms", "under_ms", "exposed_ms"} <= set(tl["segments"]["exchange"])
 
 
 def test_deterministic_parity_mode_is_bit_reproducible():
