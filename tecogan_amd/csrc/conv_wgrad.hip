@@ -352,22 +352,26 @@ extern "C" int tg_debug_wgrad_trace(unsigned long long* out) {
 // launches run at: the stage -> barrier -> fragment reads -> MFMA -> barrier chain is pure exposed latency, so the fix is
 // more pixels per trip through it (and 4*PF loads in flight across the MFMA block).  The host makes `chunk` a multiple of
 // 64*PF; slots past the end run on zeros (out-of-range lanes fetch nothing).
+// XCD-aware work mapping.  Workgroup b runs on XCD b % 8, each XCD has its own L2, and the KH*KW taps (and channel
+// tiles) of one pixel chunk all read the same X / Y rows.  With the natural (tap, tile, chunk) grid the taps of a
+// chunk were sprayed over all 8 XCDs, so every L2 pulled the whole of X and Y through the fabric (8x the traffic:
+// ~84 MB per launch at the generator shape, which is what bounded the kernel at ~20 us).  Bijective remap: XCD x owns a
+// contiguous range of work items, a work item = (chunk, tile, tap) with tap fastest.
+__device__ __forceinline__ int tg_xcd_work_item() {
+  const int nwg = gridDim.x, L = blockIdx.x;
+  const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+}
+
+// body of one work item `work` = (pixel chunk, channel tile, tap) of the layer described by p
 template <int PF>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
+__device__ __forceinline__ void wgrad_bf16_body(const WgradBP& p, const int work, [[maybe_unused]] const int nwg) {
   constexpr int ROWB = 128 * PF + 8;             // bytes per channel row: 64*PF pixels * 2 B + 8 pad
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
   unsigned char* Xt = wg_smem;                    // [64 channels][ROWB]
   unsigned char* Yt = wg_smem + 64 * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware work mapping.  Workgroup b runs on XCD b % 8, each XCD has its own L2, and the KH*KW taps (and channel
-  // tiles) of one pixel chunk all read the same X / Y rows.  With the natural (tap, tile, chunk) grid the taps of a
-  // chunk were sprayed over all 8 XCDs, so every L2 pulled the whole of X and Y through the fabric (8x the traffic:
-  // ~84 MB per launch at the generator shape, which is what bounded the kernel at ~20 us).  Bijective remap: XCD x owns a
-  // contiguous range of work items, a work item = (chunk, tile, tap) with tap fastest.
-  const int nwg = gridDim.x, L = blockIdx.x;
-  const int xcd = L & 7, slot = L >> 3, q8 = nwg >> 3, r8 = nwg & 7;
-  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
 #ifdef TG_WGRAD_TRACE
   const bool trace_on = work == (nwg / 2) && threadIdx.x == 0;
   int stamp = 3;
@@ -578,6 +582,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
 #endif
 }
 
+template <int PF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradBP p) {
+  wgrad_bf16_body<PF>(p, tg_xcd_work_item(), (int)gridDim.x);
+}
+
+// Several layers of DIFFERENT geometry in one launch (round 5: the discriminator's four stride-2 4x4 convs, reference
+// lib/Teco.py:35-39,52-66 under tf.gradients): a launch of this kernel costs ~30 us before its first and after its last useful
+// step whatever the layer's size (prologue, split-K atomics tail) -- the three small layers of D (1.6 - 3.2 GFLOP) cost as much
+// as the large one (12.9) -- so the layers go out together and the small ones fill the large one's tail.  A workgroup finds its
+// layer by scanning the work-prefix table (workgroup-uniform), then runs the single-layer body on that layer's descriptor.
+#define TG_WGRAD_BM_MAX 8
+struct WgradBM {
+  WgradBP g[TG_WGRAD_BM_MAX];
+  int wstart[TG_WGRAD_BM_MAX + 1];
+  int groups;
+};
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_multi_kernel(WgradBM P) {
+  const int work = tg_xcd_work_item();
+  int grp = 0;
+  for (int g1 = 1; g1 < P.groups; ++g1) grp = work >= P.wstart[g1] ? g1 : grp;
+  if (work >= P.wstart[P.groups]) return;
+  const WgradBP p = P.g[grp];
+  wgrad_bf16_body<2>(p, work - P.wstart[grp], (int)gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row kernel: stride-1 convolutions with 3 horizontal taps and SAME width (every 3x3 layer of generator_F, FNet and the
 // D input conv).  One workgroup accumulates the THREE kw taps of one kernel row kh for a 64x64 channel tile:
@@ -773,6 +802,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
 
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
                        float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip
+int tg_wgrad_bf16_multi_launch(const tg_conv_desc* const* ds, int n, const void* const* x, const int* ldxs, const void* const* y,
+                               const int* ldys, float* const* dw, float* const* dbias, hipStream_t st);   // below
+static bool tg_wgrad_bf16_setup(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
+                                WgradBP& p, int& base_blocks);                                             // below
 
 static bool tg_wgrad_row3_applies(const tg_conv_desc* d, int ldx, int ldy) {
   const bool enabled = true;
@@ -927,12 +960,72 @@ extern "C" int tg_conv_wgrad_multi(const tg_conv_desc* descs, int groups, const 
   } else {
     for (int g = 0; g < groups && g < TG_WGRAD_MAX_GROUPS; ++g) taken[g] = false;     // (groups > the table: `taken` has 40 entries)
   }
+  // the layers left over that the per-tap bf16 kernel takes (strided / non-3-wide kernels: the discriminator's 4x4 stride-2 convs)
+  // go out as ONE multi-layer launch of that kernel, largest layer first
+  if (x_dtype == TG_BF16 && y_dtype == TG_BF16 && groups <= TG_WGRAD_MAX_GROUPS) {
+    int idx[TG_WGRAD_BM_MAX], nb = 0;
+    for (int g = 0; g < groups && nb < TG_WGRAD_BM_MAX; ++g) {
+      if (taken[g]) continue;
+      const tg_conv_desc* d = descs + g;
+      const int a = ldx[g] > 0 ? ldx[g] : d->Cin, b = ldy[g] > 0 ? ldy[g] : d->Cout;
+      WgradBP tmp;
+      int bb;
+      // (3x3 s1 layers the row kernel takes alone stay with it: tg_conv_wgrad below)
+      if (d->mode == 0 && a >= d->Cin && b >= d->Cout && !tg_wgrad_row3_applies(d, a, b) &&
+          tg_wgrad_bf16_setup(d, x[g], a, y[g], b, dw[g], nullptr, tmp, bb))
+        idx[nb++] = g;
+    }
+    if (nb >= 2) {
+      for (int i = 1; i < nb; ++i)                      // insertion sort by work (pixels x taps x channel tiles), descending
+        for (int j = i; j > 0; --j) {
+          const tg_conv_desc *da = descs + idx[j - 1], *db = descs + idx[j];
+          const double wa = (double)da->N * da->Hout * da->Wout * da->KH * da->KW * ((da->Cin + 63) / 64) * ((da->Cout + 63) / 64);
+          const double wb = (double)db->N * db->Hout * db->Wout * db->KH * db->KW * ((db->Cin + 63) / 64) * ((db->Cout + 63) / 64);
+          if (wb > wa) { const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; } else break;
+        }
+      const tg_conv_desc* bd[TG_WGRAD_BM_MAX];
+      const void *bx[TG_WGRAD_BM_MAX], *by[TG_WGRAD_BM_MAX];
+      float *bw[TG_WGRAD_BM_MAX], *bb2[TG_WGRAD_BM_MAX];
+      int blx[TG_WGRAD_BM_MAX], bly[TG_WGRAD_BM_MAX];
+      bool any_bias = false;
+      for (int i = 0; i < nb; ++i) {
+        const int g = idx[i];
+        bd[i] = descs + g; bx[i] = x[g]; by[i] = y[g]; bw[i] = dw[g]; bb2[i] = dbias ? dbias[g] : nullptr;
+        blx[i] = ldx[g] > 0 ? ldx[g] : descs[g].Cin; bly[i] = ldy[g] > 0 ? ldy[g] : descs[g].Cout;
+        any_bias = any_bias || bb2[i] != nullptr;
+      }
+      if (tg_wgrad_bf16_multi_launch(bd, nb, bx, blx, by, bly, bw, any_bias ? bb2 : nullptr, static_cast<hipStream_t>(stream))) {
+        if (hipGetLastError() != hipSuccess) { tg_set_error("%s: launch failed", __func__); return TG_ELAUNCH; }
+        for (int i = 0; i < nb; ++i) taken[idx[i]] = true;
+      }
+    }
+  }
   for (int g = 0; g < groups; ++g) {
     if (g < TG_WGRAD_MAX_GROUPS && taken[g]) continue;
     const int rc = tg_conv_wgrad(descs + g, x[g], x_dtype, ldx[g], y[g], y_dtype, ldy[g], dw[g], dbias ? dbias[g] : nullptr, stream);
     if (rc != TG_OK) return rc;
   }
   return TG_OK;
+}
+
+// Parameters of the per-tap bf16 kernel for one layer; false if the layer does not fit it (then: the generic kernel).
+static bool tg_wgrad_bf16_setup(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
+                                WgradBP& p, int& base_blocks) {
+  if (ldx % 8 || ldy % 8 || (((uintptr_t)x | (uintptr_t)y) & 15)) return false;
+  p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;
+  p.N = d->N; p.Hx = d->Hin; p.Wx = d->Win; p.Cx = d->Cin; p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
+  p.M = d->N * d->Hout * d->Wout; p.ldx = ldx; p.ldy = ldy;
+  const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
+  if (M64 >= ((int64_t)1 << 30) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
+      M64 * ldy >= ((int64_t)1 << 30) || (d->Wout & 1))
+    return false;                       // 32-bit byte offsets out of range, or odd width (pixel pairs): generic kernel
+  p.xbytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * ldx * 2);
+  p.ybytes = (unsigned)(M64 * ldy * 2);
+  p.xtiles = (p.Cx + 63) / 64;
+  p.ytiles = (p.Cy + 63) / 64;
+  base_blocks = d->KH * d->KW * p.xtiles * p.ytiles;
+  return true;
 }
 
 // returns 1 if launched
@@ -944,37 +1037,59 @@ int tg_wgrad_bf16_try(const tg_conv_desc* d, const void* x, int x_dtype, int ldx
     return 1;                           // 64-channel 3x3 layers on images whose width is a multiple of 32 (conv_wgrad_tr.hip)
   if (tg_wgrad_row3_try(d, x, ldx, y, ldy, dw, dbias, st)) return 1;
   WgradBP p;
-  p.x = (const u16*)x; p.y = (const u16*)y; p.dw = dw; p.dbias = dbias;
-  p.N = d->N; p.Hx = d->Hin; p.Wx = d->Win; p.Cx = d->Cin; p.Hy = d->Hout; p.Wy = d->Wout; p.Cy = d->Cout;
-  p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l;
-  p.M = d->N * d->Hout * d->Wout; p.ldx = ldx; p.ldy = ldy;
+  int base_blocks = 0;
+  if (!tg_wgrad_bf16_setup(d, x, ldx, y, ldy, dw, dbias, p, base_blocks)) return 0;
   const int64_t M64 = (int64_t)d->N * d->Hout * d->Wout;
-  if (M64 >= ((int64_t)1 << 30) || (int64_t)d->N * d->Hin * d->Win * ldx >= ((int64_t)1 << 30) ||
-      M64 * ldy >= ((int64_t)1 << 30) || (d->Wout & 1))
-    return 0;                           // 32-bit byte offsets out of range, or odd width (pixel pairs): generic kernel
-  p.xbytes = (unsigned)((int64_t)d->N * d->Hin * d->Win * ldx * 2);
-  p.ybytes = (unsigned)(M64 * ldy * 2);
-  const int xtiles = (p.Cx + 63) / 64;
-  p.ytiles = (p.Cy + 63) / 64;
-  p.xtiles = xtiles;
-  const int base_blocks = d->KH * d->KW * xtiles * p.ytiles;
-  const int pf_env = 2;
-  const int pf = pf_env <= 1 ? 1 : (pf_env == 2 ? 2 : 4);        // 2: best or within noise at every swept shape
+  const int pf = 2;                                              // 2: best or within noise at every swept shape (round 2)
   const int quantum = 64 * pf;
   int ksplit = tg_wgrad_ksplit(p.M, (int64_t)base_blocks * 4096, base_blocks, quantum);
   p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
   ksplit = (p.M + p.chunk - 1) / p.chunk;
-  const dim3 grid((unsigned)(d->KH * d->KW * xtiles * p.ytiles * ksplit));   // 1-D: the kernel maps work XCD-aware
-  const unsigned lds = 2u * 64u * (128u * pf + 8u) + ((d->flags & TG_CONV_COEXIST) && pf <= 2 ? 24576u : 0u);  // see row3
-  static std::once_flag attr_once;                                    // PF = 4 needs 66.5 KB of dynamic LDS
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (128 * 4 + 8));
-  });
+  const dim3 grid((unsigned)(base_blocks * ksplit));   // 1-D: the kernel maps work XCD-aware
+  const unsigned lds = 2u * 64u * (128u * pf + 8u) + ((d->flags & TG_CONV_COEXIST) ? 24576u : 0u);  // see row3
   const double wfl = 2.0 * (double)M64 * d->KH * d->KW * (double)d->Cin * d->Cout;
   const double wby = (double)d->N * d->Hin * d->Win * ldx * 2.0 + (double)M64 * ldy * 2.0 + 4.0 * d->KH * d->KW * d->Cin * d->Cout;
-  if (pf == 1) TG_LAUNCH("conv_wgrad_bf16<1>", wfl, wby, conv_wgrad_bf16_kernel<1>, grid, dim3(256), lds, st, p);
-  else if (pf == 2) TG_LAUNCH("conv_wgrad_bf16<2>", wfl, wby, conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p);
-  else TG_LAUNCH("conv_wgrad_bf16<4>", wfl, wby, conv_wgrad_bf16_kernel<4>, grid, dim3(256), lds, st, p);
+  TG_LAUNCH("conv_wgrad_bf16<2>", wfl, wby, conv_wgrad_bf16_kernel<2>, grid, dim3(256), lds, st, p);
+  return 1;
+}
+
+// `n` layers (2 <= n <= TG_WGRAD_BM_MAX) the per-tap kernel takes, as ONE launch.  Split-K per layer: the layer with the longest
+// per-workgroup chain alone (steps / its own optimal split) sets the chain length T of the launch; every other layer is split so
+// that its workgroups run about T steps too, never finer than it would be split alone (fewer, equally long workgroups: the small
+// layers' atomics shrink with their split and their workgroups fill the large layer's tail).  Returns 1 if launched.
+int tg_wgrad_bf16_multi_launch(const tg_conv_desc* const* ds, int n, const void* const* x, const int* ldxs, const void* const* y,
+                               const int* ldys, float* const* dw, float* const* dbias, hipStream_t st) {
+  if (n < 2 || n > TG_WGRAD_BM_MAX) return 0;
+  WgradBM P;
+  int base[TG_WGRAD_BM_MAX], alone[TG_WGRAD_BM_MAX];
+  constexpr int quantum = 128;
+  double T = 1.0, flops = 0.0, bytes = 0.0;
+  for (int g = 0; g < n; ++g) {
+    const tg_conv_desc* d = ds[g];
+    if (d->mode != 0 || ldxs[g] < d->Cin || ldys[g] < d->Cout) return 0;
+    if (!tg_wgrad_bf16_setup(d, x[g], ldxs[g], y[g], ldys[g], dw[g], dbias ? dbias[g] : nullptr, P.g[g], base[g])) return 0;
+    alone[g] = tg_wgrad_ksplit(P.g[g].M, (int64_t)base[g] * 4096, base[g], quantum);
+    const double t = (double)P.g[g].M / 64.0 / alone[g];
+    if (t > T) T = t;
+    const double M = (double)P.g[g].M;
+    flops += 2.0 * M * d->KH * d->KW * (double)d->Cin * d->Cout;
+    bytes += (double)d->N * d->Hin * d->Win * ldxs[g] * 2.0 + M * ldys[g] * 2.0 + 4.0 * d->KH * d->KW * d->Cin * d->Cout;
+  }
+  int w = 0;
+  for (int g = 0; g < n; ++g) {
+    WgradBP& p = P.g[g];
+    int ksplit = (int)((double)p.M / 64.0 / T + 0.5);
+    if (ksplit > alone[g]) ksplit = alone[g];
+    if (ksplit < 1 || tg_det()) ksplit = 1;
+    p.chunk = (((p.M + ksplit - 1) / ksplit) + quantum - 1) / quantum * quantum;
+    ksplit = (p.M + p.chunk - 1) / p.chunk;
+    P.wstart[g] = w;
+    w += base[g] * ksplit;
+  }
+  for (int g = n; g < TG_WGRAD_BM_MAX; ++g) P.g[g] = P.g[0];
+  for (int g = n; g <= TG_WGRAD_BM_MAX; ++g) P.wstart[g] = w;
+  P.groups = n;
+  const unsigned lds = 2u * 64u * (128u * 2 + 8u) + ((ds[0]->flags & TG_CONV_COEXIST) ? 24576u : 0u);
+  TG_LAUNCH("conv_wgrad_bf16_multi", flops, bytes, conv_wgrad_bf16_multi_kernel, dim3((unsigned)w), dim3(256), lds, st, P);
   return 1;
 }

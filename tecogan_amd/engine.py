@@ -271,6 +271,10 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
             flow, fsaved = self.Fn.forward(fnet_in)                                              # [npair,h,h,2] fp32
             flow_t = flow.view(T - 1, B, h, h, 2)
             gd = self._gan_setup(lr_seq, flow_t) if self.gan else None
+            if self.gan:
+                # the real and the fake pass write the two halves of ONE set of [2 tb, ...] activation buffers: D's own backward
+                # pass then runs once over both (Discriminator.backward_pair)
+                gd["pair"] = self.D.alloc_pair(gd["tb"], gd["Ho"], gd["Ho"], lr_seq)
             # ---- LR warp loss (lib/Teco.py:120-122,329-333) and its gradient to the flow ----------------
             warped_lr = K.warp_forward(pre_lr, flow, torch.empty_like(pre_lr))
             npx = float(npair * h * h)
@@ -302,9 +306,9 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         if self.gan:
             sk, cx = part(2)
             with seg("dreal", sk, ["head"]):
-                gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
-                                                    gd["merge"])
-                gd["p_real"], gd["l_real"], gd["sv_real"] = self.D.forward(gd["real"], flags=cx)
+                into = self.D.pair_half(gd["pair"], 0)
+                gd["real"] = K.pack_d_input_forward(hr_seq, lr_seq, *gd["args"], into["x"], B, h, h, gd["off"], gd["merge"])
+                gd["p_real"], gd["l_real"], gd["sv_real"] = self.D.forward(gd["real"], flags=cx, into=into)
         # ---- recurrent generator (lib/Teco.py:125-155) in CHUNKS of frames; side: the VGG pass (forward, cosine loss against the
         #      target features, input gradient) of every chunk as soon as its frames exist, beside the forward recurrence of
         #      the next chunk -- the last one beside the loss / D work.
@@ -354,9 +358,9 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
             if F.pingpang:
                 self._pingpong(gen, d_gen)
             if self.gan:
-                gd["fake"] = K.pack_d_input_forward(gen, lr_seq, *gd["args"], self._d_input_buf(gd), B, h, h, gd["off"],
-                                                    gd["merge"])
-                gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"])
+                into = self.D.pair_half(gd["pair"], 1)
+                gd["fake"] = K.pack_d_input_forward(gen, lr_seq, *gd["args"], into["x"], B, h, h, gd["off"], gd["merge"])
+                gd["p_fake"], gd["l_fake"], gd["sv_fake"] = self.D.forward(gd["fake"], into=into)
                 self._gan_losses(gd)
             return d_gen
 
@@ -366,9 +370,8 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         fwd_last = "fwd_loss"                                    # the segment D's passes and the losses are complete in
         if self.gan:
             sk, cx = part(8)
-            with seg("down", sk, [fwd_last]):     # D's own gradients (t_discrim_loss) from both passes: beside the BPTT
-                self.D.backward(gd["sv_real"], gd["d_real_D"], None, wgrad=True, need_dx=False, flags=cx)
-                self.D.backward(gd["sv_fake"], gd["d_fake_D"], None, wgrad=True, need_dx=False, flags=cx)
+            with seg("down", sk, [fwd_last]):     # D's own gradients (t_discrim_loss) from both passes, one sweep over 2 tb samples
+                self.D.backward_pair(gd["pair"], (gd["sv_real"], gd["sv_fake"]), gd["d_own_D"], flags=cx)
             # D's gradients and t_balance are final: their all-reduce overlaps the rest of the backward pass
             self._exchange_seg("ar_d", ["tdiscriminator"], ["down"], with_balance=True)
         if self.lookahead and not self._skip_update and self._seg_on("vggt_next", "S", lambda: self._have_next):
@@ -533,15 +536,15 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         return dict(tb=tb, off=off, merge=merge, Ho=H if merge else H - 2 * off, args=(flow_t, flow_nxt, idx_pre, idx_nxt),
                     flow_nxt=flow_nxt)
 
-    def _d_input_buf(self, gd):
-        return torch.empty(gd["tb"], gd["Ho"], gd["Ho"], pad8(self.d_cin), device=self.dev, dtype=self.act_dtype)
-
     def _gan_losses(self, gd):
         """lib/Teco.py:275-313,374-417: adversarial / discriminator / balance scalars and the layer losses, with the gradient
         seeds of the three D backward passes."""
         F = self.F
         p_real, l_real, p_fake, l_fake = gd["p_real"], gd["l_real"], gd["p_fake"], gd["l_fake"]
-        gd["d_real_D"], gd["d_fake_D"], gd["d_fake_G"] = (torch.empty_like(p_real) for _ in range(3))
+        # (the two seeds of D's own backward pass are the halves of one [2 tb, ...] tensor, in the order of the pair buffers)
+        tb = p_real.shape[0]
+        gd["d_own_D"] = torch.empty((2 * tb,) + tuple(p_real.shape[1:]), dtype=p_real.dtype, device=p_real.device)
+        gd["d_real_D"], gd["d_fake_D"], gd["d_fake_G"] = gd["d_own_D"][:tb], gd["d_own_D"][tb:], torch.empty_like(p_real)
         # the five scalars land straight in their (contiguous) loss slots
         i0 = LI["t_adversarial_loss"]
         assert LOSS_NAMES[i0:i0 + 5] == ["t_adversarial_loss", "t_discrim_loss", "t_balance", "t_discrim_real_output",

@@ -460,15 +460,40 @@ class Discriminator:
         self._cursor += 2 * co
         return self.scratch[a:a + 2 * co].view(2, co), True
 
-    def forward(self, x, keep=True, update_moving=True, flags=0):
-        """x [tb,H,W,32|16] -> (prob [tb,H/16,W/16,1] fp32, [4 layer maps], saved)."""
+    def alloc_pair(self, tb, H, W, like):
+        """Activation buffers for TWO passes over tb samples each (the real and the fake triplets of one training step,
+        lib/Teco.py:252-272) as halves of `[2 tb, ...]` tensors, so that the discriminator's own backward pass runs ONCE over
+        the 2 tb samples (`backward_pair`): one input-gradient and one weight-gradient launch per layer instead of two -- the
+        weights are shared and dW is a sum over the samples anyway; only the batch statistics stay per pass."""
+        ps, dt = self.ps, self.ps.act_dtype
+        cp = ps.entries[self.P + "input_stage/conv/Conv/weights"]["Apad"]
+        pair = dict(tb=tb, x=_empty((2 * tb, H, W, cp), dt, like), a=_empty((2 * tb, H, W, 64), dt, like), c=[], y=[], dcv=[])
+        h, w = H, W
+        for _, _, co in DIS_BLOCKS:
+            h, w = K.same_pad(h, 4, 2)[0], K.same_pad(w, 4, 2)[0]
+            pair["c"].append(_empty((2 * tb, h, w, co), dt, like))
+            pair["y"].append(_empty((2 * tb, h, w, co), dt, like))
+            pair["dcv"].append(_empty((2 * tb, h, w, co), dt, like))
+        pair["prob"] = _empty((2 * tb, h, w, 1), _F32, like)
+        return pair
+
+    @staticmethod
+    def pair_half(pair, k):
+        """The buffers of pass k (0 / 1) of a pair, in the form `forward(into=...)` takes."""
+        tb = pair["tb"]
+        sl = slice(k * tb, (k + 1) * tb)
+        return dict(x=pair["x"][sl], a=pair["a"][sl], c=[t[sl] for t in pair["c"]], y=[t[sl] for t in pair["y"]],
+                    prob=pair["prob"][sl])
+
+    def forward(self, x, keep=True, update_moving=True, flags=0, into=None):
+        """x [tb,H,W,32|16] -> (prob [tb,H/16,W/16,1] fp32, [4 layer maps], saved).  into: buffers from pair_half()."""
         ps, p = self.ps, self.P
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x, 1, ACT_LRELU, 0.2,
-                     flags=flags)
+                     flags=flags, out=into["a"] if into else None)
         saved, layers, net = [], [], a
         for bi, (name, _, co) in enumerate(DIS_BLOCKS):
-            c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2, flags=flags)
-            y = torch.empty_like(c)
+            c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2, flags=flags, out=into["c"][bi] if into else None)
+            y = into["y"][bi] if into else torch.empty_like(c)
             stats, pz = self._ws(co, c)
             K.bn_lrelu_forward(c, y, ps.view(p + name + "/BatchNorm/beta"), 1e-3, 0.2, stats,
                                self.moving[bi] if update_moving else None, prezeroed=pz)
@@ -476,7 +501,7 @@ class Discriminator:
             layers.append(y)
             net = y
         prob = conv_fwd(ps, p + "dense_layer_2/dense/kernel", p + "dense_layer_2/dense/bias", net, 1, ACT_SIGMOID,
-                        out_dtype=_F32)
+                        out_dtype=_F32, out=into["prob"] if into else None)
         return prob, layers, ((x, a, saved, prob) if keep else None)
 
     def backward(self, saved_all, d_prob, d_layers=None, wgrad=True, need_dx=False, flags=0):
@@ -508,6 +533,38 @@ class Discriminator:
         if wgrad:
             conv_wgrad(ps, wn, bn, x, g, flags=flags)
         return conv_bwd_data(ps, wn, g, x.shape[1:3], 1, flags=flags) if need_dx else None
+
+    def backward_pair(self, pair, saved_pair, d_prob_pair, flags=0):
+        """The discriminator's OWN gradients (t_discrim_loss, lib/Teco.py:393-417,425-428) from both passes of a pair in one
+        sweep over the 2 tb samples.  saved_pair = (saved of pass 0, saved of pass 1) -- their tensors are the halves of `pair`;
+        d_prob_pair fp32 [2 tb,h,w,1].  Per layer: batch-norm backward per pass (its sums are over ONE pass's samples, as the
+        forward statistics were), then one input-gradient launch over all 2 tb samples; the weight gradients of all layers go
+        out together at the end (tg_conv_wgrad_multi: they only need the saved activations and the dcv buffers)."""
+        ps, p, tb = self.ps, self.P, pair["tb"]
+        todo = []
+        g = K.act_backward(d_prob_pair, pair["prob"], _empty(pair["prob"].shape, ps.act_dtype, pair["prob"]), ACT_SIGMOID)
+        wn, bn = p + "dense_layer_2/dense/kernel", p + "dense_layer_2/dense/bias"
+        y_last = pair["y"][-1]
+        todo.append(conv_wgrad_args(ps, wn, bn, y_last, g, flags=flags))
+        g = conv_bwd_data(ps, wn, g, y_last.shape[1:3], 1, flags=flags)
+        for bi in range(len(DIS_BLOCKS) - 1, -1, -1):
+            name, _, co = DIS_BLOCKS[bi]
+            dcv = pair["dcv"][bi]
+            for k in (0, 1):
+                sl = slice(k * tb, (k + 1) * tb)
+                _, c, y, stats = saved_pair[k][2][bi]
+                ws, pz = self._ws(co, c)
+                K.bn_lrelu_backward(c, y, g[sl], dcv[sl], stats, 1e-3, 0.2, ps.gview(p + name + "/BatchNorm/beta"), ws, prezeroed=pz)
+            net_in = pair["y"][bi - 1] if bi > 0 else pair["a"]
+            todo.append(conv_wgrad_args(ps, p + name + "/conv1/Conv/weights", None, net_in, dcv, 2, flags=flags))
+            if bi > 0:
+                g = conv_bwd_data(ps, p + name + "/conv1/Conv/weights", dcv, net_in.shape[1:3], 2, flags=flags)
+            else:   # net_in = a = lrelu(input conv)
+                g = conv_bwd_data(ps, p + name + "/conv1/Conv/weights", dcv, net_in.shape[1:3], 2, aux=pair["a"],
+                                  mask_act=ACT_LRELU, mask_alpha=0.2, flags=flags)
+        todo.append(conv_wgrad_args(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", pair["x"], g, flags=flags))
+        ds, xs, dys, dws, dbs, lxs, lys = zip(*todo)
+        K.conv_wgrad_multi(list(ds), list(xs), list(dys), list(dws), list(dbs), list(lxs), list(lys))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -1156,6 +1156,51 @@ def test_wgrad_multi_geometry_grouped_launch_matches_autograd():
         close(dbs[i], gb, 3e-4, "multi-geometry dbias layer %d %s" % (i, cases[i]))
 
 
+def test_wgrad_multi_strided_layers_share_one_launch_discriminator_geometry():
+    """tg_conv_wgrad_multi on the discriminator's own-gradient pass (lib/Teco.py:35-39,52-66 under tf.gradients, both passes of a
+    step as one batch): the four 4x4 stride-2 SAME convs 64->64, 64->64, 64->128, 128->256 go out as ONE launch of the per-tap
+    bf16 kernel (conv_wgrad_bf16_multi), the 3x3 input conv (27 channels padded to 32) and the 1x1 dense layer (1 output
+    channel) as their own launches -- each dW / dbias against torch autograd on the bf16-rounded operands."""
+    N = 6
+    cases = [(1, 1, 8, 8, 256, 256, 1), (4, 2, 16, 16, 128, 128, 256), (4, 2, 32, 32, 64, 64, 128), (4, 2, 64, 64, 64, 64, 64),
+             (4, 2, 128, 128, 64, 64, 64), (3, 1, 128, 128, 27, 32, 64)]
+    descs, xs, ys, dws, dbs, lxs, lys, refs = [], [], [], [], [], [], [], []
+    for i, (k, s, H, W, Ci, Cp, Co) in enumerate(cases):
+        x = torch.zeros(N, H, W, Cp)
+        x[..., :Ci] = rnd(N, H, W, Ci, seed=10 + i)
+        x = x.bfloat16()
+        Ho, pt = K.same_pad(H, k, s)
+        Wo, pl = K.same_pad(W, k, s)
+        y = rnd(N, Ho, Wo, Co, seed=40 + i).bfloat16()
+        has_b = k != 4                                                   # D's strided convs have no bias (batch-norm follows)
+        descs.append(K.conv_desc(N, H, W, Ci, Ho, Wo, Co, k, k, s, pt, pl, 0, TG_BF16, TG_BF16))
+        xs.append(x.to(DEV))
+        ys.append(y.to(DEV))
+        dws.append(torch.full((k, k, Ci, Co), 0.5, device=DEV))
+        dbs.append(torch.zeros(Co, device=DEV) if has_b else None)
+        lxs.append(Cp)
+        lys.append(Co)
+        xr = x.float()[..., :Ci].requires_grad_()
+        w = torch.zeros(k, k, Ci, Co, requires_grad=True)
+        b = torch.zeros(Co, requires_grad=True)
+        (O.conv2(xr, w, b, s) * y.float()).sum().backward()
+        refs.append((w.grad, b.grad if has_b else None))
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_wgrad_multi(descs, xs, ys, dws, dbs, lxs, lys)
+    K.prof_enable(False)
+    ents = {e["name"]: e["calls"] for e in K.prof_collect()}
+    assert ents.get("conv_wgrad_bf16_multi") == 1 and "conv_wgrad_bf16<2>" not in ents, ents
+    for i, (gw, gb) in enumerate(refs):
+        close(dws[i] - 0.5, gw, 3e-4, "strided multi-layer dW layer %d %s" % (i, cases[i]))
+        if gb is not None:
+            close(dbs[i], gb, 3e-4, "strided multi-layer dbias layer %d %s" % (i, cases[i]))
+    # a single strided layer still takes the one-layer launch, and the two agree
+    dw1 = torch.zeros(4, 4, 64, 64, device=DEV)
+    K.conv_wgrad(descs[4], xs[4], ys[4], dw1, None, ldx=64, ldy=64)
+    close(dw1, refs[4][0], 3e-4, "single strided layer")
+
+
 # ---- csrc/resblock_lat.hip: one launch per residual block of the training recurrence ------------------------------------------
 RB_SHAPES = [(4, 32, 32), (2, 8, 8), (1, 5, 7), (3, 6, 6), (1, 13, 9), (1, 4, 4), (2, 3, 2)]
 
