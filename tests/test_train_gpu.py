@@ -433,7 +433,7 @@ def test_bf16_latency_kernels_on_vs_off_at_baseline_config_C3():
     F = OT.default_flags()
     x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
     res = {}
-    for tag, blocks, tails in (("A", True, True), ("B", True, False), ("C", False, False)):
+    for tag, blocks, tails in (("A", True, True), ("B", True, False), ("C", False, False), ("C2", False, False)):
         eng = TrainEngine(F, DEV, gan=True, act_dtype=torch.bfloat16, seed=7, use_graph=False)
         eng.ps.load(damp_values(eng.ps.state_dict()))
         eng.G.resblock_lat = blocks
@@ -447,15 +447,22 @@ def test_bf16_latency_kernels_on_vs_off_at_baseline_config_C3():
         torch.cuda.empty_cache()
     rl2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))     # noqa: E731
     (ga, la, gra, gia), (gb, lb, grb, gib), (gc, lc, grc, gic) = res["A"], res["B"], res["C"]
-    assert torch.equal(gb, gc), "C3: HR frames differ between the one-launch and the two-launch residual blocks"
+    gc2, _, grc2, gic2 = res["C2"]
+    assert torch.equal(gb, gc) and torch.equal(gc2, gc), "C3: HR frames differ between the one-launch and the two-launch residual blocks"
+    # run-to-run NOISE of the bf16 step itself (C vs C2: the same code twice): batch-norm and loss sums accumulate with fp32
+    # atomics in a run-dependent order, the sums are rounded to bf16 activations, decisions flip -- 1e-2 on D's gradient and on the
+    # seeds of the BPTT (profiles/r05b_pytest_quick.log).  B vs C is held to that noise, not to a constant.
+    n_g = {sc: rl2(grc2[sc], grc[sc]) for sc in grc}
+    n_gi = (rel_err(gic2, gic), rl2(gic2, gic))
     e_bc = {sc: rl2(grb[sc], grc[sc]) for sc in grc}
     e_ac = {sc: rl2(gra[sc], grc[sc]) for sc in grc}
-    print("\n[C3 bf16 latency kernels] blocks only vs generic: frames bit-equal, gradients %s; all ON vs generic: frames max %.2e / L2 %.2e, "
-          "gradients %s" % ({k: "%.1e" % v for k, v in e_bc.items()}, rel_err(ga, gc), rl2(ga, gc), {k: "%.1e" % v for k, v in e_ac.items()}))
-    # (the recurrent input gradient passes 18 scatter kernels -- fp32 atomics in a run-dependent order -- on its way down the BPTT:
-    #  measured 2.2e-2 in max-norm between two such runs, 1.3e-2 on D's gradient, profiles/r05a_pytest_gpu.log)
-    assert torch.equal(gib.view(torch.int16), gic.view(torch.int16)) or (rel_err(gib, gic) < 5e-2 and rl2(gib, gic) < 1e-2), (rel_err(gib, gic), rl2(gib, gic))
-    assert all(v < 3e-2 for v in e_bc.values()), e_bc
+    print("\n[C3 bf16 latency kernels] run-to-run noise: gradients %s, g_in max %.1e / L2 %.1e; blocks only vs generic: frames bit-equal, "
+          "gradients %s, g_in max %.1e / L2 %.1e; all ON vs generic: frames max %.2e / L2 %.2e, gradients %s"
+          % ({k: "%.1e" % v for k, v in n_g.items()}, n_gi[0], n_gi[1], {k: "%.1e" % v for k, v in e_bc.items()}, rel_err(gib, gic),
+             rl2(gib, gic), rel_err(ga, gc), rl2(ga, gc), {k: "%.1e" % v for k, v in e_ac.items()}))
+    assert torch.equal(gib.view(torch.int16), gic.view(torch.int16)) or \
+        (rel_err(gib, gic) <= 3.0 * n_gi[0] + 1e-3 and rl2(gib, gic) <= 3.0 * n_gi[1] + 1e-4), (rel_err(gib, gic), rl2(gib, gic), n_gi)
+    assert all(e_bc[sc] <= 3.0 * n_g[sc] + 1e-4 for sc in e_bc), (e_bc, n_g)
     assert rel_err(ga, gc) < 2e-3 and rl2(ga, gc) < 1e-3, (rel_err(ga, gc), rl2(ga, gc))
     for k, v in lc.items():
         if k in la and abs(v) > 1e-6 and k not in ("t_balance", "t_balance_now"):
