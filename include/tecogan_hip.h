@@ -108,6 +108,20 @@ int tg_conv_forward(const tg_conv_desc* d, const void* in, const void* weight /*
 int tg_conv3x3_c64_frag(const void* x, const void* w_frag, const float* bias /*nullable*/, const void* res /*nullable*/, void* out,
                         int N, int H, int W, int act, float act_alpha, void* stream);
 
+/* Wide 3x3 stride-1 SAME bf16 convolutions of the FROZEN perceptual-loss network with the weight operand in fragment order
+ * (csrc/conv3x3_wr.hip): VGG-19 conv2_2 ... conv4_4 of reference lib/ops.py:319-327 as called through lib/Teco.py:5-24,174-178,
+ * and their input gradients under tf.gradients (lib/Teco.py:441-449).  Same arithmetic, epilogue and results (bit-identical) as
+ * tg_conv_forward for the descriptor `d` (mode 0 with the W^T copy, mode 1 with the natural copy); the weight fragments stream
+ * global -> registers, only the activation halo goes through LDS.  Cin % 32 == 0, Cin >= 64, Cout % 64 == 0.
+ *   tg_pack_wide_frag: w [9][Cout][Cin] bf16 (the operand tg_conv_forward takes) -> w_frag[Cout/16][Cin/32][9][64][8] with
+ *     w_frag[g][c][t][l][j] = w[flip ? 8 - t : t][16 g + l % 16][32 c + 8 (l / 16) + j]; flip = 1 for the input-gradient
+ *     operand (d->mode == 1: the taps are mirrored in the copy, the kernel sees one direction only).  Once per weight load:
+ *     the network is frozen (lib/Teco.py:421 collects generator / fnet / discriminator variables only).
+ *   tile_rows: 0 = chosen from the launch size, 8 or 16 = forced (measurement). */
+int tg_pack_wide_frag(const void* w, void* w_frag, int Cout, int Cin, int flip, void* stream);
+int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const void* w_frag, const float* bias /*nullable*/,
+                         const void* res /*nullable*/, const void* aux /*nullable*/, void* out, int tile_rows, void* stream);
+
 /* Weight gradient of the gather-form convolution described by `d`
  * (X = the tensor that is gathered, [N,Hin,Win,Cin]; Y = per-output-pixel tensor
  * [N,Hout,Wout,Cout]):   dW[tap][cx][cy] += sum_m X[m@tap][cx] * Y[m][cy]   (fp32 atomics)

@@ -77,7 +77,7 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         self.G, self.Fn = Generator(self.ps, F.num_resblock), FNet(self.ps)
         self.D = Discriminator(self.ps) if gan else None
         if self.use_vgg:
-            self.vps = ParamStore(OrderedDict(vgg=vgg_spec()), self.dev, act_dtype, trainable=False)
+            self.vps = ParamStore(OrderedDict(vgg=vgg_spec()), self.dev, act_dtype, trainable=False, wide_frag=True)
             self.vps.load(init_values(vgg_spec(), seed + 3, he_normal=True))
             self.V = VGG19(self.vps)
         # optimisers: index 0 = discriminator (gated) when present

@@ -187,6 +187,26 @@ def conv3x3_c64_frag(x, w_frag, bias, res, out, act=0, alpha=0.0):
     return out
 
 
+def pack_wide_frag(w, w_frag, Cout, Cin, flip):
+    """Fragment-order copy of a [9][Cout][Cin] bf16 conv operand (csrc/conv3x3_wr.hip); flip mirrors the taps (input gradient)."""
+    assert w.dtype == torch.bfloat16 and w_frag.dtype == torch.bfloat16 and w.numel() == 9 * Cout * Cin == w_frag.numel()
+    check(lib().tg_pack_wide_frag(_p(w), _p(w_frag), Cout, Cin, int(flip), _stream()), "tg_pack_wide_frag")
+    return w_frag
+
+
+def conv3x3_wide_frag_ok(desc):
+    """Shapes tg_conv3x3_wide_frag covers: wide 3x3 stride-1 SAME bf16 layers on images larger than 8x8."""
+    return (desc.KH == 3 and desc.KW == 3 and desc.stride == 1 and desc.Cin % 32 == 0 and desc.Cin > 64 and desc.Cout % 64 == 0
+            and desc.in_dtype == 1 and desc.out_dtype == 1 and desc.Hin > 8 and desc.Win > 8)
+
+
+def conv3x3_wide_frag(desc, x, w_frag, bias, res, aux, out, tile_rows=0):
+    """tg_conv_forward's result for a wide 3x3 layer, weights streamed into registers from the fragment-order copy."""
+    check(lib().tg_conv3x3_wide_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), tile_rows, _stream()),
+          "tg_conv3x3_wide_frag")
+    return out
+
+
 def hr_tail_backward(d_frame, scale, w_out, t2, w_tr_frag, t1, g_out, g_t2, g_t1):
     """Frame gradient -> g_out, g_t2, g_t1 in one launch (csrc/hr_bwd_lat.hip; bf16): see tg_hr_tail_backward."""
     N, H2, W2, C = t1.shape

@@ -28,6 +28,10 @@ def _empty(shape, dtype, like):
 # --------------------------------------------------------------------------------------------------
 # layer primitives
 # --------------------------------------------------------------------------------------------------
+# wide frozen 3x3 layers (VGG-19 conv2_2 ... conv4_4) through csrc/conv3x3_wr.hip when the store keeps fragment-order copies
+WIDE_FRAG = os.environ.get("TG_WIDE_FRAG", "1") != "0"      # A/B against conv3x3_dma.hip
+
+
 def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None, out=None, flags=0):
     """slim.conv2d SAME (reference lib/ops.py:47-56) + fused epilogue.  x [N,H,W,Cin_pad]."""
     e = ps.entries[wname]
@@ -39,7 +43,11 @@ def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, o
     if out is None:
         out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
     d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha, flags=flags)
-    K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
+    wf = ps.packed_wide(wname, True) if WIDE_FRAG else None
+    if wf is not None and K.conv3x3_wide_frag_ok(d):
+        K.conv3x3_wide_frag(d, x, wf, ps.view(bname) if bname else None, res, None, out)
+    else:
+        K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
     return out
 
 
@@ -55,7 +63,11 @@ def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=A
     dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, Ho, Wo, Co, H, W, e["Apad"], k, k, stride, pt, pl, 1, K.dt(dy), K.dt(dx), 0, 0.0,
                     mask_act, mask_alpha, flags=flags)
-    K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)
+    wf = ps.packed_wide(wname, False) if WIDE_FRAG else None
+    if wf is not None and K.conv3x3_wide_frag_ok(d):
+        K.conv3x3_wide_frag(d, dy, wf, None, res, aux, dx)
+    else:
+        K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)
     return dx
 
 

@@ -131,10 +131,14 @@ def damp_values(values, conv2=0.25, out=0.1):
 class ParamStore:
     """One flat fp32 buffer + compute copies.  `specs`: OrderedDict scope -> OrderedDict(name -> shape)."""
 
-    def __init__(self, specs, device, act_dtype=torch.float32, trainable=True, bpad=()):
+    def __init__(self, specs, device, act_dtype=torch.float32, trainable=True, bpad=(), wide_frag=False):
         """bpad: names of weights whose OUTPUT channels are also padded to a multiple of 8 in the natural copy
-        (layers whose output-gradient is kept channel-padded, e.g. the 3-channel generator output conv)."""
+        (layers whose output-gradient is kept channel-padded, e.g. the 3-channel generator output conv).
+        wide_frag: also keep fragment-order copies of the wide 3x3 layers for csrc/conv3x3_wr.hip (frozen stores: the
+        copies are refreshed by repack() like the others, which a frozen store runs once per load())."""
         self.device, self.act_dtype, self.trainable = device, act_dtype, trainable
+        self.wide_frag = bool(wide_frag) and act_dtype == torch.bfloat16
+        self.wide = {}                                             # name -> [forward copy or None, input-gradient copy or None]
         self.entries = OrderedDict()
         self.scope_range = OrderedDict()
         off = poff = 0
@@ -197,6 +201,12 @@ class ParamStore:
         n = e["taps"] * e["Apad"] * (e["B"] if transposed else e["Bpad"])
         return (self.wT if transposed else self.wN)[e["packed"]:e["packed"] + n]
 
+    def packed_wide(self, name, transposed):
+        """Fragment-order copy of a wide 3x3 layer for tg_conv3x3_wide_frag (forward operand if transposed, else the
+        input-gradient operand with mirrored taps), or None."""
+        w = self.wide.get(name)
+        return None if w is None else w[0 if transposed else 1]
+
     def packed_frag(self, name, transposed):
         """Fragment-order copy (csrc/resblock_lat.hip) of a residual-block conv, or None when the store keeps none."""
         o = self.frag.get(name)
@@ -228,6 +238,20 @@ class ParamStore:
             K.pack_weights_both(self.flat, self.wT, self.wN, self.table, self.ntab)
         if self.frag:
             K.pack_weights_frag(self.flat, self.wTf, self.wNf, self.frag_table, len(self.frag))
+        if self.wide_frag:
+            for name, e in self.entries.items():
+                if e.get("taps") != 9 or e["Apad"] != e["A"] or e["Bpad"] != e["B"]:
+                    continue
+                A, B = e["A"], e["B"]
+                w = self.wide.setdefault(name, [None, None])
+                if A % 32 == 0 and A > 64 and B % 64 == 0:         # forward: Cin = A, Cout = B
+                    if w[0] is None:
+                        w[0] = torch.empty(9 * A * B, device=self.device, dtype=torch.bfloat16)
+                    K.pack_wide_frag(self.packed(name, True), w[0], B, A, False)
+                if B % 32 == 0 and B > 64 and A % 64 == 0:         # input gradient: Cin = B, Cout = A, taps mirrored
+                    if w[1] is None:
+                        w[1] = torch.empty(9 * A * B, device=self.device, dtype=torch.bfloat16)
+                    K.pack_wide_frag(self.packed(name, False), w[1], A, B, True)
 
     def zero_grad(self):
         self.grad.zero_()

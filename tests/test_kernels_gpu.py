@@ -1042,6 +1042,76 @@ def test_conv3x3_wide_layer_dma_kernel(case):
     assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
 
 
+# ---- conv3x3_wr.hip (round 5): wide frozen layers, weight fragments streamed into registers ------------------------------------
+WR_CASES = [
+    # N, H, W, Cin, Cout, flip, res, aux, act, tile_rows
+    (6, 32, 32, 256, 256, False, False, False, ACT_RELU, 16),    # VGG conv3_x geometry: 4 tiles per image, 8 stages
+    (6, 32, 32, 256, 256, False, False, False, ACT_RELU, 8),     # ... in 8-row tiles
+    (28, 16, 16, 512, 512, False, False, False, ACT_RELU, 0),    # VGG conv4_x of the early chunk: tile height chosen by the launch
+    (48, 16, 16, 512, 512, True, False, True, ACT_NONE, 0),      # ... input gradient of the late chunk with the ReLU mask
+    (3, 64, 64, 128, 128, True, False, True, ACT_NONE, 16),      # conv2_2 input gradient: mirrored taps + ReLU mask
+    (5, 64, 64, 128, 64, True, False, False, ACT_NONE, 0),       # conv2_1 input gradient (128 -> 64: one channel block)
+    (35, 40, 27, 96, 64, False, True, False, ACT_LRELU, 16),     # ragged right / bottom edges, Cin = 96 (3 stages), residual
+    (35, 40, 27, 96, 128, False, True, True, ACT_LRELU, 8),      # ... 8-row tiles, residual + mask; unit count not a multiple of 8
+    (1, 128, 128, 128, 64, True, True, True, ACT_NONE, 0),       # one image, many tiles
+    (76, 32, 32, 128, 256, False, False, False, ACT_RELU, 0),    # conv3_1 at the full batch
+]
+
+
+@pytest.mark.parametrize("case", WR_CASES)
+def test_conv3x3_wide_frag_kernel_is_bit_identical_to_conv_forward(case):
+    """tg_conv3x3_wide_frag (weights global -> registers from the fragment-order copy, halo by LDS-DMA) against the oracle's conv2
+    (lib/ops.py:47-56) AND bit for bit against tg_conv_forward on the same operands: same MFMA, same operand roles, same
+    accumulation order (stage, kw, kh)."""
+    N, H, W, Cin, Cout, flip, has_res, has_aux, act, th = case
+    x = rnd(N, H, W, Cin, seed=1).bfloat16()
+    w = rnd(3, 3, Cin, Cout, seed=2, scale=0.05).bfloat16()
+    b = None if flip else rnd(Cout, seed=3)
+    res = rnd(N, H, W, Cout, seed=4).bfloat16() if has_res else None
+    aux = rnd(N, H, W, Cout, seed=5).bfloat16() if has_aux else None
+    alpha = 0.2 if act == ACT_LRELU else 0.0
+    ref = O.conv2(x.float(), w.float().flip(0, 1) if flip else w.float(), b, 1)
+    if act == ACT_RELU:
+        ref = torch.relu(ref)
+    elif act == ACT_LRELU:
+        ref = torch.where(ref > 0, ref, ref * alpha)
+    if has_res:
+        ref = ref + res.float()
+    if has_aux:
+        ref = ref * (aux.float() > 0).float()
+    wt = w.permute(0, 1, 3, 2).reshape(9, Cout, Cin).contiguous().to(DEV)          # [tap][Cout][Cin], the operand of tg_conv_forward
+    wf = K.pack_wide_frag(wt, torch.empty_like(wt), Cout, Cin, flip)
+    d = K.conv_desc(N, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1 if flip else 0, TG_BF16, TG_BF16, act, alpha,
+                    ACT_RELU if has_aux else ACT_NONE, 0.0)
+    assert K.conv3x3_wide_frag_ok(d)
+    args = (None if b is None else b.to(DEV), None if res is None else res.to(DEV), None if aux is None else aux.to(DEV))
+    old = K.conv_forward(d, x.to(DEV), wt, *args, torch.full((N, H, W, Cout), 7.0, device=DEV, dtype=torch.bfloat16))
+    K.prof_collect()
+    K.prof_enable(True)
+    out = K.conv3x3_wide_frag(d, x.to(DEV), wf, *args, torch.full((N, H, W, Cout), 7.0, device=DEV, dtype=torch.bfloat16), tile_rows=th)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"].startswith("conv3x3_wr"), ents
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 8e-3 * ref.abs() + 4e-2).all(), "%s: max err %g" % (case, err.max().item())
+    assert torch.equal(out.view(torch.int16), old.view(torch.int16)), \
+        "%s: %d of %d elements differ from tg_conv_forward, max %g" % (case, (out != old).sum().item(), out.numel(),
+                                                                       (out.float() - old.float()).abs().max().item())
+
+
+def test_wide_frag_rejects_what_it_does_not_cover():
+    from tecogan_amd._lib import TecoHipError
+    x = torch.zeros(1, 16, 16, 48, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(9 * 64 * 48, device=DEV, dtype=torch.bfloat16)
+    d = K.conv_desc(1, 16, 16, 48, 16, 16, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16)
+    with pytest.raises(TecoHipError):
+        K.conv3x3_wide_frag(d, x, w, None, None, None, torch.zeros(1, 16, 16, 64, device=DEV, dtype=torch.bfloat16))
+    d = K.conv_desc(1, 16, 16, 128, 8, 8, 64, 4, 4, 2, 1, 1, 0, TG_BF16, TG_BF16)
+    with pytest.raises(TecoHipError):
+        K.conv3x3_wide_frag(d, torch.zeros(1, 16, 16, 128, device=DEV, dtype=torch.bfloat16), w, None, None, None,
+                            torch.zeros(1, 8, 8, 64, device=DEV, dtype=torch.bfloat16))
+
+
 @pytest.mark.parametrize("case", [(1, 270, 480, 64, 64), (2, 128, 128, 32, 64), (1, 133, 245, 64, 128)])
 def test_deconv3x3s2_weights_in_registers_kernel(case):
     """slim.conv2d_transpose k3 s2 SAME (lib/ops.py:35-44) + bias + ReLU in the throughput regime: the four output phases as

@@ -22,7 +22,7 @@ ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--flags", type=int, default=0, help="1 = TG_CONV_COEXIST tiles")
 a = ap.parse_args()
 dev = "cuda"
-vps = ParamStore(OrderedDict(vgg=vgg_spec()), dev, torch.bfloat16, trainable=False)
+vps = ParamStore(OrderedDict(vgg=vgg_spec()), dev, torch.bfloat16, trainable=False, wide_frag=True)
 vps.load(init_values(vgg_spec(), 45, he_normal=True))
 V = VGG19(vps)
 H = 128
