@@ -117,10 +117,29 @@ int tg_conv3x3_c64_frag(const void* x, const void* w_frag, const float* bias /*n
  *     w_frag[g][c][t][l][j] = w[flip ? 8 - t : t][16 g + l % 16][32 c + 8 (l / 16) + j]; flip = 1 for the input-gradient
  *     operand (d->mode == 1: the taps are mirrored in the copy, the kernel sees one direction only).  Once per weight load:
  *     the network is frozen (lib/Teco.py:421 collects generator / fnet / discriminator variables only).
- *   tile_rows: 0 = chosen from the launch size, 8 or 16 = forced (measurement). */
+ * Images of exactly 8 x 8 pixels (VGG conv5_x) run as PACKED tiles -- two whole images per 8 x 16 tile, each with its own zero
+ * border -- and, when the launch has fewer than one wave per SIMD, with the input channels SPLIT over ksplit groups of waves
+ * whose partial sums meet in LDS in a fixed order (deterministic; not bit-identical to tg_conv_forward's single sum).
+ *   tile_rows: 0 = chosen from the launch size, 8 or 16 = forced; ksplit: 0 = chosen from the launch size, 1 / 2 / 4 = forced
+ *   (8-row tiles only; must divide Cin / 32). */
 int tg_pack_wide_frag(const void* w, void* w_frag, int Cout, int Cin, int flip, void* stream);
 int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const void* w_frag, const float* bias /*nullable*/,
-                         const void* res /*nullable*/, const void* aux /*nullable*/, void* out, int tile_rows, void* stream);
+                         const void* res /*nullable*/, const void* aux /*nullable*/, void* out, int tile_rows, int ksplit,
+                         void* stream);
+
+/* discriminator_F's four `conv2(net, 4, C, 2)` layers (reference lib/Teco.py:52-66; conv2 = lib/ops.py:47-56, slim.conv2d k4 s2
+ * SAME) and their input gradients under tf.gradients (lib/Teco.py:393-449), bf16 (csrc/conv4x4s2.hip): the same result as
+ * tg_conv_forward for the descriptor `d` up to the summation order (same products, fp32 accumulation).
+ *   d->mode 0: out [N,H/2,W/2,Cout] = conv(in [N,H,W,Cin]) (+ bias, none / ReLU / LeakyReLU, + res); H, W even, pad 1
+ *   d->mode 1: out [N,2H,2W,Cout]   = input gradient from dY = in [N,H,W,Cin] (+ res, * act'(aux)); the four output phases run as
+ *              2x2-tap stride-1 convolutions over one halo of dY
+ * w_frag = tg_pack_taps_frag(w, 16, Cout, Cin) of the [16][Cout][Cin] operand tg_conv_forward takes for the same descriptor
+ * (mode 0: the W^T copy, mode 1: the HWIO weights as stored).  Cin % 32 == 0, Cout % 64 == 0.
+ *   tg_pack_taps_frag: w [taps][Cout][Cin] bf16 -> w_frag[Cout/16][Cin/32][taps][64][8],
+ *     w_frag[g][c][t][l][j] = w[t][16 g + l % 16][32 c + 8 (l / 16) + j]  (a wave's weight load = 1 KiB contiguous). */
+int tg_pack_taps_frag(const void* w, void* w_frag, int taps, int Cout, int Cin, void* stream);
+int tg_conv4x4s2_frag(const tg_conv_desc* d, const void* in, const void* w_frag, const float* bias /*nullable*/,
+                      const void* res /*nullable*/, const void* aux /*nullable*/, void* out, void* stream);
 
 /* Weight gradient of the gather-form convolution described by `d`
  * (X = the tensor that is gathered, [N,Hin,Win,Cin]; Y = per-output-pixel tensor

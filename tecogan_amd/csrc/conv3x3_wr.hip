@@ -24,6 +24,7 @@
 //   * accumulation order per output element = conv3x3_dma.hip's (chunk, kw, kh ascending; same MFMA, same operand roles):
 //     results are BIT-IDENTICAL to tg_conv_forward's (tests/test_kernels_gpu.py holds that).
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 struct ConvWrP {
@@ -46,14 +47,18 @@ typedef __attribute__((address_space(3))) void lds_void_w;
 
 namespace {
 constexpr unsigned WR_OOB = 0x80000000u;
-constexpr int WR_HW = 18;                                            // halo row pitch in pixels
-template <int TH> struct WrGeo {
+// PK = images per tile row.  PK = 1: a 16 x TH tile of a larger image, (TH + 2) x 18 halo.  PK = 2 (PACKED tiles, images of exactly
+// 8 x 8 pixels: VGG conv5): the 8 x 16 output pixels are two whole images side by side, each with its own zero border in a
+// 10 x 20 halo; output pixel (r, c) reads halo (r + kh, c + 2 (c / 8) + kw) -- a per-lane column shift on the fragment base.
+template <int TH, int PK> struct WrGeo {
+  static_assert(PK == 1 || (PK == 2 && TH == 8), "packed tiles: two 8 x 8 images");
+  static constexpr int HW = PK == 1 ? 18 : 20;                       // halo row pitch in pixels
   static constexpr int HR = TH + 2;                                  // halo rows
-  static constexpr int HALO = HR * WR_HW;                            // 324 / 180 halo pixels
-  static constexpr int INST = (HALO * 4 + 63) / 64;                  // 21 / 12 wave-wide DMA instructions (1 KB each)
-  static constexpr int ROUNDS = (INST + 3) / 4;                      // 6 / 3 rounds of 4 waves
-  static constexpr int BYTES = ROUNDS * 4 * 1024;                    // 24576 / 12288 per buffer: every wave issues every round (the
-                                                                     // slots past the halo take out-of-range lanes = zeros), no branch
+  static constexpr int HALO = HR * HW;                               // 324 / 180 / 200 halo pixels
+  static constexpr int INST = (HALO * 4 + 63) / 64;                  // 21 / 12 / 13 wave-wide DMA instructions (1 KB each)
+  static constexpr int ROUNDS = (INST + 3) / 4;                      // 6 / 3 / 4 rounds of 4 waves
+  static constexpr int BYTES = ROUNDS * 4 * 1024;                    // 24576 / 12288 / 16384 per buffer: every wave issues every round
+                                                                     // (the slots past the halo take out-of-range lanes = zeros), no branch
 };
 template <int I, int N, typename F>
 __device__ __forceinline__ void wr_static_for(F&& f) {
@@ -64,14 +69,19 @@ __device__ __forceinline__ void wr_static_for(F&& f) {
 }
 }  // namespace
 
-template <bool HAS_RES, bool HAS_AUX, int TH>
-__global__ __launch_bounds__(256, 3) void conv3x3_wr_kernel(ConvWrP p) {
-  using G = WrGeo<TH>;
-  constexpr int HR = G::HR, ROUNDS = G::ROUNDS, HB = G::BYTES;
+// KS = K split: the workgroup has 4 KS waves; wave (kpart, cg) accumulates input-channel chunks [kpart nchunk / KS, ...) for channel
+// group cg from its kpart's OWN halo double buffer, the partial sums meet in LDS at the end (fixed order: deterministic).  For
+// launches with few pixels and many channels (conv5: 3072 pixels x 512 x 4608) it is the only parallelism left: 192 units of 4
+// waves would put one wave on three quarters of the SIMDs and none on the rest.
+template <bool HAS_RES, bool HAS_AUX, int TH, int PK, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : (KS == 2 ? 2 : 1)) void conv3x3_wr_kernel(ConvWrP p) {
+  using G = WrGeo<TH, PK>;
+  constexpr int HW = G::HW, HR = G::HR, ROUNDS = G::ROUNDS, HB = G::BYTES;
   constexpr int NS = 3 * HR;                                          // halo fragments of a stage: s = kw * HR + hr
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x HB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // KS x 2 x HB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kpart = KS == 1 ? 0 : wave >> 2, cg = wave & 3;
   const int frow = lane & 15, fg = lane >> 4;
 
   // unit -> (tile, channel block): XCD x (linear workgroup id % 8) owns units [x u8, (x + 1) u8)
@@ -80,12 +90,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wr_kernel(ConvWrP p) {
   if (u >= p.nunits) return;
   const int tile = u / p.nblk, blk = u - tile * p.nblk;
   const int tx = tile % p.tiles_x, t1 = tile / p.tiles_x;
-  const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+  const int ty = t1 % p.tiles_y;
+  const int n = PK == 1 ? t1 / p.tiles_y : tile * 2;                  // packed: the tile's first image
   const int y0 = ty * TH - 1, x0 = tx * 16 - 1;
-  const int g16 = blk * 4 + wave;                                     // this wave's group of 16 output channels
+  const int g16 = blk * 4 + cg;                                       // this wave's group of 16 output channels
   const int cbase = g16 * 16;
   const int row_bytes = p.Cin * 2;
   const int nchunk = p.Cin >> 5;
+  const int nc = nchunk / KS, c0 = kpart * nc;                        // this wave's stages: chunks [c0, c0 + nc)
+  unsigned char* const kb = smem + kpart * 2 * HB;                    // this kpart's halo double buffer
 
   const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wf), 0, (int)p.w_bytes, 0x00020000);
@@ -100,27 +113,33 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wr_kernel(ConvWrP p) {
   unsigned hoff[ROUNDS];
 #pragma unroll
   for (int k = 0; k < ROUNDS; ++k) {
-    const int S = (wave + 4 * k) * 64 + lane;
+    const int S = (cg + 4 * k) * 64 + lane;
     const int q = S >> 2, ch = (S & 3) ^ (((S >> 4) & 1) << 1);
-    const int dy = q / WR_HW, dx = q - WR_HW * dy;
-    const bool ok = q < G::HALO && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
-    hoff[k] = ok ? (unsigned)(((n * p.H + y0 + dy) * p.W + x0 + dx) * row_bytes + ch * 16) : WR_OOB;
+    const int dy = q / HW, dx = q - HW * dy;
+    if constexpr (PK == 1) {
+      const bool ok = q < G::HALO && (unsigned)(y0 + dy) < (unsigned)p.H && (unsigned)(x0 + dx) < (unsigned)p.W;
+      hoff[k] = ok ? (unsigned)(((n * p.H + y0 + dy) * p.W + x0 + dx) * row_bytes + ch * 16) : WR_OOB;
+    } else {                  // packed: image b of the pair, pixel (ry, rx) of that image or its zero border
+      const int b = dx / 10, rx = dx - 10 * b - 1, ry = dy - 1;
+      const bool ok = q < G::HALO && (unsigned)ry < 8u && (unsigned)rx < 8u && n + b < p.N;
+      hoff[k] = ok ? (unsigned)((((n + b) * 8 + ry) * 8 + rx) * row_bytes + ch * 16) : WR_OOB;
+    }
   }
   auto dma_round = [&](int k, int chunk, int buf, bool live) {
-    const int inst = wave + 4 * k;                                    // wave-uniform
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_w*)(smem + buf * HB + inst * 1024), 16,
-                                               (int)(live ? hoff[k] : WR_OOB), chunk * 64, 0, 0);
+    const int inst = cg + 4 * k;                                      // wave-uniform
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void_w*)(kb + buf * HB + inst * 1024), 16,
+                                             (int)(live ? hoff[k] : WR_OOB), chunk * 64, 0, 0);
   };
 
   // ---- prologue: bias, the first stage's halo, the first stage's nine weight fragments (this order: the counted wait
   //      at the top of a stage relies on the nine weight loads being the YOUNGEST vector-memory operations of the wave)
   const u32x4w bq = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (cbase + fg * 4) * 4, 0, 0);
 #pragma unroll
-  for (int k = 0; k < ROUNDS; ++k) dma_round(k, 0, 0, true);
+  for (int k = 0; k < ROUNDS; ++k) dma_round(k, c0, 0, true);
   // weight fragment (chunk c, tap t) of this wave: bytes [((g16 * nchunk + c) * 9 + t) * 1024, + 1024); lane l holds
   // w[t][cbase + l % 16][32 c + 8 (l / 16) .. + 8]
   const int wlane = lane * 16;
-  int wsoff = g16 * nchunk * 9216;                                    // scalar: this stage's nine fragments
+  int wsoff = (g16 * nchunk + c0) * 9216;                             // scalar: this stage's nine fragments
   u32x4w wf[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
@@ -129,30 +148,32 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wr_kernel(ConvWrP p) {
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  // halo fragment (row hr, tap column kw): pixels q = K + frow with K = 18 hr + kw (compile time).  The swizzle bit
-  // (q >> 2) & 1 depends only on (frow + K) mod 8: eight lane bases cover every K, the read is base[K & 7] + 64 K.
+  // halo fragment (row hr, tap column kw): pixels q = K + Q0 with K = HW hr + kw (compile time) and Q0 = the lane's column
+  // (packed: + 2 border columns once past the first image).  The swizzle bit (q >> 2) & 1 depends only on (Q0 + K) mod 8:
+  // eight lane bases cover every K, the read is base[K & 7] + 64 K.
+  const int Q0 = PK == 1 ? frow : frow + 2 * (frow >> 3);
   int abase[8];
 #pragma unroll
-  for (int d = 0; d < 8; ++d) abase[d] = frow * 64 + ((fg ^ (((((frow & 7) + d) >> 2) & 1) << 1)) << 4);
+  for (int d = 0; d < 8; ++d) abase[d] = Q0 * 64 + ((fg ^ (((((Q0 & 7) + d) >> 2) & 1) << 1)) << 4);
 
   f32x4 acc[TH];
 #pragma unroll
   for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int buf = chunk & 1;
+  for (int c = 0; c < nc; ++c) {
+    const int buf = c & 1;
     // This wave's DMA slots of the stage have landed: the vector-memory queue retires in order and holds (oldest first) the
     // stage's DMA and the stage's nine weight loads, so a counted wait covers the DMA without draining the weight stream.
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                         // every wave's slots landed; nobody still reads the other buffer
-    const bool has_next = chunk + 1 < nchunk;
+    const bool has_next = c + 1 < nc;
     const unsigned wl_next = has_next ? (unsigned)wlane : WR_OOB;     // past the last stage the loads read zeros (no branch)
     wsoff += 9216;
-    const unsigned char* sb = smem + buf * HB;
+    const unsigned char* sb = kb + buf * HB;
     auto rd = [&](int s) {
       const int kw = s / HR, hr = s - kw * HR;
-      const int K = hr * WR_HW + kw;
+      const int K = hr * HW + kw;
       return *reinterpret_cast<const u32x4w*>(sb + abase[K & 7] + K * 64);
     };
     u32x4w F[3];
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wr_kernel(ConvWrP p) {
       // cycles to issue: back to back they would stall this wave's MFMA stream)
       if constexpr (s < ROUNDS) {
         __builtin_amdgcn_sched_barrier(0);
-        dma_round(s, chunk + 1, buf ^ 1, has_next);
+        dma_round(s, c0 + c + 1, buf ^ 1, has_next);
         __builtin_amdgcn_sched_barrier(0);
       }
       // tap (kh, kw) was used for the last time at hr = TH - 1 + kh: request the next stage's fragment into the same registers
@@ -186,16 +207,36 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wr_kernel(ConvWrP p) {
     });
   }
 
-  // ---- epilogue in registers: accumulator r of lane (frow, fg) at row i = pixel (ty TH + i, tx 16 + frow), channel
-  //      cbase + 4 fg + r
+  // ---- K split: partial sums of kparts 1 .. KS-1 -> LDS (over the halo buffers, once the last stage's trailing zero-fill DMA
+  //      has landed and every wave has left its last stage), kpart 0 adds them in a fixed order and finishes the tile
+  if constexpr (KS > 1) {
+    static_assert((KS - 1) * 4 * TH * 1024 <= KS * 2 * HB, "partial sums must fit over the halo buffers");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kpart > 0) {
+#pragma unroll
+      for (int i = 0; i < TH; ++i)
+        *reinterpret_cast<f32x4*>(smem + (((kpart - 1) * 4 + cg) * TH + i) * 1024 + lane * 16) = acc[i];
+    }
+    __syncthreads();
+    if (kpart > 0) return;
+#pragma unroll 1
+    for (int k = 1; k < KS; ++k)
+#pragma unroll
+      for (int i = 0; i < TH; ++i) acc[i] += *reinterpret_cast<const f32x4*>(smem + (((k - 1) * 4 + cg) * TH + i) * 1024 + lane * 16);
+  }
+
+  // ---- epilogue in registers: accumulator r of lane (frow, fg) at row i = pixel (ty TH + i, tx 16 + frow) (packed: pixel
+  //      (i, frow % 8) of image n + frow / 8), channel cbase + 4 fg + r
   const float bv[4] = {__uint_as_float(bq.x), __uint_as_float(bq.y), __uint_as_float(bq.z), __uint_as_float(bq.w)};
-  const int x = tx * 16 + frow, ybase = ty * TH;
+  const int x = PK == 1 ? tx * 16 + frow : (frow & 7), ybase = PK == 1 ? ty * TH : 0;
+  const int ni = PK == 1 ? n : n + (frow >> 3);
   const int co = cbase + fg * 4;
   unsigned offs[TH];
 #pragma unroll
   for (int i = 0; i < TH; ++i) {
     const int y = ybase + i;
-    offs[i] = (y < p.H && x < p.W) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + co) * 2) : WR_OOB;
+    offs[i] = (y < p.H && x < p.W && ni < p.N) ? (unsigned)((((ni * p.H + y) * p.W + x) * p.Cout + co) * 2) : WR_OOB;
   }
   u32x2w rr[HAS_RES ? TH : 1], aa[HAS_AUX ? TH : 1];
   if constexpr (HAS_RES) {
@@ -258,29 +299,41 @@ extern "C" int tg_pack_wide_frag(const void* w, void* w_frag, int Cout, int Cin,
   TG_CHECK_LAUNCH();
 }
 
-template <bool HAS_RES, bool HAS_AUX, int TH>
+template <bool HAS_RES, bool HAS_AUX, int TH, int PK, int KS>
 static void launch_wr(const ConvWrP& p, hipStream_t st) {
-  auto kern = conv3x3_wr_kernel<HAS_RES, HAS_AUX, TH>;
-  constexpr int LDS = 2 * WrGeo<TH>::BYTES;
+  auto kern = conv3x3_wr_kernel<HAS_RES, HAS_AUX, TH, PK, KS>;
+  constexpr int LDS = KS * 2 * WrGeo<TH, PK>::BYTES;
+  if constexpr (LDS > 65536) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    });
+  }
   static const char* const pname =
-      TH == 16 ? (HAS_RES ? (HAS_AUX ? "conv3x3_wr<res,aux>" : "conv3x3_wr<res>") : (HAS_AUX ? "conv3x3_wr<aux>" : "conv3x3_wr<>"))
-               : (HAS_RES ? (HAS_AUX ? "conv3x3_wr8<res,aux>" : "conv3x3_wr8<res>") : (HAS_AUX ? "conv3x3_wr8<aux>" : "conv3x3_wr8<>"));
+      PK == 2 ? (HAS_AUX ? "conv3x3_wr_pack2<aux>" : "conv3x3_wr_pack2<>")
+      : TH == 16 ? (HAS_RES ? (HAS_AUX ? "conv3x3_wr<res,aux>" : "conv3x3_wr<res>") : (HAS_AUX ? "conv3x3_wr<aux>" : "conv3x3_wr<>"))
+                 : (HAS_RES ? (HAS_AUX ? "conv3x3_wr8<res,aux>" : "conv3x3_wr8<res>") : (HAS_AUX ? "conv3x3_wr8<aux>" : "conv3x3_wr8<>"));
   const double px = (double)p.N * p.H * p.W;
   TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
-            px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(8 * p.u8), dim3(256),
+            px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(8 * p.u8), dim3(256 * KS),
             LDS, st, p);
 }
 
-template <int TH>
+template <int TH, int PK, int KS>
 static void launch_wr_th(const ConvWrP& p, bool res, bool aux, hipStream_t st) {
-  if (res && aux) launch_wr<true, true, TH>(p, st);
-  else if (res) launch_wr<true, false, TH>(p, st);
-  else if (aux) launch_wr<false, true, TH>(p, st);
-  else launch_wr<false, false, TH>(p, st);
+  if constexpr (PK == 2) {                  // packed tiles: the residual form is not instantiated (no caller: VGG conv5 has none)
+    if (aux) launch_wr<false, true, TH, PK, KS>(p, st);
+    else launch_wr<false, false, TH, PK, KS>(p, st);
+  } else {
+    if (res && aux) launch_wr<true, true, TH, PK, KS>(p, st);
+    else if (res) launch_wr<true, false, TH, PK, KS>(p, st);
+    else if (aux) launch_wr<false, true, TH, PK, KS>(p, st);
+    else launch_wr<false, false, TH, PK, KS>(p, st);
+  }
 }
 
 extern "C" int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const void* w_frag, const float* bias, const void* res,
-                                    const void* aux, void* out, int tile_rows, void* stream) {
+                                    const void* aux, void* out, int tile_rows, int ksplit, void* stream) {
   TG_CHECK_ARG(d && in && w_frag && out, "null pointer");
   TG_CHECK_ARG(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->Hin == d->Hout && d->Win == d->Wout,
                "3x3 stride-1 SAME convolutions only (either direction: the fragment-order copy carries the tap order)");
@@ -288,6 +341,7 @@ extern "C" int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const
   TG_CHECK_ARG(d->Cin % 32 == 0 && d->Cin >= 64 && d->Cout % 64 == 0, "Cin % 32 == 0, Cin >= 64, Cout % 64 == 0");
   TG_CHECK_ARG(d->act < TG_ACT_TANH, "epilogue activations: none / ReLU / LeakyReLU");
   TG_CHECK_ARG(tile_rows == 0 || tile_rows == 8 || tile_rows == 16, "tile_rows: 0 (auto), 8 or 16");
+  TG_CHECK_ARG(ksplit == 0 || ksplit == 1 || ksplit == 2 || ksplit == 4, "ksplit: 0 (auto), 1, 2 or 4");
   TG_CHECK_ARG((((uintptr_t)in | (uintptr_t)w_frag | (uintptr_t)out | (uintptr_t)res | (uintptr_t)aux) & 15) == 0,
                "pointers must be 16-byte aligned");
   const int64_t px = (int64_t)d->N * d->Hin * d->Win;
@@ -300,21 +354,44 @@ extern "C" int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
   p.nblk = p.Cout / 64;
   p.tiles_x = (p.W + 15) / 16;
+  const int nchunk = p.Cin / 32;
+  const bool packed = p.H == 8 && p.W == 8;               // two whole images per tile (VGG conv5)
+  TG_CHECK_ARG(!packed || !res, "packed tiles (8 x 8 images) take no residual operand");
   // tile height: 16 rows read 18 halo rows for 16 (8: 10 for 8), but a launch needs several units per CU for the dispatcher to
   // balance its tail: 8-row tiles below 4 units of 16 rows per CU
-  int th = tile_rows;
+  int th = packed ? 8 : tile_rows;
   if (th == 0) {
     const int64_t u16 = (int64_t)p.N * ((p.H + 15) / 16) * p.tiles_x * p.nblk;
-    th = (u16 >= 4 * (int64_t)tg_num_cus() || p.H <= 8) ? 16 : 8;
+    th = u16 >= 4 * (int64_t)tg_num_cus() ? 16 : 8;
   }
-  p.tiles_y = (p.H + th - 1) / th;
-  const int64_t nunits = (int64_t)p.N * p.tiles_y * p.tiles_x * p.nblk;
+  p.tiles_y = packed ? 1 : (p.H + th - 1) / th;
+  const int64_t ntiles = packed ? ((int64_t)p.N + 1) / 2 : (int64_t)p.N * p.tiles_y * p.tiles_x;
+  if (packed) p.tiles_x = 1;
+  const int64_t nunits = ntiles * p.nblk;
   TG_CHECK_ARG(nunits < ((int64_t)1 << 28), "too many tiles");
+  // K split: only when the launch cannot give every SIMD a wave otherwise (4 waves per unit), and at least two stages per part
+  int ks = ksplit;
+  if (ks == 0) {
+    ks = 1;
+    if (packed)
+      while (ks < 4 && nunits * 4 * ks < 4 * (int64_t)tg_num_cus() && nchunk % (2 * ks) == 0 && nchunk / (2 * ks) >= 2) ks *= 2;
+  }
+  TG_CHECK_ARG(nchunk % ks == 0 && (ks == 1 || th == 8), "ksplit must divide Cin / 32 and needs 8-row tiles");
   p.nunits = (int)nunits;
   p.u8 = (int)((nunits + 7) / 8);
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (th == 16) launch_wr_th<16>(p, res != nullptr, aux != nullptr, st);
-  else launch_wr_th<8>(p, res != nullptr, aux != nullptr, st);
+  const bool r = res != nullptr, a = aux != nullptr;
+  if (packed) {
+    if (ks == 1) launch_wr_th<8, 2, 1>(p, r, a, st);
+    else if (ks == 2) launch_wr_th<8, 2, 2>(p, r, a, st);
+    else launch_wr_th<8, 2, 4>(p, r, a, st);
+  } else if (th == 16) {
+    launch_wr_th<16, 1, 1>(p, r, a, st);
+  } else {
+    if (ks == 1) launch_wr_th<8, 1, 1>(p, r, a, st);
+    else if (ks == 2) launch_wr_th<8, 1, 2>(p, r, a, st);
+    else launch_wr_th<8, 1, 4>(p, r, a, st);
+  }
   TG_CHECK_LAUNCH();
 }

@@ -195,15 +195,41 @@ def pack_wide_frag(w, w_frag, Cout, Cin, flip):
 
 
 def conv3x3_wide_frag_ok(desc):
-    """Shapes tg_conv3x3_wide_frag covers: wide 3x3 stride-1 SAME bf16 layers on images larger than 8x8."""
+    """Shapes tg_conv3x3_wide_frag covers: wide 3x3 stride-1 SAME bf16 layers on images larger than 8x8, or of exactly 8x8
+    pixels (packed tiles)."""
     return (desc.KH == 3 and desc.KW == 3 and desc.stride == 1 and desc.Cin % 32 == 0 and desc.Cin > 64 and desc.Cout % 64 == 0
-            and desc.in_dtype == 1 and desc.out_dtype == 1 and desc.Hin > 8 and desc.Win > 8)
+            and desc.in_dtype == 1 and desc.out_dtype == 1
+            and ((desc.Hin > 8 and desc.Win > 8) or (desc.Hin == 8 and desc.Win == 8)))
 
 
-def conv3x3_wide_frag(desc, x, w_frag, bias, res, aux, out, tile_rows=0):
+def conv3x3_wide_frag(desc, x, w_frag, bias, res, aux, out, tile_rows=0, ksplit=0):
     """tg_conv_forward's result for a wide 3x3 layer, weights streamed into registers from the fragment-order copy."""
-    check(lib().tg_conv3x3_wide_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), tile_rows, _stream()),
-          "tg_conv3x3_wide_frag")
+    check(lib().tg_conv3x3_wide_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), tile_rows, ksplit,
+                                     _stream()), "tg_conv3x3_wide_frag")
+    return out
+
+
+def pack_taps_frag(w, w_frag, taps, Cout, Cin):
+    """Fragment-order copy of a [taps][Cout][Cin] bf16 conv operand (csrc/conv4x4s2.hip)."""
+    assert w.dtype == torch.bfloat16 and w_frag.dtype == torch.bfloat16 and w.numel() == taps * Cout * Cin == w_frag.numel()
+    check(lib().tg_pack_taps_frag(_p(w), _p(w_frag), taps, Cout, Cin, _stream()), "tg_pack_taps_frag")
+    return w_frag
+
+
+def conv4x4s2_frag_ok(desc):
+    """Shapes tg_conv4x4s2_frag covers: the discriminator's 4x4 stride-2 bf16 convs (even sizes) and their input gradients."""
+    if not (desc.KH == 4 and desc.KW == 4 and desc.stride == 2 and desc.pad_t == 1 and desc.pad_l == 1 and desc.Cin % 32 == 0
+            and desc.Cout % 64 == 0 and desc.in_dtype == 1 and desc.out_dtype == 1):
+        return False
+    if desc.mode == 0:
+        return desc.Hin % 2 == 0 and desc.Win % 2 == 0 and desc.Hout * 2 == desc.Hin and desc.Wout * 2 == desc.Win
+    return desc.Hout == 2 * desc.Hin and desc.Wout == 2 * desc.Win
+
+
+def conv4x4s2_frag(desc, x, w_frag, bias, res, aux, out):
+    """tg_conv_forward's result for a 4x4 stride-2 layer (either direction), weights streamed into registers."""
+    check(lib().tg_conv4x4s2_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), _stream()),
+          "tg_conv4x4s2_frag")
     return out
 
 

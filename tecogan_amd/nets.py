@@ -43,8 +43,10 @@ def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, o
     if out is None:
         out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
     d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha, flags=flags)
-    wf = ps.packed_wide(wname, True) if WIDE_FRAG else None
-    if wf is not None and K.conv3x3_wide_frag_ok(d):
+    wf = ps.packed_wide(wname, True) if (WIDE_FRAG or k == 4) else None
+    if wf is not None and k == 4 and K.conv4x4s2_frag_ok(d):
+        K.conv4x4s2_frag(d, x, wf, ps.view(bname) if bname else None, res, None, out)
+    elif wf is not None and k == 3 and K.conv3x3_wide_frag_ok(d):
         K.conv3x3_wide_frag(d, x, wf, ps.view(bname) if bname else None, res, None, out)
     else:
         K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
@@ -63,8 +65,10 @@ def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=A
     dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, Ho, Wo, Co, H, W, e["Apad"], k, k, stride, pt, pl, 1, K.dt(dy), K.dt(dx), 0, 0.0,
                     mask_act, mask_alpha, flags=flags)
-    wf = ps.packed_wide(wname, False) if WIDE_FRAG else None
-    if wf is not None and K.conv3x3_wide_frag_ok(d):
+    wf = ps.packed_wide(wname, False) if (WIDE_FRAG or k == 4) else None
+    if wf is not None and k == 4 and K.conv4x4s2_frag_ok(d):
+        K.conv4x4s2_frag(d, dy, wf, None, res, aux, dx)
+    elif wf is not None and k == 3 and K.conv3x3_wide_frag_ok(d):
         K.conv3x3_wide_frag(d, dy, wf, None, res, aux, dx)
     else:
         K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)

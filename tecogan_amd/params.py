@@ -12,6 +12,7 @@ launches for the whole store, the transposed (`wT`) and natural (`wN`) compute c
 activation dtype with first-layer input channels zero-padded to a multiple of 8.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -19,6 +20,7 @@ import torch
 from . import kernels as K
 
 SCOPES = ("generator", "fnet", "tdiscriminator")
+K4S2_FRAG = os.environ.get("TG_K4S2_FRAG", "1") != "0"      # A/B against conv_igemm.hip for the discriminator's stride-2 convs
 
 FNET_BLOCKS = [("encoder_1", 6, 32), ("encoder_2", 32, 64), ("encoder_3", 64, 128),
                ("decoder_1", 128, 256), ("decoder_2", 256, 128), ("decoder_3", 128, 64)]
@@ -238,6 +240,20 @@ class ParamStore:
             K.pack_weights_both(self.flat, self.wT, self.wN, self.table, self.ntab)
         if self.frag:
             K.pack_weights_frag(self.flat, self.wTf, self.wNf, self.frag_table, len(self.frag))
+        if self.act_dtype == torch.bfloat16 and K4S2_FRAG:
+            # the discriminator's 4x4 stride-2 convs (csrc/conv4x4s2.hip): fragment-order copies of both operands, refreshed with
+            # the other compute copies (trainable weights: every step)
+            for name, e in self.entries.items():
+                if e.get("taps") != 16 or e["Apad"] != e["A"] or e["Bpad"] != e["B"]:
+                    continue
+                A, B = e["A"], e["B"]
+                if A % 64 or B % 64:
+                    continue
+                w = self.wide.setdefault(name, [None, None])
+                for k, (co, ci) in enumerate(((B, A), (A, B))):     # forward: [16][B][A]; input gradient: [16][A][B]
+                    if w[k] is None:
+                        w[k] = torch.empty(16 * A * B, device=self.device, dtype=torch.bfloat16)
+                    K.pack_taps_frag(self.packed(name, k == 0), w[k], 16, co, ci)
         if self.wide_frag:
             for name, e in self.entries.items():
                 if e.get("taps") != 9 or e["Apad"] != e["A"] or e["Bpad"] != e["B"]:
