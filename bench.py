@@ -43,7 +43,7 @@ def _newest(*names):
 
 
 # rocprofv3 --pmc passes summarised by tools/pmc_summary.py (newest session first)
-PMC_FILES = {"train": _newest("r04_pmc_train.json", "r03_pmc_train.json", "r02u_pmc_train.json"),
+PMC_FILES = {"train": _newest("r05_pmc_train.json", "r04_pmc_train.json", "r03_pmc_train.json", "r02u_pmc_train.json"),
              "infer": _newest("r04_pmc_infer.json", "r03_pmc_infer.json", "r02u_pmc_infer.json")}
 
 
@@ -254,8 +254,9 @@ FAMILIES = (                  # kernel-name prefix -> family (what the launch is
     ("deconv_bwd_lat", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
     ("warp_s2d", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
     ("conv3x3_tile<bf16,bf16,4,16", "recurrent chain (residual blocks, HR tails, warp, input conv: latency regime)"),
-    ("conv3x3_dma_pack", "VGG-19 conv5 / FNet inner levels (packed 8x8 / 4x4 images)"),
-    ("conv3x3_dma", "VGG-19 wide layers conv2_2..conv4_4 + FNet wide levels (LDS-DMA conv)"),
+    ("conv3x3_wr", "VGG-19 wide layers conv2_2..conv5_4 (weights-in-registers conv, round 5)"),
+    ("conv3x3_dma_pack", "FNet inner levels (packed 8x8 / 4x4 images, LDS-DMA conv)"),
+    ("conv3x3_dma", "FNet wide levels (LDS-DMA conv)"),
     ("conv3x3_ws", "64-channel throughput convs (VGG conv1_2 / conv2_1, D input conv, FNet 64-ch levels)"),
     ("conv3x3_c8", "8-channel input convs (VGG conv1_1, padded 3-channel tensors)"),
     ("conv4x4s2", "discriminator stride-2 4x4 convs (forward / input gradient)"),
@@ -295,8 +296,14 @@ def build_roofline(config, dtype, device, with_inference):
     r = roofline_entry(dom, nstep, dtype, pmc)
     r["share_of_profiled_kernel_time"] = round(dom["total_us"] / tot, 4)
     r["source"] = ("dispatch start/stop timestamps (hipExtLaunchKernel events on the launch stream) of every instrumented "
-                   "launch of %d eager steps of the timed workload; committed rocprofv3 summaries: profiles/r04_*_kernel_stats.txt" % nstep)
+                   "launch of %d eager steps of the timed workload; committed rocprofv3 summaries: profiles/r05_*_kernel_stats.txt" % nstep)
     r["top_kernels"] = [roofline_entry(e, nstep, dtype, pmc) for e in ents[1:6]]
+    # The dominant launch by time is the recurrent chain's latency-regime node since round 5 (the VGG convs it used to tie with
+    # got faster): beside it, the dominant THROUGHPUT-regime kernel -- the one whose fraction of the MFMA peak says how well the
+    # matrix cores are used where they can be (the chain node is bound by its kernel boundary and per-CU weight stream)
+    thr = [e for e in ents if e["flops"] > 0 and not any(e["name"].startswith(p) for p, f in FAMILIES if f.startswith("recurrent chain"))]
+    if thr:
+        r["throughput_kernel"] = roofline_entry(thr[0], nstep, dtype, pmc)
     mf = [e for e in ents if e["flops"] > 0]
     r["all_mfma_kernels"] = {"flop_per_step": sum(e["flops"] for e in mf) / nstep,
                              "us_per_step": round(sum(e["total_us"] for e in mf) / nstep, 1),

@@ -34,6 +34,8 @@ struct C4P {
   float nslope, mslope;
   int tiles_y, tiles_x, nblk, nunits, u8;
   unsigned in_bytes, w_bytes, out_bytes;
+  float* stats;       // forward, nullable: [2][Cout] += per-channel mean and second moment of the (pre-activation) result
+  float inv_rows;     // 1 / (N Ho Wo)
 };
 
 typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
@@ -214,6 +216,36 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_fwd_kernel(C4P p) {
     const unsigned off = (y < p.Ho && x < p.Wo) ? (unsigned)((((n * p.Ho + y) * p.Wo + x) * p.Cout + co) * 2) : C4_OOB;
     c4_store<HAS_RES, false>(acc[i], bv, p.nslope, 1.f, off, rsrcO, rsrcR, rsrcR);
   }
+  // Batch-norm statistics of the layer (lib/ops.py:88-90 after lib/Teco.py:37): per-channel sum and sum of squares of conv + bias
+  // from the fp32 accumulators -- the 16 lanes of a channel quad hold the tile's 16 columns -- one atomic pair per channel and wave.
+  // (tg_bn_lrelu_forward then skips its two reduction launches: 2 x 9.6 us per layer and pass.)
+  if (p.stats) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < F_TH; ++i) {
+      const bool ok = ybase + i < p.Ho && x < p.Wo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ok ? acc[i][r] + bv[r] : 0.f;
+        s1[r] += v;
+        s2[r] += v * v;
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] += __shfl_xor(s1[r], m, 64);
+        s2[r] += __shfl_xor(s2[r], m, 64);
+      }
+    if (frow == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsafeAtomicAdd(p.stats + co + r, s1[r] * p.inv_rows);
+        unsafeAtomicAdd(p.stats + p.Cout + co + r, s2[r] * p.inv_rows);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -381,7 +413,7 @@ extern "C" int tg_pack_taps_frag(const void* w, void* w_frag, int taps, int Cout
 }
 
 extern "C" int tg_conv4x4s2_frag(const tg_conv_desc* d, const void* in, const void* w_frag, const float* bias, const void* res,
-                                 const void* aux, void* out, void* stream) {
+                                 const void* aux, void* out, float* bn_stats, void* stream) {
   TG_CHECK_ARG(d && in && w_frag && out, "null pointer");
   TG_CHECK_ARG(d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad_t == 1 && d->pad_l == 1, "4x4 stride-2 convolutions with pad 1 only");
   TG_CHECK_ARG(d->in_dtype == TG_BF16 && d->out_dtype == TG_BF16, "bf16 tensors only");
@@ -395,7 +427,9 @@ extern "C" int tg_conv4x4s2_frag(const tg_conv_desc* d, const void* in, const vo
   } else {
     TG_CHECK_ARG(d->Hout == 2 * d->Hin && d->Wout == 2 * d->Win, "input gradient: output = 2 x input");
     TG_CHECK_ARG(!bias && d->act == TG_ACT_NONE, "input-gradient epilogue: residual and activation mask only");
+    TG_CHECK_ARG(!bn_stats, "batch-norm statistics belong to the forward conv");
   }
+  TG_CHECK_ARG(!bn_stats || (d->act == TG_ACT_NONE && !res), "batch-norm statistics: of conv + bias (no activation, no residual)");
   const int64_t in_bytes = (int64_t)d->N * d->Hin * d->Win * d->Cin * 2, out_bytes = (int64_t)d->N * d->Hout * d->Wout * d->Cout * 2;
   const int64_t w_bytes = (int64_t)16 * d->Cout * d->Cin * 2;
   TG_CHECK_ARG(in_bytes < ((int64_t)1 << 31) && out_bytes < ((int64_t)1 << 31), "tensor too large for 32-bit buffer offsets");
@@ -404,6 +438,8 @@ extern "C" int tg_conv4x4s2_frag(const tg_conv_desc* d, const void* in, const vo
   p.N = d->N; p.H = d->Hin; p.W = d->Win; p.Cin = d->Cin; p.Cout = d->Cout; p.Ho = d->Hout; p.Wo = d->Wout;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
+  p.stats = bn_stats;
+  p.inv_rows = (float)(1.0 / ((double)d->N * d->Hout * d->Wout));
   p.nblk = p.Cout / 64;
   if (fwd) {
     p.tiles_x = (p.Wo + 15) / 16;

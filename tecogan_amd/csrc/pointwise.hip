@@ -563,6 +563,12 @@ __global__ __launch_bounds__(256) void bn_stats_x8_kernel(const u16* __restrict_
   }
 }
 
+// stats[C + c] holds E[x^2] (accumulated by the producing conv's epilogue): -> biased variance E[x^2] - mean^2
+__global__ __launch_bounds__(256) void bn_moment_to_var_kernel(float* __restrict__ stats, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) stats[C + c] = fmaxf(stats[C + c] - stats[c] * stats[c], 0.f);
+}
+
 __global__ __launch_bounds__(256) void bn_lrelu_apply_x8_kernel(const u16* __restrict__ x, u16* __restrict__ y,
                                                                 int64_t rows, int C, const float* __restrict__ beta,
                                                                 const float* __restrict__ stats, float eps, float alpha,
@@ -957,6 +963,15 @@ extern "C" int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t ro
   if (!prezeroed && hipMemsetAsync(stats, 0, sizeof(float) * 2 * C, ST(stream)) != hipSuccess) {
     tg_set_error("tg_bn_lrelu_forward: memset failed");
     return TG_ELAUNCH;
+  }
+  TG_CHECK_ARG(prezeroed != 2 || bn_x8_ok(dtype, C, x, y, nullptr, nullptr), "prezeroed = 2 (statistics given): bf16, C % 8 == 0 only");
+  if (prezeroed == 2) {
+    const int OC = C / 8;
+    const dim3 eg8(grid_1d(rows * OC, 256, 2048));
+    hipLaunchKernelGGL(bn_moment_to_var_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), stats, C);
+    hipLaunchKernelGGL(bn_lrelu_apply_x8_kernel, eg8, dim3(256), 0, ST(stream), (const u16*)x, (u16*)y, rows, C, beta, stats,
+                       eps, alpha, moving);
+    TG_CHECK_LAUNCH();
   }
   if (bn_x8_ok(dtype, C, x, y, nullptr, nullptr)) {
     const int OC = C / 8, RP = 256 / OC;

@@ -226,9 +226,10 @@ def conv4x4s2_frag_ok(desc):
     return desc.Hout == 2 * desc.Hin and desc.Wout == 2 * desc.Win
 
 
-def conv4x4s2_frag(desc, x, w_frag, bias, res, aux, out):
-    """tg_conv_forward's result for a 4x4 stride-2 layer (either direction), weights streamed into registers."""
-    check(lib().tg_conv4x4s2_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), _stream()),
+def conv4x4s2_frag(desc, x, w_frag, bias, res, aux, out, bn_stats=None):
+    """tg_conv_forward's result for a 4x4 stride-2 layer (either direction), weights streamed into registers.  bn_stats (forward,
+    [2][Cout] fp32, zero on entry) += the per-channel mean and second moment of the result: bn_lrelu_forward(..., prezeroed=2)."""
+    check(lib().tg_conv4x4s2_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), _p(bn_stats), _stream()),
           "tg_conv4x4s2_frag")
     return out
 

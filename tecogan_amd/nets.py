@@ -28,8 +28,13 @@ def _empty(shape, dtype, like):
 # --------------------------------------------------------------------------------------------------
 # layer primitives
 # --------------------------------------------------------------------------------------------------
-# wide frozen 3x3 layers (VGG-19 conv2_2 ... conv4_4) through csrc/conv3x3_wr.hip when the store keeps fragment-order copies
-WIDE_FRAG = os.environ.get("TG_WIDE_FRAG", "1") != "0"      # A/B against conv3x3_dma.hip
+# Kernel choices settled by same-box A/Bs (plain attributes: tools/mb_vgg.py --no-wide and the like set them):
+# wide frozen 3x3 layers (VGG-19 conv2_2 ... conv5_4) through csrc/conv3x3_wr.hip when the store keeps fragment-order copies
+# (conv3x3_dma.hip without: VGG pass of 48 images 1650 -> 1517 us, profiles/r05c_mb_vgg.txt)
+WIDE_FRAG = True
+# the discriminator's batch-norm statistics from the epilogue of its 4x4 stride-2 convs (csrc/conv4x4s2.hip) instead of two
+# reduction launches per layer and pass (fwd_loss 0.615 -> 0.581 ms, profiles/r05h_seg_timeline.txt)
+BN_STATS_IN_CONV = True
 
 
 def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, out_dtype=None, out=None, flags=0):
@@ -508,9 +513,21 @@ class Discriminator:
                      flags=flags, out=into["a"] if into else None)
         saved, layers, net = [], [], a
         for bi, (name, _, co) in enumerate(DIS_BLOCKS):
-            c = conv_fwd(ps, p + name + "/conv1/Conv/weights", None, net, 2, flags=flags, out=into["c"][bi] if into else None)
+            wname = p + name + "/conv1/Conv/weights"
+            stats, pz = self._ws(co, net)
+            wf = ps.packed_wide(wname, True) if BN_STATS_IN_CONV else None
+            N, H, W, Cp = net.shape
+            d = K.conv_desc(N, H, W, Cp, H // 2, W // 2, co, 4, 4, 2, 1, 1, 0, K.dt(net), K.dt(net), flags=flags)
+            if wf is not None and H % 2 == 0 and W % 2 == 0 and K.conv4x4s2_frag_ok(d):
+                # the conv's epilogue leaves the batch statistics in `stats`: no reduction launches in the batch norm
+                if not pz:
+                    stats.zero_()
+                c = into["c"][bi] if into else _empty((N, H // 2, W // 2, co), ps.act_dtype, net)
+                K.conv4x4s2_frag(d, net, wf, None, None, None, c, bn_stats=stats)
+                pz = 2
+            else:
+                c = conv_fwd(ps, wname, None, net, 2, flags=flags, out=into["c"][bi] if into else None)
             y = into["y"][bi] if into else torch.empty_like(c)
-            stats, pz = self._ws(co, c)
             K.bn_lrelu_forward(c, y, ps.view(p + name + "/BatchNorm/beta"), 1e-3, 0.2, stats,
                                self.moving[bi] if update_moving else None, prezeroed=pz)
             saved.append((net, c, y, stats))

@@ -20,7 +20,8 @@ import torch
 from . import kernels as K
 
 SCOPES = ("generator", "fnet", "tdiscriminator")
-K4S2_FRAG = os.environ.get("TG_K4S2_FRAG", "1") != "0"      # A/B against conv_igemm.hip for the discriminator's stride-2 convs
+K4S2_FRAG = True      # fragment-order copies of the discriminator's 4x4 stride-2 weights (csrc/conv4x4s2.hip; conv_igemm.hip without: 2.20 -> 2.01 ms of
+                      # main-stream discriminator segments, profiles/r05f_seg_timeline.txt); a plain attribute, set by A/B tools
 
 FNET_BLOCKS = [("encoder_1", 6, 32), ("encoder_2", 32, 64), ("encoder_3", 64, 128),
                ("decoder_1", 128, 256), ("decoder_2", 256, 128), ("decoder_3", 128, 64)]

@@ -20,7 +20,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, nargs="*", default=[20, 32, 44, 76])
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--flags", type=int, default=0, help="1 = TG_CONV_COEXIST tiles")
+ap.add_argument("--no-wide", action="store_true", help="wide layers on conv3x3_dma.hip instead of conv3x3_wr.hip (the round-4 path)")
 a = ap.parse_args()
+if a.no_wide:
+    import tecogan_amd.nets as _nets
+    _nets.WIDE_FRAG = False
 dev = "cuda"
 vps = ParamStore(OrderedDict(vgg=vgg_spec()), dev, torch.bfloat16, trainable=False, wide_frag=True)
 vps.load(init_values(vgg_spec(), 45, he_normal=True))
