@@ -142,9 +142,21 @@ int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const void* w_fr
  *     accumulators -- the batch statistics slim.batch_norm takes next (lib/ops.py:88-90); tg_bn_lrelu_forward(prezeroed = 2)
  *     turns them into [mean, biased variance] and skips its own two reduction launches. */
 int tg_pack_taps_frag(const void* w, void* w_frag, int taps, int Cout, int Cin, void* stream);
+/* The same for `count` tensors in one launch (the per-step refresh of the discriminator's eight operands): tab (device) = 5 x int64
+ * per tensor {source element offset -- in src_t, or in src_n when bit 62 is set --, destination element offset in dst, taps, Cout,
+ * Cin}; all offsets multiples of 8 elements. */
+int tg_pack_taps_frag_multi(const void* src_t, const void* src_n, void* dst, const int64_t* tab, int count, void* stream);
 int tg_conv4x4s2_frag(const tg_conv_desc* d, const void* in, const void* w_frag, const float* bias /*nullable*/,
                       const void* res /*nullable*/, const void* aux /*nullable*/, void* out, float* bn_stats /*nullable*/,
                       void* stream);
+
+/* One residual block of generator_F, out = x + conv3x3(relu(conv3x3(x, W1) + b1), W2) + b2 (reference lib/frvsr.py:50-57), as ONE
+ * launch in the THROUGHPUT regime (csrc/resblock_thr.hip): the inference step's 16 blocks at [1,270,480,64] (main.py:195-216).
+ * bf16, 64 channels; w1_frag / w2_frag = the fragment-order forward operands written by tg_pack_weights_frag (dst_t), the ones
+ * tg_conv3x3_c64_frag takes.  The intermediate never leaves the CU (rounded to bf16 once, as the two-launch path stores it); the
+ * result equals two tg_conv3x3_c64_frag launches up to the summation order inside each conv.  x and out must not alias. */
+int tg_resblock_c64_thr(const void* x, const void* w1_frag, const float* b1 /*nullable*/, const void* w2_frag,
+                        const float* b2 /*nullable*/, void* out, int N, int H, int W, void* stream);
 
 /* Weight gradient of the gather-form convolution described by `d`
  * (X = the tensor that is gathered, [N,Hin,Win,Cin]; Y = per-output-pixel tensor

@@ -57,7 +57,9 @@ SIGNATURES = {
     "tg_pack_wide_frag": [_P, _P, _I, _I, _I, _P],
     "tg_conv3x3_wide_frag": [_D, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "tg_pack_taps_frag": [_P, _P, _I, _I, _I, _P],
+    "tg_pack_taps_frag_multi": [_P, _P, _P, _P, _I, _P],
     "tg_conv4x4s2_frag": [_D, _P, _P, _P, _P, _P, _P, _P, _P],
+    "tg_resblock_c64_thr": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tg_hr_tail_train": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "tg_act_backward": [_P, _P, _P, _I, _I, _L, _I, _F, _F, _P],
     "tg_concat2_pad": [_P, _I, _P, _I, _P, _I, _I, _L, _F, _P],

@@ -402,6 +402,35 @@ __global__ void pack_taps_frag_kernel(const uint4* __restrict__ src, uint4* __re
   dst[i] = src[(((long)t * Cout + g * 16 + (lane & 15)) * Cin + c * 32 + (lane >> 4) * 8) >> 3];
 }
 
+// several tensors in one launch (blockIdx.y = tensor): tab = 5 x int64 per tensor {source element offset in src_t (which = 0) or
+// src_n (which = 1), destination element offset in dst, taps, Cout, Cin} with which = bit 62 of the first entry
+__global__ void pack_taps_frag_multi_kernel(const u16* __restrict__ src_t, const u16* __restrict__ src_n, u16* __restrict__ dst,
+                                            const int64_t* __restrict__ tab) {
+  const int64_t* t = tab + (int64_t)blockIdx.y * 5;
+  const int64_t so = t[0] & ~((int64_t)1 << 62);
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(((t[0] >> 62) & 1 ? src_n : src_t) + so);
+  uint4* __restrict__ d = reinterpret_cast<uint4*>(dst + t[1]);
+  const int taps = (int)t[2], Cout = (int)t[3], Cin = (int)t[4];
+  const long total = (long)taps * Cout * Cin / 8;
+  const int nchunk = Cin >> 5;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long r = i >> 6;
+    const int tp = (int)(r % taps);
+    r /= taps;
+    const int c = (int)(r % nchunk), g = (int)(r / nchunk);
+    d[i] = src[(((long)tp * Cout + g * 16 + (lane & 15)) * Cin + c * 32 + (lane >> 4) * 8) >> 3];
+  }
+}
+
+extern "C" int tg_pack_taps_frag_multi(const void* src_t, const void* src_n, void* dst, const int64_t* tab, int count, void* stream) {
+  TG_CHECK_ARG(src_t && src_n && dst && tab && count > 0, "bad argument");
+  TG_CHECK_ARG((((uintptr_t)src_t | (uintptr_t)src_n | (uintptr_t)dst) & 15) == 0, "pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(pack_taps_frag_multi_kernel, dim3(32, count), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const u16*>(src_t), static_cast<const u16*>(src_n), static_cast<u16*>(dst), tab);
+  TG_CHECK_LAUNCH();
+}
+
 extern "C" int tg_pack_taps_frag(const void* w, void* w_frag, int taps, int Cout, int Cin, void* stream) {
   TG_CHECK_ARG(w && w_frag && taps > 0 && Cout > 0 && Cout % 16 == 0 && Cin > 0 && Cin % 32 == 0,
                "bf16 [taps][Cout][Cin] with Cout % 16 == 0, Cin % 32 == 0");

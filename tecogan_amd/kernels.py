@@ -216,6 +216,11 @@ def pack_taps_frag(w, w_frag, taps, Cout, Cin):
     return w_frag
 
 
+def pack_taps_frag_multi(src_t, src_n, dst, tab, count):
+    """Fragment-order copies of `count` operands taken from the two flat compute-copy buffers, one launch (see the header)."""
+    check(lib().tg_pack_taps_frag_multi(_p(src_t), _p(src_n), _p(dst), _p(tab), count, _stream()), "tg_pack_taps_frag_multi")
+
+
 def conv4x4s2_frag_ok(desc):
     """Shapes tg_conv4x4s2_frag covers: the discriminator's 4x4 stride-2 bf16 convs (even sizes) and their input gradients."""
     if not (desc.KH == 4 and desc.KW == 4 and desc.stride == 2 and desc.pad_t == 1 and desc.pad_l == 1 and desc.Cin % 32 == 0
@@ -231,6 +236,14 @@ def conv4x4s2_frag(desc, x, w_frag, bias, res, aux, out, bn_stats=None):
     [2][Cout] fp32, zero on entry) += the per-channel mean and second moment of the result: bn_lrelu_forward(..., prezeroed=2)."""
     check(lib().tg_conv4x4s2_frag(C.byref(desc), _p(x), _p(w_frag), _p(bias), _p(res), _p(aux), _p(out), _p(bn_stats), _stream()),
           "tg_conv4x4s2_frag")
+    return out
+
+
+def resblock_c64_thr(x, w1_frag, b1, w2_frag, b2, out):
+    """out = x + conv3x3(relu(conv3x3(x, W1) + b1), W2) + b2 in one launch, throughput regime (csrc/resblock_thr.hip; bf16, 64 ch)."""
+    N, H, W, C = x.shape
+    assert C == 64 and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tuple(out.shape) == tuple(x.shape)
+    check(lib().tg_resblock_c64_thr(_p(x), _p(w1_frag), _p(b1), _p(w2_frag), _p(b2), _p(out), N, H, W, _stream()), "tg_resblock_c64_thr")
     return out
 
 

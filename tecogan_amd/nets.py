@@ -168,6 +168,7 @@ class Generator:
         self.grouped_wgrad = True
         self.hr_tail = True
         self.ws_frag = True
+        self.fused_block = True        # throughput regime (inference): a residual block as ONE launch (csrc/resblock_thr.hip)
         self.resblock_lat = self.hr_fwd_lat = self.hr_bwd_lat = True
         self.resblock_max_tiles = 1024          # 4x4-pixel tiles up to which one workgroup per tile is the latency-optimal shape
         # scheduling hint for the recurrence's own launches (forward_t / backward_t): K.CONV_COEXIST when throughput work
@@ -187,8 +188,14 @@ class Generator:
         #  green, 35.2 us per block against 35.3 us for these two launches: bound by 2-way-conflicted LDS fragment reads under
         #  the gfx950 ds_read_b128 lane grouping; numbers and cycle stamps in profiles/r03p_resblock_ws.txt, kernel deleted)
         wsf = self.ws_frag and ps.frag and a.dtype == torch.bfloat16 and K.conv3x3_c64_frag_ok(*a.shape[:3])
+        bufs = [torch.empty_like(a), torch.empty_like(a)] if (wsf and self.fused_block) else None
         for i in range(1, self.nres + 1):
             s = p + "resblock_%d/" % i
+            if bufs is not None:
+                # the whole block in one launch, intermediate in LDS (csrc/resblock_thr.hip; not in place: ping-pong buffers)
+                a = K.resblock_c64_thr(a, ps.packed_frag(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
+                                       ps.packed_frag(s + "conv_2/Conv/weights", True), ps.view(s + "conv_2/Conv/biases"), bufs[i & 1])
+                continue
             if wsf:
                 # same kernel, weights in fragment order: whole-line weight loads, two workgroups per CU (csrc/conv3x3_ws.hip)
                 r = K.conv3x3_c64_frag(a, ps.packed_frag(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"), None,

@@ -142,6 +142,7 @@ class ParamStore:
         self.device, self.act_dtype, self.trainable = device, act_dtype, trainable
         self.wide_frag = bool(wide_frag) and act_dtype == torch.bfloat16
         self.wide = {}                                             # name -> [forward copy or None, input-gradient copy or None]
+        self._k4 = None                                            # (flat buffer, table, count) of the 4x4 stride-2 copies
         self.entries = OrderedDict()
         self.scope_range = OrderedDict()
         off = poff = 0
@@ -243,18 +244,24 @@ class ParamStore:
             K.pack_weights_frag(self.flat, self.wTf, self.wNf, self.frag_table, len(self.frag))
         if self.act_dtype == torch.bfloat16 and K4S2_FRAG:
             # the discriminator's 4x4 stride-2 convs (csrc/conv4x4s2.hip): fragment-order copies of both operands, refreshed with
-            # the other compute copies (trainable weights: every step)
-            for name, e in self.entries.items():
-                if e.get("taps") != 16 or e["Apad"] != e["A"] or e["Bpad"] != e["B"]:
-                    continue
-                A, B = e["A"], e["B"]
-                if A % 64 or B % 64:
-                    continue
-                w = self.wide.setdefault(name, [None, None])
-                for k, (co, ci) in enumerate(((B, A), (A, B))):     # forward: [16][B][A]; input gradient: [16][A][B]
-                    if w[k] is None:
-                        w[k] = torch.empty(16 * A * B, device=self.device, dtype=torch.bfloat16)
-                    K.pack_taps_frag(self.packed(name, k == 0), w[k], 16, co, ci)
+            # the other compute copies (trainable weights: every step) -- all of them in ONE launch, out of wT / wN
+            if self._k4 is None:
+                rows, off = [], 0
+                for name, e in self.entries.items():
+                    if e.get("taps") != 16 or e["Apad"] != e["A"] or e["Bpad"] != e["B"] or e["A"] % 64 or e["B"] % 64:
+                        continue
+                    A, B, n = e["A"], e["B"], 16 * e["A"] * e["B"]
+                    rows.append([e["packed"], off, 16, B, A])                       # forward operand: wT [16][B][A]
+                    rows.append([e["packed"] | (1 << 62), off + n, 16, A, B])       # input gradient: wN [16][A][B]
+                    self.wide[name] = [off, off + n, n]
+                    off += 2 * n
+                buf = torch.empty(max(off, 8), device=self.device, dtype=torch.bfloat16)
+                for name, w in list(self.wide.items()):
+                    if len(w) == 3:
+                        self.wide[name] = [buf[w[0]:w[0] + w[2]], buf[w[1]:w[1] + w[2]]]
+                self._k4 = (buf, torch.tensor(rows or [[0, 0, 16, 16, 32]], dtype=torch.int64, device=self.device).contiguous(), len(rows))
+            if self._k4[2]:
+                K.pack_taps_frag_multi(self.wT, self.wN, self._k4[0], self._k4[1], self._k4[2])
         if self.wide_frag:
             for name, e in self.entries.items():
                 if e.get("taps") != 9 or e["Apad"] != e["A"] or e["Bpad"] != e["B"]:

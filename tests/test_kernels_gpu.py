@@ -900,6 +900,40 @@ def test_conv3x3_fragment_order_weights_entry_is_bit_identical(shape, has_res, a
     with pytest.raises(Exception):
         K.conv3x3_c64_frag(x[:, :32, :32].contiguous(), K.frag_order(wt), b, None, out[:, :32, :32].contiguous(), act)
 
+@pytest.mark.parametrize("shape", [(1, 270, 480), (2, 128, 136), (1, 250, 131), (3, 6, 14), (1, 5, 3)])
+def test_resblock_throughput_kernel_matches_oracle_and_the_two_launch_path(shape):
+    """tg_resblock_c64_thr (round 5: one residual block of generator_F, lib/frvsr.py:50-57, as one launch at inference resolution, the
+    intermediate in LDS) against the oracle's conv2 chain on the bf16-rounded operands with the intermediate rounded to bf16 (what
+    both paths store), and against two tg_conv_forward launches: same products, fp32 accumulation, one rounding per conv."""
+    N, H, W = shape
+    x = rnd(N, H, W, 64, seed=1).bfloat16()
+    w1 = rnd(3, 3, 64, 64, seed=2, scale=0.08).bfloat16()
+    w2 = rnd(3, 3, 64, 64, seed=3, scale=0.08).bfloat16()
+    b1, b2 = rnd(64, seed=4), rnd(64, seed=5)
+    mid = torch.relu(O.conv2(x.float(), w1.float(), b1, 1)).bfloat16().float()
+    ref = x.float() + O.conv2(mid, w2.float(), b2, 1)
+    wt1 = w1.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV)
+    wt2 = w2.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV)
+    out = torch.full((N, H, W, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    K.prof_collect()
+    K.prof_enable(True)
+    K.resblock_c64_thr(x.to(DEV), K.frag_order(wt1), b1.to(DEV), K.frag_order(wt2), b2.to(DEV), out)
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert ents and ents[0]["name"] == "resblock_thr", ents
+    # the intermediate is rounded to bf16 in both; a different summation order moves a few intermediate values by one bf16 step
+    # (2^-8 relative), which the second conv spreads over its 576-term sums: well below the result's own rounding step
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 4e-3 * ref.abs() + 6e-3).all(), "%s: max err %g at |ref| %g" % (shape, err.max().item(), ref.abs().flatten()[err.argmax()].item())
+    d = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_RELU, 0.0)
+    r = K.conv_forward(d, x.to(DEV), wt1, b1.to(DEV), None, None, torch.empty_like(out))
+    d2 = K.conv_desc(N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_NONE, 0.0)
+    two = K.conv_forward(d2, r, wt2, b2.to(DEV), x.to(DEV), None, torch.empty_like(out))
+    close(out, two.float().cpu(), 8e-3, "one-launch block vs two launches %s" % (shape,))
+    with pytest.raises(Exception):
+        K.resblock_c64_thr(out, K.frag_order(wt1), None, K.frag_order(wt2), None, out)        # in place is refused
+
+
 @pytest.mark.parametrize("B,h,w", [(1, 5, 9), (2, 33, 47), (1, 270, 480)])
 def test_warp_s2d_forward_bf16_vectorised_rows(B, h, w):
     """The LDS-assembled 16-byte-row form (bf16, Cpad 56) incl. pixel counts that are not multiples of 4 / of the grid and

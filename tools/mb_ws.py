@@ -27,6 +27,12 @@ for N, H, W in ((1, 270, 480), (76, 128, 128), (20, 128, 128)):
     if hasattr(K, "conv3x3_c64_frag"):
         tc = graph_timeit(lambda: K.conv3x3_c64_frag(x, wfr, b, None, out, ACT_RELU))
         td = graph_timeit(lambda: K.conv3x3_c64_frag(x, wfr, b, r, out, ACT_NONE))
+    te = float("nan")
+    if hasattr(K, "resblock_c64_thr"):          # the whole residual block as one launch (csrc/resblock_thr.hip)
+        out2 = torch.empty_like(x)
+        te = graph_timeit(lambda: K.resblock_c64_thr(x, wfr, b, wfr, b, out2))
     fl = 2.0 * N * H * W * 64 * 64 * 9
+    print("[%s] residual block [%d,%d,%d]: two launches (fragment-order weights) %6.1f us | one launch %6.1f us (%4.0f TFLOP/s of 2 convs)"
+          % (tag, N, H, W, tc + td, te, 2 * fl / te * 1e-6), flush=True)
     print("[%s] conv 64->64 [%d,%d,%d]: relu %6.1f us (%4.0f TFLOP/s)   +residual %6.1f us | fragment-order weights (per CU %s): %6.1f us  +residual %6.1f us"
           % (tag, N, H, W, ta, fl / ta * 1e-6, tb, "2", tc, td), flush=True)
