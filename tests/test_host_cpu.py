@@ -581,6 +581,84 @@ def test_wgrad_tr_lds_swizzle_is_consistent_and_conflict_free():
                     assert group_conflicts(addrs) == 1
 
 
+def test_round5_halo_layouts_are_consistent_and_conflict_free():
+    """Python mirrors of the LDS layouts the round-5 kernels share (64-byte rows = one 32-channel chunk of a pixel, 16-byte groups
+    XOR-swizzled by 2 * ((position >> 2) & 1); MI355X_MICROARCH.md LDS table for the ds_read_b128 lane groups):
+      * csrc/conv4x4s2.hip forward: the 18 x 34 input halo as two column-parity planes of 18 x 17 positions -- every DMA slot's
+        source pixel, and the fragment (input row r, tap column kw) of lane (frow, fg) = input pixel (r, 2 frow + kw), channels 8 fg..;
+      * csrc/resblock_thr.hip: the intermediate region written from accumulator registers (ds_write_b64: channels 16 wave + 4 fg ..)
+        and read back as fragments by the second conv;
+    every fragment read is conflict-free (each of the four 16-lane groups touches 64 distinct banks exactly once)."""
+    def swz(q):
+        return ((q >> 2) & 1) << 1
+
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+    def conflict_free(addrs):
+        for g in groups:
+            banks = [((addrs[lane] + 4 * w) // 4) % 64 for lane in g for w in range(4)]
+            if len(set(banks)) != 64:
+                return False
+        return True
+
+    def frag_addr(lane, K):                                     # abase[K & 7] + K * 64 of the kernels
+        frow, fg = lane & 15, lane >> 4
+        return frow * 64 + ((fg ^ (((((frow & 7) + (K & 7)) >> 2) & 1) << 1)) << 4) + K * 64
+
+    # ---- conv4x4s2 forward: planes
+    ROWS, PC, PLANE = 18, 17, 18 * 17
+    lds = {}                                                    # byte address -> (input row, input column, channel) as the DMA fills it
+    for inst in range(39):
+        for lane in range(64):
+            S = inst * 64 + lane
+            q, ch = S >> 2, (S & 3) ^ swz(S >> 2)
+            if q >= 2 * PLANE:
+                continue
+            pl, rem = divmod(q, PLANE)
+            r, c = divmod(rem, PC)
+            for b in range(0, 16, 2):
+                lds[inst * 1024 + lane * 16 + b] = (r, 2 * c + pl, ch * 8 + b // 2)
+    seen = set()
+    for kw in range(4):
+        for r in range(ROWS):
+            K = ((kw & 1) * ROWS + r) * PC + (kw >> 1)
+            addrs = [frag_addr(lane, K) for lane in range(64)]
+            for lane in range(64):
+                frow, fg = lane & 15, lane >> 4
+                for e in range(8):
+                    assert lds[addrs[lane] + 2 * e] == (r, 2 * frow + kw, 8 * fg + e), (kw, r, lane)
+                seen.add((r, 2 * frow + kw))
+            assert conflict_free(addrs), (kw, r)
+    assert seen == {(r, c) for r in range(18) for c in range(34)}          # every halo pixel is used, none is missing
+
+    # ---- resblock_thr: the intermediate written by the first conv's epilogue, read by the second conv's fragments
+    MR, MW = 8, 16
+    mid = {}
+    for wave in range(4):
+        cgrp_w, cchunk = (wave & 1) * 2, wave >> 1
+        for m in range(MR):
+            for lane in range(64):
+                frow, fg = lane & 15, lane >> 4
+                q = m * MW + frow
+                a = cchunk * 8704 + q * 64 + (((cgrp_w + (fg >> 1)) ^ swz(q)) << 4) + (fg & 1) * 8
+                for e in range(4):
+                    assert (a + 2 * e) not in mid
+                    mid[a + 2 * e] = (m, frow, 16 * wave + 4 * fg + e)
+    for ks in range(2):
+        for kw in range(3):
+            for mr in range(MR):
+                K = mr * MW + kw
+                addrs = [ks * 8704 + frag_addr(lane, K) for lane in range(64)]
+                assert conflict_free(addrs)
+                for lane in range(64):
+                    frow, fg = lane & 15, lane >> 4
+                    if frow + kw >= MW:
+                        continue                                # columns 14, 15 of the second conv read past the row: discarded outputs
+                    for e in range(8):
+                        assert mid[addrs[lane] + 2 * e] == (mr, frow + kw, 32 * ks + 8 * fg + e)
+
+
 def test_lookahead_promise_is_checked_by_memory_identity_and_version():
     """tecogan_amd/promise.py: an announced next input counts as kept only for the same memory (any view of it),
     unmodified since the announcement; equal values elsewhere, an in-place write, or None do not count."""

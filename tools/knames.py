@@ -29,6 +29,19 @@ def tg_name(k):
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
         return "conv3x3_dma%s<%s>" % ({"2": "_pack2", "4": "_pack4"}.get(m.group(3), ""), ",".join(tags))
+    m = re.search(r"conv3x3_wr_kernel<(true|false), (true|false), (\d+), (\d+), \d+>", k)     # <HAS_RES, HAS_AUX, TH, PK, KS>
+    if m:
+        tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true"]
+        base = "conv3x3_wr_pack2" if m.group(4) == "2" else ("conv3x3_wr" if m.group(3) == "16" else "conv3x3_wr8")
+        return "%s<%s>" % (base, ",".join(tags))
+    m = re.search(r"conv4x4s2_fwd_kernel<(true|false)>", k)
+    if m:
+        return "conv4x4s2_fwd<%s>" % ("res" if m.group(1) == "true" else "")
+    m = re.search(r"conv4x4s2_bwd_kernel<(true|false), (true|false)>", k)
+    if m:
+        return "conv4x4s2_bwd<%s>" % ",".join(t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true")
+    if "resblock_thr_kernel" in k:
+        return "resblock_thr"
     m = re.search(r"conv3x3_c8_kernel<(\d+)>", k)
     if m:
         return "conv3x3_c8<%s>" % m.group(1)
