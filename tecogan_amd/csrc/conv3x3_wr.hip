@@ -39,6 +39,7 @@ struct ConvWrP {
   float mslope;       // act-grad mask: aux > 0 ? 1 : mslope
   int tiles_y, tiles_x, nblk, nunits, u8;
   unsigned in_bytes, w_bytes, out_bytes;
+  int lds_floor;      // host only: dynamic LDS request floor (residency cap beside the latency-bound chain, TG_CONV_COEXIST)
 };
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
@@ -314,9 +315,10 @@ static void launch_wr(const ConvWrP& p, hipStream_t st) {
       : TH == 16 ? (HAS_RES ? (HAS_AUX ? "conv3x3_wr<res,aux>" : "conv3x3_wr<res>") : (HAS_AUX ? "conv3x3_wr<aux>" : "conv3x3_wr<>"))
                  : (HAS_RES ? (HAS_AUX ? "conv3x3_wr8<res,aux>" : "conv3x3_wr8<res>") : (HAS_AUX ? "conv3x3_wr8<aux>" : "conv3x3_wr8<>"));
   const double px = (double)p.N * p.H * p.W;
+  const int lds = LDS > p.lds_floor ? LDS : p.lds_floor;
   TG_LAUNCH(pname, 2.0 * px * p.Cout * 9.0 * p.Cin,
             px * (p.Cin * 2.0 + p.Cout * 2.0 * (1 + HAS_RES + HAS_AUX)) + 18.0 * p.Cin * p.Cout, kern, dim3(8 * p.u8), dim3(256 * KS),
-            LDS, st, p);
+            lds, st, p);
 }
 
 template <int TH, int PK, int KS>
@@ -380,6 +382,11 @@ extern "C" int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const
   p.nunits = (int)nunits;
   p.u8 = (int)((nunits + 7) / 8);
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
+  // Beside the latency-bound recurrent chain (TG_CONV_COEXIST) the launch asks for 56 KB of LDS it does not use: TWO workgroups per
+  // CU instead of three / four, so that a chain workgroup (22 KB, 132 registers) always finds room at once instead of waiting for
+  // one of this kernel's 15-us units to retire.  Same box, alternating runs: TecoGAN step 8.70 / 8.67 -> 8.61 / 8.57 ms and
+  // 8.62 / 8.60 -> 8.52 / 8.50 ms (bwd_b 2.47 -> 2.40); a cap at three (40 KB) or one (80 KB) gains nothing (profiles/r05m_ab.txt).
+  p.lds_floor = (d->flags & TG_CONV_COEXIST) ? 56 * 1024 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool r = res != nullptr, a = aux != nullptr;
   if (packed) {

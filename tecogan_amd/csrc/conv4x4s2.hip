@@ -486,13 +486,17 @@ extern "C" int tg_conv4x4s2_frag(const tg_conv_desc* d, const void* in, const vo
   const double fl = 2.0 * (fwd ? (double)p.N * p.Ho * p.Wo : (double)p.N * p.H * p.W) * 16.0 * p.Cin * p.Cout;
   const double by = (double)in_bytes + (double)out_bytes * (1 + (res != nullptr) + (aux != nullptr)) + (double)w_bytes;
   if (fwd) {
-    constexpr int LDS = 2 * F_HB;
+    constexpr int LDS0 = 2 * F_HB, LDS_MAX = 96 * 1024;
     static bool attr = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
       return true;
     }();
     (void)attr;
+    // TG_CONV_COEXIST (the real-triplet pass runs beside the forward chain): ONE workgroup per CU -- two of them (156 KB) leave no
+    // room for a chain workgroup's 22 KB (the residency cap of conv3x3_wr.hip, same reason): fwd_0 0.89 -> 0.865 ms, step 8.534 /
+    // 8.539 -> 8.511 / 8.514 ms, alternating runs on one box (profiles/r05m_ab.txt)
+    const int LDS = (d->flags & TG_CONV_COEXIST) ? 88 * 1024 : LDS0;
     if (res) TG_LAUNCH("conv4x4s2_fwd<res>", fl, by, (conv4x4s2_fwd_kernel<true>), dim3(8 * p.u8), dim3(256), LDS, st, p);
     else TG_LAUNCH("conv4x4s2_fwd<>", fl, by, (conv4x4s2_fwd_kernel<false>), dim3(8 * p.u8), dim3(256), LDS, st, p);
   } else {

@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 1400 python tools/bf16_trajectory.py --steps 2000 --batches 8 --seeds 3 --out gpurun_out/r05_bf16_trajectory.txt 2>&1 | grep -v "^ROCm\|^HIP\|amdgpu.ids" | tail -30
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+for kb in 0 88 0 88; do AB_TAG="k4_coexist_kb=$kb" TG_K4_COEXIST_KB=$kb timeout 120 python tools/_ab.py 2>&1 | grep "ms/step" | cut -c1-120; done
