@@ -137,10 +137,12 @@ int tg_conv3x3_wide_frag(const tg_conv_desc* d, const void* in, const void* w_fr
  * (mode 0: the W^T copy, mode 1: the HWIO weights as stored).  Cin % 32 == 0, Cout % 64 == 0.
  *   tg_pack_taps_frag: w [taps][Cout][Cin] bf16 -> w_frag[Cout/16][Cin/32][taps][64][8],
  *     w_frag[g][c][t][l][j] = w[t][16 g + l % 16][32 c + 8 (l / 16) + j]  (a wave's weight load = 1 KiB contiguous).
- *   bn_stats (mode 0, nullable; needs act none and no residual): [2][Cout] fp32, ZEROED by the caller; the launch adds the
- *     per-channel mean and second moment (E[v], E[v^2]) of v = conv + bias over all N Ho Wo positions, from the fp32
- *     accumulators -- the batch statistics slim.batch_norm takes next (lib/ops.py:88-90); tg_bn_lrelu_forward(prezeroed = 2)
- *     turns them into [mean, biased variance] and skips its own two reduction launches. */
+ *   bn_stats (mode 0, nullable; needs act none and no residual): [TG_BN_STAT_REPLICAS][2][Cout] fp32, ZEROED by the caller; the
+ *     launch adds the per-channel mean and second moment (E[v], E[v^2]) of v = conv + bias over all N Ho Wo positions, from the
+ *     fp32 accumulators, spread over the replicas (one address per channel would serialise 768 workgroups' atomics) -- the batch
+ *     statistics slim.batch_norm takes next (lib/ops.py:88-90); tg_bn_lrelu_forward(prezeroed = 2) sums the replicas into the
+ *     first one as [mean, biased variance] and skips its own two reduction launches. */
+#define TG_BN_STAT_REPLICAS 16
 int tg_pack_taps_frag(const void* w, void* w_frag, int taps, int Cout, int Cin, void* stream);
 /* The same for `count` tensors in one launch (the per-step refresh of the discriminator's eight operands): tab (device) = 5 x int64
  * per tensor {source element offset -- in src_t, or in src_n when bit 62 is set --, destination element offset in dst, taps, Cout,
@@ -341,8 +343,9 @@ int tg_dt_ratio(const double* state, float r0, float add, float rmax, float* out
 int tg_bn_lrelu_forward(const void* x, void* y, int dtype, int64_t rows, int C, const float* beta, float eps,
                         float alpha, float* stats, float* moving /*[2][C] nullable, decay .9*/,
                         int prezeroed /*1: caller guarantees stats == 0 on entry (no memset node); 2 (bf16, C % 8 == 0): stats
-                        already hold [mean, second moment] of x (tg_conv4x4s2_frag's bn_stats): one tiny launch turns the moment
-                        into the biased variance, the two reduction launches are skipped*/, void* stream);
+                        = [TG_BN_STAT_REPLICAS][2][C] holding partial [mean, second moment] of x (tg_conv4x4s2_frag's bn_stats):
+                        one tiny launch sums them into stats[0] = [mean, biased variance], the two reduction launches are
+                        skipped*/, void* stream);
 int tg_bn_lrelu_backward(const void* x, const void* y, const void* d_y, void* d_x, int dtype, int64_t rows, int C,
                          const float* stats, float eps, float alpha, float* d_beta /*+=*/,
                          float* ws /*[2][C] scratch*/, int prezeroed /*1: ws == 0 on entry*/, void* stream);

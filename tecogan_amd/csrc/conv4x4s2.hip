@@ -58,10 +58,12 @@ constexpr int F_INST = (F_HALO * 4 + 63) / 64, F_ROUNDS = (F_INST + 3) / 4, F_HB
 constexpr int B_TH = 4, B_HR = B_TH + 2, B_HW = 18, B_HALO = B_HR * B_HW;                               // 108
 constexpr int B_INST = (B_HALO * 4 + 63) / 64, B_ROUNDS = (B_INST + 3) / 4, B_HB = B_ROUNDS * 4 * 1024; // 7, 2, 8192
 
-// common epilogue of one accumulator tile: bias, activation, residual, mask, bf16 pack, 8-byte store
+// common epilogue of one accumulator tile: bias, activation, residual, mask, bf16 pack, 8-byte store.  The residual / mask
+// operands are loaded by the CALLER for all tiles before the first store (a load issued between two stores waits for the store
+// ahead of it: 16 dependent round trips per wave, measured as 89 us in the step for a launch that takes 27 us alone).
 template <bool HAS_RES, bool HAS_AUX, typename RS>
 __device__ __forceinline__ void c4_store(const f32x4& a, const float (&bv)[4], float nslope, float mslope, unsigned off, const RS& rsO,
-                                         const RS& rsR, const RS& rsM) {
+                                         const u32x2c& rr, const u32x2c& aa) {
   float v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -69,14 +71,12 @@ __device__ __forceinline__ void c4_store(const f32x4& a, const float (&bv)[4], f
     v[r] = fmaxf(v[r], v[r] * nslope);
   }
   if constexpr (HAS_RES) {
-    const u32x2c rr = __builtin_amdgcn_raw_buffer_load_b64(rsR, (int)off, 0, 0);
     v[0] += __uint_as_float(rr.x << 16);
     v[1] += __uint_as_float(rr.x & 0xffff0000u);
     v[2] += __uint_as_float(rr.y << 16);
     v[3] += __uint_as_float(rr.y & 0xffff0000u);
   }
   if constexpr (HAS_AUX) {
-    const u32x2c aa = __builtin_amdgcn_raw_buffer_load_b64(rsM, (int)off, 0, 0);
     v[0] *= __uint_as_float(aa.x << 16) > 0.f ? 1.f : mslope;
     v[1] *= __uint_as_float(aa.x & 0xffff0000u) > 0.f ? 1.f : mslope;
     v[2] *= __uint_as_float(aa.y << 16) > 0.f ? 1.f : mslope;
@@ -210,12 +210,16 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_fwd_kernel(C4P p) {
   const float bv[4] = {__uint_as_float(bq.x), __uint_as_float(bq.y), __uint_as_float(bq.z), __uint_as_float(bq.w)};
   const int x = tx * 16 + frow, ybase = ty * F_TH;
   const int co = cbase + fg * 4;
+  unsigned offs[F_TH];
+  u32x2c rr[HAS_RES ? F_TH : 1];
 #pragma unroll
   for (int i = 0; i < F_TH; ++i) {
     const int y = ybase + i;
-    const unsigned off = (y < p.Ho && x < p.Wo) ? (unsigned)((((n * p.Ho + y) * p.Wo + x) * p.Cout + co) * 2) : C4_OOB;
-    c4_store<HAS_RES, false>(acc[i], bv, p.nslope, 1.f, off, rsrcO, rsrcR, rsrcR);
+    offs[i] = (y < p.Ho && x < p.Wo) ? (unsigned)((((n * p.Ho + y) * p.Wo + x) * p.Cout + co) * 2) : C4_OOB;
+    if constexpr (HAS_RES) rr[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i], 0, 0);
   }
+#pragma unroll
+  for (int i = 0; i < F_TH; ++i) c4_store<HAS_RES, false>(acc[i], bv, p.nslope, 1.f, offs[i], rsrcO, rr[HAS_RES ? i : 0], rr[0]);
   // Batch-norm statistics of the layer (lib/ops.py:88-90 after lib/Teco.py:37): per-channel sum and sum of squares of conv + bias
   // from the fp32 accumulators -- the 16 lanes of a channel quad hold the tile's 16 columns -- one atomic pair per channel and wave.
   // (tg_bn_lrelu_forward then skips its two reduction launches: 2 x 9.6 us per layer and pass.)
@@ -239,10 +243,13 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_fwd_kernel(C4P p) {
         s2[r] += __shfl_xor(s2[r], m, 64);
       }
     if (frow == 0) {
+      // TG_BN_STAT_REPLICAS accumulator sets, picked by the unit: 768 workgroups adding to the SAME 2 x 64 addresses serialise in
+      // the L2 (the launch went from 22 to 39 us in the step); tg_bn_lrelu_forward(prezeroed = 2) sums the replicas
+      float* __restrict__ st = p.stats + (size_t)(u % TG_BN_STAT_REPLICAS) * 2 * p.Cout;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        unsafeAtomicAdd(p.stats + co + r, s1[r] * p.inv_rows);
-        unsafeAtomicAdd(p.stats + p.Cout + co + r, s2[r] * p.inv_rows);
+        unsafeAtomicAdd(st + co + r, s1[r] * p.inv_rows);
+        unsafeAtomicAdd(st + p.Cout + co + r, s2[r] * p.inv_rows);
       }
     }
   }
@@ -377,6 +384,8 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_bwd_kernel(C4P p) {
 
   const float bv[4] = {0.f, 0.f, 0.f, 0.f};
   const int co = cbase + fg * 4;
+  unsigned offs[B_TH][2][2];
+  u32x2c rr[HAS_RES ? B_TH : 1][2][2], aa[HAS_AUX ? B_TH : 1][2][2];
 #pragma unroll
   for (int i = 0; i < B_TH; ++i)
 #pragma unroll
@@ -384,9 +393,18 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_bwd_kernel(C4P p) {
 #pragma unroll
       for (int px = 0; px < 2; ++px) {
         const int y = 2 * (ty * B_TH + i) + py, x = 2 * (tx * 16 + frow) + px;
-        const unsigned off = (y < p.Ho && x < p.Wo) ? (unsigned)((((n * p.Ho + y) * p.Wo + x) * p.Cout + co) * 2) : C4_OOB;
-        c4_store<HAS_RES, HAS_AUX>(acc[py][px][i], bv, 1.f, p.mslope, off, rsrcO, rsrcR, rsrcM);
+        offs[i][py][px] = (y < p.Ho && x < p.Wo) ? (unsigned)((((n * p.Ho + y) * p.Wo + x) * p.Cout + co) * 2) : C4_OOB;
+        if constexpr (HAS_RES) rr[i][py][px] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, (int)offs[i][py][px], 0, 0);
+        if constexpr (HAS_AUX) aa[i][py][px] = __builtin_amdgcn_raw_buffer_load_b64(rsrcM, (int)offs[i][py][px], 0, 0);
       }
+#pragma unroll
+  for (int i = 0; i < B_TH; ++i)
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+        c4_store<HAS_RES, HAS_AUX>(acc[py][px][i], bv, 1.f, p.mslope, offs[i][py][px], rsrcO, rr[HAS_RES ? i : 0][py][px],
+                                   aa[HAS_AUX ? i : 0][py][px]);
 }
 
 // ---- fragment-order copy of a [taps][Cout][Cin] bf16 operand: dst[g][c][t][l][j] = src[t][16 g + l % 16][32 c + 8 (l / 16) + j]

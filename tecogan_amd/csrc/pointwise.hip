@@ -563,10 +563,19 @@ __global__ __launch_bounds__(256) void bn_stats_x8_kernel(const u16* __restrict_
   }
 }
 
-// stats[C + c] holds E[x^2] (accumulated by the producing conv's epilogue): -> biased variance E[x^2] - mean^2
+// stats[r][0][c] / stats[r][1][c], r < TG_BN_STAT_REPLICAS: partial E[x] / E[x^2] accumulated by the producing conv's epilogue
+// -> stats[0] = [mean, biased variance E[x^2] - mean^2]
 __global__ __launch_bounds__(256) void bn_moment_to_var_kernel(float* __restrict__ stats, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < C) stats[C + c] = fmaxf(stats[C + c] - stats[c] * stats[c], 0.f);
+  if (c >= C) return;
+  float m = 0.f, q = 0.f;
+#pragma unroll
+  for (int r = 0; r < TG_BN_STAT_REPLICAS; ++r) {
+    m += stats[(size_t)r * 2 * C + c];
+    q += stats[(size_t)r * 2 * C + C + c];
+  }
+  stats[c] = m;
+  stats[C + c] = fmaxf(q - m * m, 0.f);
 }
 
 __global__ __launch_bounds__(256) void bn_lrelu_apply_x8_kernel(const u16* __restrict__ x, u16* __restrict__ y,

@@ -19,6 +19,7 @@ from .nets import FNET_CPAD, GEN_CPAD, VGG_CPAD, VGG_TAPS, Discriminator, FNet, 
 from .parallel import ExchangeMixin
 from .params import (DIS_BLOCKS, ParamStore, discriminator_spec, fnet_spec, generator_spec, init_values, pad8,
                      vgg_spec)
+from .streams import shared_stream as _shared_stream
 from .segments import SegmentRunner, plan_launch_order  # noqa: F401  (plan_launch_order: re-exported for tools/)
 
 LOSS_NAMES = ["l2_content_loss", "l2_warp_loss", "PingPang", "vgg_loss_2", "vgg_loss_3", "vgg_loss_4", "vgg_loss_5",
@@ -91,7 +92,8 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         self.hyper = torch.zeros(nopt, 8, device=self.dev)
         # one fp32 scratch, zeroed by ONE fill per step: the loss slots, then the batch-norm statistics / backward sums
         # of the 2 forward + 3 backward discriminator passes
-        nbn = 5 * 2 * sum(co for _, _, co in DIS_BLOCKS) if gan else 0
+        # (the two forward passes keep K.BN_STAT_REPLICAS partial sets each: csrc/conv4x4s2.hip's epilogue)
+        nbn = (3 + 2 * K.BN_STAT_REPLICAS) * 2 * sum(co for _, _, co in DIS_BLOCKS) if gan else 0
         self.zbuf = torch.zeros(len(LOSS_NAMES) + nbn, device=self.dev)
         self.loss = self.zbuf[:len(LOSS_NAMES)]
         self.bn_pool = self.zbuf[len(LOSS_NAMES):]
@@ -113,7 +115,7 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         self.host_step = 0
         self._skip_update = False
         self.gen = None
-        self.side_stream = torch.cuda.Stream(device=self.dev)
+        self.side_stream = _shared_stream(self.dev, "S")
         # two-stream overlap of the latency-bound chain with throughput work (see _program_compute); TG_OVERLAP=0: A/B
         self.overlap = os.environ.get("TG_OVERLAP", "1") != "0"
         # which pieces go to the side stream (A/B bit mask): 1 VGG target features, 2 D real pass, 4 VGG pass of the early
@@ -140,7 +142,7 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         self._have_next = False                         # this step() was given next_targets
         self._announced = None                          # (tensor, its _version) announced as next_targets: identity check in step()
         self._hold = []
-        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.comm_stream = _shared_stream(self.dev, "C") if self.world > 1 else None
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments

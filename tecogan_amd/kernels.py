@@ -209,6 +209,9 @@ def conv3x3_wide_frag(desc, x, w_frag, bias, res, aux, out, tile_rows=0, ksplit=
     return out
 
 
+BN_STAT_REPLICAS = 16      # TG_BN_STAT_REPLICAS of include/tecogan_hip.h
+
+
 def pack_taps_frag(w, w_frag, taps, Cout, Cin):
     """Fragment-order copy of a [taps][Cout][Cin] bf16 conv operand (csrc/conv4x4s2.hip)."""
     assert w.dtype == torch.bfloat16 and w_frag.dtype == torch.bfloat16 and w.numel() == taps * Cout * Cin == w_frag.numel()

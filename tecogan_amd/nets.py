@@ -521,18 +521,21 @@ class Discriminator:
         saved, layers, net = [], [], a
         for bi, (name, _, co) in enumerate(DIS_BLOCKS):
             wname = p + name + "/conv1/Conv/weights"
-            stats, pz = self._ws(co, net)
             wf = ps.packed_wide(wname, True) if BN_STATS_IN_CONV else None
             N, H, W, Cp = net.shape
             d = K.conv_desc(N, H, W, Cp, H // 2, W // 2, co, 4, 4, 2, 1, 1, 0, K.dt(net), K.dt(net), flags=flags)
             if wf is not None and H % 2 == 0 and W % 2 == 0 and K.conv4x4s2_frag_ok(d):
-                # the conv's epilogue leaves the batch statistics in `stats`: no reduction launches in the batch norm
+                # the conv's epilogue leaves the batch statistics in `stats` (K.BN_STAT_REPLICAS partial sets, summed into the
+                # first by the batch norm's one finishing launch): no reduction launches in the batch norm
+                rep, pz = self._ws(co * K.BN_STAT_REPLICAS, net)
                 if not pz:
-                    stats.zero_()
+                    rep.zero_()
+                stats = rep.view(-1)[:2 * co].view(2, co)
                 c = into["c"][bi] if into else _empty((N, H // 2, W // 2, co), ps.act_dtype, net)
-                K.conv4x4s2_frag(d, net, wf, None, None, None, c, bn_stats=stats)
+                K.conv4x4s2_frag(d, net, wf, None, None, None, c, bn_stats=rep)
                 pz = 2
             else:
+                stats, pz = self._ws(co, net)
                 c = conv_fwd(ps, wname, None, net, 2, flags=flags, out=into["c"][bi] if into else None)
             y = into["y"][bi] if into else torch.empty_like(c)
             K.bn_lrelu_forward(c, y, ps.view(p + name + "/BatchNorm/beta"), 1e-3, 0.2, stats,

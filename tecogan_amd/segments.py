@@ -9,6 +9,8 @@ import time
 
 import torch
 
+from .streams import shared_stream
+
 from . import kernels as K
 
 
@@ -198,7 +200,7 @@ class SegmentRunner:
         # warm-up run (allocator pools, lazy module loads, the real two-stream schedule), state restored afterwards
         snap = [t.clone() for t in (self.ps.flat, self.ps.m, self.ps.v, self.sched, self.hyper)]
         moving = [m.clone() for m in self.D.moving] if self.gan else []
-        s = torch.cuda.Stream()
+        s = shared_stream(self.dev, "W")
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._run_program("eager")

@@ -1195,19 +1195,20 @@ def test_conv4x4s2_forward_matches_oracle(case):
         out = torch.full((N, H // 2, W // 2, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
         K.prof_collect()
         K.prof_enable(True)
-        stats = torch.zeros(2, Cout, device=DEV) if variant == 0 else None
-        K.conv4x4s2_frag(d, x.to(DEV), wf, b.to(DEV) if variant else None, res.to(DEV) if variant else None, None, out, bn_stats=stats)
+        rep = torch.zeros(K.BN_STAT_REPLICAS, 2, Cout, device=DEV) if variant == 0 else None
+        K.conv4x4s2_frag(d, x.to(DEV), wf, b.to(DEV) if variant else None, res.to(DEV) if variant else None, None, out, bn_stats=rep)
         K.prof_enable(False)
-        if stats is not None:
-            # the epilogue's batch statistics (mean, second moment over N Ho Wo) and the batch norm built on them against the
-            # two-reduction path on the stored bf16 tensor
+        if rep is not None:
+            # the epilogue's batch statistics (mean, second moment over N Ho Wo; partial sets summed) and the batch norm built on
+            # them against the two-reduction path on the stored bf16 tensor
             flat = pre.reshape(-1, Cout).double()
-            close(stats[0], flat.mean(0).float(), 2e-5, "fused BN mean %s" % (case,))
-            close(stats[1], (flat * flat).mean(0).float(), 2e-5, "fused BN second moment %s" % (case,))
+            close(rep.sum(0)[0], flat.mean(0).float(), 2e-5, "fused BN mean %s" % (case,))
+            close(rep.sum(0)[1], (flat * flat).mean(0).float(), 2e-5, "fused BN second moment %s" % (case,))
             beta = rnd(Cout, seed=9).to(DEV)
             y_ref, st_ref = torch.empty_like(out), torch.zeros(2, Cout, device=DEV)
             K.bn_lrelu_forward(out, y_ref, beta, 1e-3, 0.2, st_ref, None, prezeroed=True)
-            y_fused = K.bn_lrelu_forward(out, torch.empty_like(out), beta, 1e-3, 0.2, stats, None, prezeroed=2)
+            y_fused = K.bn_lrelu_forward(out, torch.empty_like(out), beta, 1e-3, 0.2, rep, None, prezeroed=2)
+            stats = rep[0]
             close(stats[0], st_ref[0], 1e-3, "fused BN mean vs reduction kernels %s" % (case,))
             close(stats[1], st_ref[1], 2e-3, "fused BN variance vs reduction kernels %s" % (case,))
             if N * (H // 2) * (W // 2) >= 64:       # (with a handful of positions the variance is ~0 and rsqrt(eps) = 32 amplifies the
