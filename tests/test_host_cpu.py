@@ -395,7 +395,9 @@ def test_engine_replay_executes_the_plan_with_streams_and_events(monkeypatch):
         del log[:]
         state["ready"] = state["have"] = ready
         skipped = {"vggt"} if ready else {"vggt_pre", "vggt_next"}
-        eng = types.SimpleNamespace(_segs=segs, streams={"S": side, "C": comm}, lazy_side=lazy)
+        # (comm_thread=False: the communication segments' waits stay on this thread, as for backends that cannot be captured; the
+        #  threaded launcher is covered on the GPU by the stand-in world-2 / world-8 tests)
+        eng = types.SimpleNamespace(_segs=segs, streams={"S": side, "C": comm}, lazy_side=lazy, comm_thread=False, _comm_error=[])
         TrainEngine._replay(eng)
         replays = [e for e in log if e[0] == "replay"]
         assert sorted(r[1] for r in replays) == sorted(n for n, _, _ in TECO_SEGS if n not in skipped)

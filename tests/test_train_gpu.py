@@ -668,10 +668,11 @@ def test_host_jitter_before_exchange_segments_standin_world8():
           "segments (%.0f us of sleep per step)" % (t_plain, t_jit, per_step * 1e6))
     assert len(slept) >= 3 * 80
     # What is held: injected host sleep is never AMPLIFIED -- the step grows by at most the sleep itself (+ 30 us of timing noise).
-    # It is NOT hidden either: the one host thread that launches the exchange segments just in time also launches everything else, so
-    # 296 us of sleep per step cost 174 / 217 / 284 us in sessions G / Z / N (2.1 / 2.5 / 3.6 % of the step; the round-4 form of this
-    # line, "within 3 %", held only while the step was slower than 8.2 ms).  Real launch jitter on an 8-GPU host is tens of
-    # microseconds per segment; a helper thread per stream is the open fix.
+    # Most of it cannot hide by construction: `ar_g` and `ar_f` are launched when the generator's / FNet's gradients exist -- the tail
+    # of the step -- and `update` needs both at once, so two of the three sleeps (~200 of 296 us) sit on the critical path whatever
+    # the launcher does; `ar_d`'s sleep (it overlaps the whole BPTT) hides since the exchange segments are launched from their own
+    # thread (segments.SegmentRunner.comm_thread, round 5: 296 us of sleep cost 284 us before, 232 us after; the round-4 form of this
+    # line, "within 3 %", held only while the step was slower than 8.2 ms).  Real launch jitter is tens of microseconds per segment.
     print("    hidden fraction of the injected sleep: %.2f" % (1.0 - (t_jit - t_plain) / (per_step * 1e3)))
     assert t_jit - t_plain <= per_step * 1e3 + 0.03, (t_plain, t_jit, per_step)
     assert all(v == v for v in b.losses().values())
