@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
-( timeout 600 python -m pytest tests -m gpu -q -s -k "standin or world2 or exchange or one_rank or data_parallel or validation_pass" --tb=short 2>&1 | grep -v "^$" | cut -c1-300 | tail -25 ) > $O/r05o_pytest.log 2>&1; cat $O/r05o_pytest.log
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+for cfg in "0 0" "1 0" "0 1" "1 1" "0 0" "1 0" "0 1" "1 1"; do set -- $cfg; AB_TAG="wr_prio=$1 dcap=$2" TG_WR_PRIO=$1 TG_AB_DCAP=$2 timeout 120 python tools/_ab.py 2>&1 | grep "ms/step" | cut -c1-200; done
