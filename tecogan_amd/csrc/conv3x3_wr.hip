@@ -2,7 +2,8 @@
 // streamed into REGISTERS from a fragment-order copy -- gfx950.
 //
 // Covers VGG-19 conv2_2 ... conv4_4 (reference lib/ops.py:319-327 through lib/Teco.py:5-24,174-178: 76 % of the perceptual
-// loss's MACs, which are 72 % of the TecoGAN step's) and -- taps mirrored at pack time -- their input gradients.
+// loss's MACs, which are 72 % of the TecoGAN step's), conv5_x as packed tiles (two 8 x 8 images per tile, see WrGeo / KS below)
+// and -- taps mirrored at pack time -- their input gradients.
 //
 // Why a fourth 3x3 kernel.  conv3x3_dma.hip brings BOTH operands of a 32-channel stage in by LDS-DMA: 20 KB of halo and
 // 36 KB of weight panel per 576 MFMAs per CU, and its stage trace (profiles/r02m_trace_dma.txt, DESIGN lesson 9) shows the
@@ -17,8 +18,9 @@
 //   * only the halo ((TH+2) x 18 pixels x 64 bytes = 20 KB) goes through LDS, by LDS-DMA into a double buffer, with the
 //     swizzled 64-byte rows of conv3x3_dma.hip (conflict-free ds_read_b128 under the gfx950 lane grouping): 36 % of the
 //     bytes the DMA path carried; every halo fragment is read once per (row, kw) and feeds three MFMAs (54 reads per 144);
-//   * 43 KB of LDS and <= 168 registers: three workgroups per CU whose stages drift apart, so one's barrier / DMA wait
-//     runs under the others' MFMAs (lesson 25) and a chain workgroup still fits beside them;
+//   * 48 KB of LDS and 152 registers (16-row tiles; 24 KB / 113 for 8-row tiles): three / four workgroups per CU whose stages
+//     drift apart, so one's barrier / DMA wait runs under the others' MFMAs (lesson 25); beside the latency-bound recurrent
+//     chain (TG_CONV_COEXIST) the launch caps itself at two per CU so that a chain workgroup always finds room (see the host code);
 //   * one workgroup per (tile, channel block), no persistent loop: the hardware dispatcher balances the tail, units are
 //     numbered so that an XCD owns a contiguous range (the four channel blocks of a tile run concurrently on ONE L2);
 //   * accumulation order per output element = conv3x3_dma.hip's (chunk, kw, kh ascending; same MFMA, same operand roles):
