@@ -143,6 +143,9 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         self._announced = None                          # (tensor, its _version) announced as next_targets: identity check in step()
         self._hold = []
         self.comm_stream = _shared_stream(self.dev, "C") if self.world > 1 else None
+        # captured exchange segments are launched from their own host thread (segments.SegmentRunner); TG_COMM_THREAD=0 keeps
+        # their just-in-time waits on the caller's thread (the round-4 behaviour) should a backend object to the second thread
+        self.comm_thread = os.environ.get("TG_COMM_THREAD", "1") != "0"
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments
