@@ -658,8 +658,9 @@ def main():
         # JSON line (config.exchange), and the run continues with the eager-split exchange.  All ranks decide together.
         ok = torch.ones(1, device=device)
         try:
-            eng.step()
-            torch.cuda.synchronize()
+            for _ in range(2):                                   # capture + first replay, then a steady-state replay (the exchange
+                eng.step()                                       # segments are launched from their own host thread there)
+                torch.cuda.synchronize()
         except Exception as e:                                   # noqa: BLE001
             capture_failure = "%s: %s" % (type(e).__name__, str(e)[:200])
             ok.zero_()
