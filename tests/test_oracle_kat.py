@@ -259,6 +259,45 @@ def test_transposed_conv_equals_a_stride1_conv_into_four_phases():
     assert (got - want).abs().max().item() < 1e-12
 
 
+def test_stride2_conv_decompositions_used_by_conv4x4s2():
+    """The two index identities csrc/conv4x4s2.hip is built on (round 5), on the oracle's conv2 (slim.conv2d k4 s2 SAME, lib/ops.py:47-56,
+    as discriminator_F calls it, lib/Teco.py:52-66), in float64:
+      * FORWARD as stride-1 reads of two column-parity planes: out[oy, ox] = sum_{kh, kw} plane[kw & 1][2 oy - 1 + kh, ox + (kw >> 1)] . W[kh, kw]
+        with plane[p][r, c] = x[r, 2 c + p - 1] (zero outside the image);
+      * INPUT GRADIENT as four output phases, each a 2x2-tap stride-1 convolution over dY: phase py = y & 1 takes
+        (kernel row, row shift) = (1, 0), (3, -1) for py = 0 and (0, +1), (2, 0) for py = 1 -- the same table for columns --
+        the PYK table of conv4x4s2_bwd_kernel."""
+    from oracle import ops as O
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Ci, Co = 2, 8, 12, 5, 3
+    x = torch.randn(N, H, W, Ci, generator=g, dtype=torch.float64).requires_grad_()
+    w = torch.randn(4, 4, Ci, Co, generator=g, dtype=torch.float64)
+    y = O.conv2(x, w, None, 2)                                                      # [N, H/2, W/2, Co]
+    Ho, Wo = H // 2, W // 2
+    # forward: parity planes (row index r <-> input row r - 1: one zero row above, columns as described)
+    xp = torch.zeros(N, H + 2, W + 3, Ci, dtype=torch.float64)
+    xp[:, 1:H + 1, 1:W + 1] = x.detach()                                            # xp[r, c] = x[r - 1, c - 1]
+    plane = [xp[:, :, 0::2], xp[:, :, 1::2]]                                        # plane[p][r, c] = x[r - 1, 2 c + p - 1]
+    got = torch.zeros_like(y)
+    for kh in range(4):
+        for kw in range(4):
+            rows = plane[kw & 1][:, kh:kh + 2 * Ho:2, (kw >> 1):(kw >> 1) + Wo]      # input row 2 oy - 1 + kh <-> xp row 2 oy + kh
+            got += torch.einsum("nyxc,co->nyxo", rows, w[kh, kw])
+    assert (got - y.detach()).abs().max().item() < 1e-12
+    # input gradient: four phases over dY
+    dy = torch.randn(N, Ho, Wo, Co, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dyp = torch.zeros(N, Ho + 2, Wo + 2, Co, dtype=torch.float64)
+    dyp[:, 1:Ho + 1, 1:Wo + 1] = dy                                                 # dyp[r, c] = dY[r - 1, c - 1]
+    PYK = [(0, 1, 0), (0, 3, -1), (1, 0, 1), (1, 2, 0)]                             # (phase, kernel index, shift)
+    dx = torch.zeros(N, H, W, Ci, dtype=torch.float64)
+    for py, kh, dr in PYK:
+        for px, kw, dc in PYK:
+            src = dyp[:, 1 + dr:1 + dr + Ho, 1 + dc:1 + dc + Wo]                     # dY[oy + dr, ox + dc]
+            dx[:, py::2, px::2] += torch.einsum("nyxo,co->nyxc", src, w[kh, kw])
+    assert (dx - x.grad).abs().max().item() < 1e-12
+
+
 # ---------------------------------------------------------------------------------------------------------
 # REAL TensorFlow goldens (tools/make_tf_goldens.py, to be run on a box with TF 1.x): turn "parity unpinned" into pinned.
 # The file cannot be produced in this container (no TensorFlow, no network); the test skips until it exists.
