@@ -50,6 +50,9 @@ typedef __attribute__((address_space(3))) void lds_void_w;
 
 namespace {
 constexpr unsigned WR_OOB = 0x80000000u;
+#ifndef WR_DIST
+#define WR_DIST 2      // LDS fragment prefetch distance (fragments ahead of their MFMAs); 3 / 4 measured within 1.4 % (profiles/r05m_ab.txt)
+#endif
 // PK = images per tile row.  PK = 1: a 16 x TH tile of a larger image, (TH + 2) x 18 halo.  PK = 2 (PACKED tiles, images of exactly
 // 8 x 8 pixels: VGG conv5): the 8 x 16 output pixels are two whole images side by side, each with its own zero border in a
 // 10 x 20 halo; output pixel (r, c) reads halo (r + kh, c + 2 (c / 8) + kw) -- a per-lane column shift on the fragment base.
@@ -179,19 +182,19 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : (KS == 2 ? 2 : 1)) void con
       const int K = hr * HW + kw;
       return *reinterpret_cast<const u32x4w*>(sb + abase[K & 7] + K * 64);
     };
-    u32x4w F[3];
-    F[0] = rd(0);
-    F[1] = rd(1);
+    u32x4w F[WR_DIST + 1];
+#pragma unroll
+    for (int k = 0; k < WR_DIST; ++k) F[k] = rd(k);
     wr_static_for<0, NS>([&](auto sv) {
       constexpr int s = decltype(sv)::value;
       constexpr int kw = s / HR, hr = s - kw * HR;
-      if constexpr (s + 2 < NS) F[(s + 2) % 3] = rd(s + 2);          // two fragments ahead of the MFMAs that use them
+      if constexpr (s + WR_DIST < NS) F[(s + WR_DIST) % (WR_DIST + 1)] = rd(s + WR_DIST);   // WR_DIST fragments ahead of the MFMAs that use them
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int i = hr - kh;
         if (i >= 0 && i < TH)
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[kh * 3 + kw]),
-                                                           __builtin_bit_cast(bf16x8, F[s % 3]), acc[i], 0, 0, 0);
+                                                           __builtin_bit_cast(bf16x8, F[s % (WR_DIST + 1)]), acc[i], 0, 0, 0);
       }
       // the next stage's halo: one DMA round after each of the first fragments' MFMAs (an LDS-DMA instruction takes 60-180
       // cycles to issue: back to back they would stall this wave's MFMA stream)
