@@ -180,6 +180,14 @@ int tg_conv_wgrad(const tg_conv_desc* d, const void* x, int x_dtype, int ldx /*c
 int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
                           const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
                           void* stream);
+/* The same plus ONE more layer of the same spatial geometry and output width with FEWER input channels -- generator_F's input conv
+ * (51 channels in a 56-channel pixel, lib/frvsr.py:47-49) beside the 2 x num_resblock trunk convs: X pixels of ldx_extra channels,
+ * dW with cin_extra rows per tap.  One launch where the transpose-read kernel applies (bf16, 64 -> 64, W % 32 == 0, H % 8 == 0);
+ * otherwise tg_conv_wgrad_grouped + tg_conv_wgrad. */
+int tg_conv_wgrad_grouped_plus(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx, const void* const* y,
+                               int y_dtype, int ldy, float* const* dw, float* const* dbias /*nullable*/, const void* x_extra,
+                               int ldx_extra, int cin_extra, const void* y_extra, float* dw_extra, float* dbias_extra /*nullable*/,
+                               void* stream);
 
 /* Weight gradients of `groups` layers of DIFFERENT geometry in one call (descs[g], ldx[g], ldy[g] per layer; ld* = 0 means the
  * channel count): the 14 convolutions of fnet, reference lib/frvsr.py:4-41 under tf.gradients (lib/Teco.py:441-449).  bf16 3x3

@@ -33,6 +33,7 @@ SIGNATURES = {
     "tg_conv_forward": [_D, _P, _P, _P, _P, _P, _P, _P],
     "tg_conv_wgrad": [_D, _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "tg_conv_wgrad_grouped": [_D, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P],
+    "tg_conv_wgrad_grouped_plus": [_D, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "tg_conv_wgrad_multi": [_D, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P],
     "tg_colsum": [_P, _I, _L, _I, _P, _P],
     "tg_pack_weights": [_P, _P, _I, _P, _I, _I, _P],

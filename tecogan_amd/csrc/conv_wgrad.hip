@@ -801,7 +801,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_bf16_kernel(WgradRP p)
 }
 
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
-                       float* const* dw, float* const* dbias, hipStream_t st);     // conv_wgrad_tr.hip
+                       float* const* dw, float* const* dbias, hipStream_t st, const void* x_narrow = nullptr, int ldx_narrow = 0,
+                       int cin_narrow = 0, const void* y_narrow = nullptr, float* dw_narrow = nullptr, float* db_narrow = nullptr);     // conv_wgrad_tr.hip
 int tg_wgrad_bf16_multi_launch(const tg_conv_desc* const* ds, int n, const void* const* x, const int* ldxs, const void* const* y,
                                const int* ldys, float* const* dw, float* const* dbias, hipStream_t st);   // below
 static bool tg_wgrad_bf16_setup(const tg_conv_desc* d, const void* x, int ldx, const void* y, int ldy, float* dw, float* dbias,
@@ -924,6 +925,29 @@ extern "C" int tg_conv_wgrad_grouped(const tg_conv_desc* d, int groups, const vo
     if (rc != TG_OK) return rc;
   }
   return TG_OK;
+}
+
+// tg_conv_wgrad_grouped plus ONE more layer of the same spatial geometry and output width but FEWER input channels (the generator's
+// input conv beside its residual trunk): one launch when the transpose-read kernel takes the group, otherwise the grouped call and
+// an ordinary tg_conv_wgrad for the extra layer.
+extern "C" int tg_conv_wgrad_grouped_plus(const tg_conv_desc* d, int groups, const void* const* x, int x_dtype, int ldx,
+                                          const void* const* y, int y_dtype, int ldy, float* const* dw, float* const* dbias,
+                                          const void* x_extra, int ldx_extra, int cin_extra, const void* y_extra, float* dw_extra,
+                                          float* dbias_extra, void* stream) {
+  TG_CHECK_ARG(d && x && y && dw && groups >= 1 && x_extra && y_extra && dw_extra, "null pointer / no groups");
+  TG_CHECK_ARG(cin_extra >= 1 && cin_extra <= d->Cin && ldx_extra >= cin_extra, "the extra layer has at most the group's input channels");
+  for (int g = 0; g < groups; ++g) TG_CHECK_ARG(x[g] && y[g] && dw[g], "null group pointer");
+  const int lx = ldx > 0 ? ldx : d->Cin, ly = ldy > 0 ? ldy : d->Cout;
+  bool fast = d->mode == 0 && x_dtype == TG_BF16 && y_dtype == TG_BF16 && lx % 8 == 0 && ly % 8 == 0 && lx >= d->Cin && ly >= d->Cout;
+  for (int g = 0; g < groups && fast; ++g) fast = ((((uintptr_t)x[g] | (uintptr_t)y[g])) & 15) == 0;
+  if (fast && tg_wgrad_tr_launch(d, groups, x, lx, y, ly, dw, dbias, static_cast<hipStream_t>(stream), x_extra, ldx_extra, cin_extra,
+                                 y_extra, dw_extra, dbias_extra))
+    TG_CHECK_LAUNCH();
+  const int rc = tg_conv_wgrad_grouped(d, groups, x, x_dtype, ldx, y, y_dtype, ldy, dw, dbias, stream);
+  if (rc != TG_OK) return rc;
+  tg_conv_desc de = *d;
+  de.Cin = cin_extra;
+  return tg_conv_wgrad(&de, x_extra, x_dtype, ldx_extra, y_extra, y_dtype, ldy, dw_extra, dbias_extra, stream);
 }
 
 // Weight gradients of `groups` layers of DIFFERENT geometry in one call: descs[g] / ldx[g] / ldy[g] per layer.  bf16 3x3 stride-1

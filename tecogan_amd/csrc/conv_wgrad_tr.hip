@@ -43,6 +43,10 @@ struct WgradTrP {
   int ntiles;           // N * tiles_y * tiles_x
   int cout;             // real output channels (dW's innermost extent): 64, or <= 8 for the YC = 8 instantiation
   unsigned xbytes, ybytes;
+  // Round 5: the LAST group may be a layer with FEWER input channels on the same geometry (the generator's input conv, 51 channels
+  // padded to a 56-channel pixel, lib/frvsr.py:47-49): X pixels of narrow_pix bytes (the 16-byte chunks past them read zeros), dW
+  // with narrow_rows rows per tap.  narrow_grp < 0: none.
+  int narrow_grp, narrow_pix, narrow_rows;
 };
 
 typedef short s16x4t __attribute__((ext_vector_type(4)));
@@ -114,6 +118,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
   const u16* __restrict__ gy = p.ys[grp];
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gx), 0, (int)p.xbytes, 0x00020000);
   const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(gy), 0, (int)p.ybytes, 0x00020000);
+  const bool narrow = grp == p.narrow_grp;                 // workgroup-uniform
+  const int xpix = narrow ? p.narrow_pix : TR_PIX;          // bytes per X pixel in memory (LDS pixels are always 128 bytes)
+  const int arows = narrow ? p.narrow_rows : 64;            // rows of dW per tap
 
   // ---- DMA slot descriptors.  X: slot S = (wave + 8k)*64 + lane -> halo pixel S / 8 = (dy, dx), 16-byte channel chunk S % 8
   int xrel[TR_XROUNDS], xcode[TR_XROUNDS];
@@ -122,8 +129,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
     const int S = (wave + TR_NW * k) * 64 + lane;
     const int q = S >> 3, c = S & 7;
     const int dy = q / (TR_W + 2), dx = q - (TR_W + 2) * dy;
-    xrel[k] = ((dy - 1) * p.W + dx - 1) * TR_PIX + ((((c >> 1) ^ tr_swz(q)) << 1) | (c & 1)) * 16;
-    xcode[k] = dy | (dx << 8) | (S < TR_XSLOTS ? (1 << 16) : 0);
+    const int cgl = (((c >> 1) ^ tr_swz(q)) << 1) | (c & 1);              // the 16-byte chunk of the pixel this slot receives
+    xrel[k] = ((dy - 1) * p.W + dx - 1) * xpix + cgl * 16;
+    xcode[k] = dy | (dx << 8) | ((S < TR_XSLOTS && cgl * 16 < xpix) ? (1 << 16) : 0);
   }
   //      dY: slot S -> tile row S / YROW_SLOTS, 16-byte unit S % YROW_SLOTS of that row's 32 pixels
   int yrel[G::YROUNDS];
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
         if (r + 1 < TR_XROUNDS || inst < TR_XINST) {
           const int dy = xcode[r] & 255, dx = (xcode[r] >> 8) & 255;
           const bool ok = (xcode[r] >> 16) && (unsigned)(y0 + dy - 1) < (unsigned)p.H && (unsigned)(x0 + dx - 1) < (unsigned)p.W;
-          const unsigned off = ok ? (unsigned)(pix0 * TR_PIX + xrel[r]) : TR_OOB;
+          const unsigned off = ok ? (unsigned)(pix0 * xpix + xrel[r]) : TR_OOB;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_t*)(dst + inst * 1024), 16, (int)off, 0, 0, 0);
         }
       } else if (r < G::ROUNDS) {
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(WgradTrP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ci = ci0 + 16 * i + 4 * fg + r, co = co0 + 16 * j + frow;
-            if (YC == 64 || co < p.cout) unsafeAtomicAdd(dw + ((T0 + t) * 64 + ci) * p.cout + co, acc[t][i][j][r]);
+            if ((YC == 64 || co < p.cout) && ci < arows) unsafeAtomicAdd(dw + ((T0 + t) * arows + ci) * p.cout + co, acc[t][i][j][r]);
           }
   };
   if (tset == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
@@ -293,9 +301,13 @@ static void wgrad_tr_go(const WgradTrP& p, double flops, double bytes, hipStream
 // returns 1 if launched, 0 otherwise.  Geometries: 3x3 s1 SAME, 64 input channels (ldx = 64), images H % 8 == 0, W % 32 == 0;
 // 64 -> 64 (ldy = 64: the generator trunk, grouped) or 64 -> <= 8 with ldy = 8 (the generator's output conv).
 int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, int ldx, const void* const* y, int ldy,
-                       float* const* dw, float* const* dbias, hipStream_t st) {
+                       float* const* dw, float* const* dbias, hipStream_t st, const void* x_narrow, int ldx_narrow, int cin_narrow,
+                       const void* y_narrow, float* dw_narrow, float* db_narrow) {
   static const bool enabled = getenv("TG_WGRAD_TR") == nullptr || atoi(getenv("TG_WGRAD_TR")) != 0;
-  if (!enabled || tg_det() || groups < 1 || groups > TG_WTR_MAX_GROUPS) return 0;
+  const int gtot = groups + (x_narrow ? 1 : 0);
+  if (!enabled || tg_det() || groups < 1 || gtot > TG_WTR_MAX_GROUPS) return 0;
+  if (x_narrow && !(d->Cout == 64 && ldy == 64 && ldx_narrow % 8 == 0 && ldx_narrow <= 64 && cin_narrow >= 1 && cin_narrow <= ldx_narrow &&
+                    y_narrow && dw_narrow && ((((uintptr_t)x_narrow | (uintptr_t)y_narrow)) & 15) == 0)) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->mode != 0) return 0;
   if (d->Win % TR_W != 0 || d->Wout != d->Win || d->Hin != d->Hout || d->Hin % TR_TH != 0) return 0;
   const bool trunk = d->Cout == 64 && ldy == 64, outc = d->Cout <= 8 && ldy == 8;
@@ -307,6 +319,12 @@ int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, 
     const int k = g < groups ? g : 0;
     p.xs[g] = (const u16*)x[k]; p.ys[g] = (const u16*)y[k]; p.dws[g] = dw[k]; p.dbs[g] = dbias ? dbias[k] : nullptr;
   }
+  p.narrow_grp = -1; p.narrow_pix = TR_PIX; p.narrow_rows = 64;
+  if (x_narrow) {
+    p.xs[groups] = (const u16*)x_narrow; p.ys[groups] = (const u16*)y_narrow; p.dws[groups] = dw_narrow; p.dbs[groups] = db_narrow;
+    p.narrow_grp = groups; p.narrow_pix = ldx_narrow * 2; p.narrow_rows = cin_narrow;
+  }
+  groups = gtot;
   p.groups = groups;
   p.N = d->N; p.H = d->Hin; p.W = d->Win;
   p.tiles_y = d->Hin / TR_TH; p.tiles_x = d->Win / TR_W;
@@ -319,7 +337,8 @@ int tg_wgrad_tr_launch(const tg_conv_desc* d, int groups, const void* const* x, 
   if (nsplit > p.ntiles) nsplit = p.ntiles;
   p.nsplit = nsplit;
   const double M = (double)px;
-  const double flops = 2.0 * groups * M * 9.0 * 64 * d->Cout, bytes = groups * (M * (TR_PIX + 2.0 * ldy) + 36.0 * 64 * d->Cout);
+  const double gfl = groups - (x_narrow ? 1.0 - cin_narrow / 64.0 : 0.0);      // the narrow group counts with its real channels
+  const double flops = 2.0 * gfl * M * 9.0 * 64 * d->Cout, bytes = groups * (M * (TR_PIX + 2.0 * ldy) + 36.0 * 64 * d->Cout);
   if (trunk) wgrad_tr_go<64>(p, flops, bytes, st);
   else wgrad_tr_go<8>(p, flops, bytes, st);
   return 1;

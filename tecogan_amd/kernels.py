@@ -66,6 +66,21 @@ def conv_wgrad_grouped(desc, xs, ys, dws, dbiases, ldx=0, ldy=0):
           "tg_conv_wgrad_grouped")
 
 
+def conv_wgrad_grouped_plus(desc, xs, ys, dws, dbiases, extra, ldx=0, ldy=0):
+    """conv_wgrad_grouped plus one more layer of the same spatial geometry / output width with fewer input channels, in the same
+    launch where the transpose-read kernel applies.  extra = (x, ldx, cin, dy, dW, dbias)."""
+    G = len(xs)
+    assert G >= 1 and len(ys) == G and len(dws) == G and (dbiases is None or len(dbiases) == G)
+
+    def table(ts):
+        return (C.c_void_p * G)(*[_p(t) if t is not None else None for t in ts])
+    tx, ty, tw = table(xs), table(ys), table(dws)
+    tb = table(dbiases) if dbiases is not None else None
+    xe, ldxe, cine, ye, dwe, dbe = extra
+    check(lib().tg_conv_wgrad_grouped_plus(C.byref(desc), G, tx, dt(xs[0]), ldx, ty, dt(ys[0]), ldy, tw, tb, _p(xe), ldxe, cine, _p(ye),
+                                           _p(dwe), _p(dbe), _stream()), "tg_conv_wgrad_grouped_plus")
+
+
 def conv_wgrad_multi(descs, xs, ys, dws, dbiases, ldxs, ldys):
     """Weight gradients of len(xs) layers of DIFFERENT geometry in one call (one launch for bf16 3x3 stride-1 layers)."""
     G = len(xs)

@@ -169,6 +169,7 @@ class Generator:
         self.hr_tail = True
         self.ws_frag = True
         self.fused_block = True        # throughput regime (inference): a residual block as ONE launch (csrc/resblock_thr.hip)
+        self.input_in_group = True     # the input conv's weight gradient as a narrower last group of the trunk's grouped launch
         self.resblock_lat = self.hr_fwd_lat = self.hr_bwd_lat = True
         self.resblock_max_tiles = 1024          # 4x4-pixel tiles up to which one workgroup per tile is the latency-optimal shape
         # scheduling hint for the recurrence's own launches (forward_t / backward_t): K.CONV_COEXIST when throughput work
@@ -341,8 +342,10 @@ class Generator:
             x = x[t0:t1]
             return x.reshape(-1, *x.shape[2:])
 
-        conv_wgrad(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", flat(q["x_in"]),
-                   flat(q["g_in"]), flags=flags)
+        wi, bi = p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases"
+        with_input = self.grouped_wgrad and n >= 1 and self.input_in_group and 2 * n + 1 <= 40
+        if not with_input:
+            conv_wgrad(ps, wi, bi, flat(q["x_in"]), flat(q["g_in"]), flags=flags)
         if self.grouped_wgrad and n >= 1:
             # the 2n res-block convs have one geometry and their gradients are all due here: ONE grouped launch
             # (tg_conv_wgrad_grouped) instead of 2n -- the per-launch fixed cost is paid once
@@ -357,7 +360,14 @@ class Generator:
             _, pt = K.same_pad(H, e["k"], 1)
             _, pl = K.same_pad(W, e["k"], 1)
             d = K.conv_desc(N, H, W, e["A"], H, W, e["B"], e["k"], e["k"], 1, pt, pl, 0, 0, 0, flags=flags)
-            for g0 in range(0, len(names), 40):                     # TG_WGRAD_MAX_GROUPS per call
+            if with_input:
+                # ... and the input conv (51 channels in a 56-channel pixel, same images, 64 outputs) rides in the same launch as a
+                # narrower last group (round 5: its own launch took 110 us for 5 GFLOP on the row kernel)
+                xi = flat(q["x_in"])
+                K.conv_wgrad_grouped_plus(d, xs, dys, [ps.gview(nm + "weights") for nm in names], [ps.gview(nm + "biases") for nm in names],
+                                          (xi, xi.shape[-1], ps.entries[wi]["A"], flat(q["g_in"]), ps.gview(wi), ps.gview(bi)),
+                                          ldx=Cp, ldy=dys[0].shape[-1])
+            for g0 in range(0, 0 if with_input else len(names), 40):   # TG_WGRAD_MAX_GROUPS per call
                 sl = slice(g0, g0 + 40)
                 K.conv_wgrad_grouped(d, xs[sl], dys[sl], [ps.gview(nm + "weights") for nm in names[sl]],
                                      [ps.gview(nm + "biases") for nm in names[sl]], ldx=Cp, ldy=dys[0].shape[-1])

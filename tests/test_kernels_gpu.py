@@ -1316,6 +1316,43 @@ def test_wgrad_transpose_read_kernel_matches_autograd(case):
 
 
 @pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") == "0", reason="TG_WGRAD_TR=0 switches the transpose-read kernel off")
+@pytest.mark.parametrize("case", [(2, 5, 32, 51, 56), (32, 76, 32, 51, 56), (3, 4, 16, 9, 16)])
+def test_wgrad_transpose_read_kernel_with_a_narrower_last_group(case):
+    """Round 5: generator_F's input conv (51 channels in a 56-channel pixel, lib/frvsr.py:47-49) as a narrower last group of the
+    trunk's grouped transpose-read launch (tg_conv_wgrad_grouped_plus): its dW has 51 rows per tap, the pixel's 16-byte chunks past
+    its 112 bytes read zeros.  Against torch autograd on the bf16-rounded operands; the trunk groups beside it must be unchanged."""
+    G, N, H, A, ldx = case
+    d = K.conv_desc(N, H, 32, 64, H, 32, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16)
+    xs = [rnd(N, H, 32, 64, seed=10 + g).bfloat16() for g in range(G)]
+    ys = [rnd(N, H, 32, 64, seed=50 + g).bfloat16() for g in range(G)]
+    xe = torch.zeros(N, H, 32, ldx)
+    xe[..., :A] = rnd(N, H, 32, A, seed=7)
+    xe, ye = xe.bfloat16(), rnd(N, H, 32, 64, seed=8).bfloat16()
+    got_w = [torch.full((3, 3, 64, 64), 0.5, device=DEV) for _ in range(G)]
+    got_b = [torch.zeros(64, device=DEV) for _ in range(G)]
+    we, be = torch.full((3, 3, A, 64), 0.25, device=DEV), torch.zeros(64, device=DEV)
+    K.prof_collect()
+    K.prof_enable(True)
+    K.conv_wgrad_grouped_plus(d, [x.to(DEV) for x in xs], [y.to(DEV) for y in ys], got_w, got_b, (xe.to(DEV), ldx, A, ye.to(DEV), we, be))
+    K.prof_enable(False)
+    ents = K.prof_collect()
+    assert len(ents) == 1 and ents[0]["name"] == "conv_wgrad_tr" and ents[0]["calls"] == 1, ents
+    xr = xe[..., :A].float().requires_grad_()
+    w = torch.zeros(3, 3, A, 64, requires_grad=True)
+    b = torch.zeros(64, requires_grad=True)
+    O.conv2(xr, w, b, 1).backward(ye.float())
+    close(we - 0.25, w.grad, 3e-4, "narrow group dW %s" % (case,))
+    close(be, b.grad, 3e-4, "narrow group dbias %s" % (case,))
+    for g in (0, G - 1):
+        xr = xs[g].float().requires_grad_()
+        w = torch.zeros(3, 3, 64, 64, requires_grad=True)
+        b = torch.zeros(64, requires_grad=True)
+        O.conv2(xr, w, b, 1).backward(ys[g].float())
+        close(got_w[g] - 0.5, w.grad, 3e-4, "trunk group %d beside the narrow one %s" % (g, case))
+        close(got_b[g], b.grad, 3e-4, "trunk dbias %d %s" % (g, case))
+
+
+@pytest.mark.skipif(os.environ.get("TG_WGRAD_TR") == "0", reason="TG_WGRAD_TR=0 switches the transpose-read kernel off")
 @pytest.mark.parametrize("case", [(2, 8, 64, 64), (3, 24, 96, 64), (5, 16, 128, 3), (2, 128, 128, 3), (1, 8, 32, 8)])
 def test_wgrad_transpose_read_kernel_wide_images_and_output_conv(case):
     """Round 3: the transpose-read weight-gradient kernel on images of any width that is a multiple of 32 (tiles of 8 x 32
