@@ -278,6 +278,27 @@ int tg_bicubic_add_preprocess(const float* conv_out /*[B,4h,4w,3]*/, const void*
 int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                 const void* aux1, const void* aux2, void* mid, void* out, int N, int H, int W, int C, int dtype,
                 int w_frag, void* stream);
+/* The residual TRUNK of generator_F -- `for i in range(1, FLAGS.num_resblock + 1): net = residual_block(net, 64, 1, ...)`,
+ * reference lib/frvsr.py:66-70 -- of one frame (mode 0), or the input-gradient chain through the same blocks (mode 1, lib/Teco.py:
+ * 441-449), as ONE persistent launch (csrc/resblock_chain.hip): nblocks (1..16) x tg_resblock(w_frag = 1), bit-identical, with the
+ * kernel boundary between blocks replaced by a neighbour hand-off of the 2-pixel ring around every 4x4 tile (tagged 8-byte
+ * granules, write-through stores, polled with agent-scope loads).  Per-block arrays are HOST arrays of device pointers in
+ * PROCESSING order (mode 1: from the last block of the network to the first): w1 / w2 fragment-order weights of the first / second
+ * conv applied, b1 / b2 nullable (arrays or entries), aux1 (mode 1 only) the saved relu(conv_1) outputs, mid nullable; aux2_last
+ * (nullable) masks the output of the last block processed (mode 1: the ReLU output of the input stage).  x = input of the first
+ * block processed; out[k] may not alias it.
+ * scratch: the byte count tg_resblock_chain_scratch_bytes reports, device memory, ZEROED ONCE by the caller at allocation and then
+ * owned by these calls (control words + granule ring; epochs advance from launch to launch, so it is never cleared again and a
+ * captured launch replays); one scratch per stream -- two launches sharing it may not overlap.
+ * Needs every workgroup resident: TG_EINVAL when N * ceil(H/4) * ceil(W/4) exceeds the number of compute units (the caller then
+ * runs tg_resblock per block).  A workgroup whose wait exceeds ~0.3 s gives up and is counted in ((unsigned*)scratch)[2]
+ * (sticky; results are then garbage -- it means a workgroup could not become resident).
+ * variant: 0 = default; bit 0: a fifth wave sweeps the ring; bits 1.. = prefetch distance of the weight stream (14 / 28 / 35). */
+int tg_resblock_chain_scratch_bytes(int N, int H, int W, int64_t* bytes);
+int tg_resblock_chain(int mode, const void* x, int nblocks, const void* const* w1, const float* const* b1,
+                      const void* const* w2, const float* const* b2, const void* const* aux1, const void* aux2_last,
+                      void* const* mid, void* const* out, void* scratch, int N, int H, int W, int C, int dtype, int variant,
+                      void* stream);
 /* Fragment-order bf16 copies of `count` 64 -> 64 3x3 weights (the residual-block convs of lib/frvsr.py:50-57) for tg_resblock:
  * copy[2 tap + kk][wave][lane][j] = W[tap][row = 16 wave + lane % 16][k = 32 kk + 8 (lane / 16) + j]; dst_t: row = output channel
  * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 2 x int64 per tensor -- offset of the

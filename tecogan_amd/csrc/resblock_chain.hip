@@ -1,0 +1,560 @@
+// The residual TRUNK of generator_F -- `for i in range(1, num_resblock + 1): net = residual_block(net, 64, 1, ...)`, reference
+// lib/frvsr.py:50-57,66-70 -- of one frame, or the input-gradient chain of the same blocks (tf.gradients, lib/Teco.py:441-449),
+// as ONE persistent launch for the LATENCY regime of the training recurrence ([B,32,32,64]: 256 tiles of 4x4 pixels).
+//
+// Why.  csrc/resblock_lat.hip runs a block as one launch: 4.5 us per block in a graph chain, of which ~0.3 us is matrix work --
+// the rest is the kernel boundary (1.45 us), a cold round trip for the halo tile and the 147 KB per-CU weight stream that only
+// starts once the launch has.  19 frames x 16 blocks x 2 directions = 608 such nodes are 58 % of the TecoGAN step.  Here the
+// boundary is replaced by a NEIGHBOUR hand-off inside the launch:
+//   * workgroup = tile, as in resblock_lat.hip (same levels, same MFMA order: results are BIT-IDENTICAL to nb x tg_resblock);
+//     a workgroup keeps its tile for all nb blocks: the block output goes to the centre of the LDS input region in place;
+//   * what a block needs from outside is the 2-pixel ring around the tile (48 pixels x 128 B = 6 KB) from up to 8 neighbour
+//     workgroups.  Every workgroup PUBLISHES its 4x4 output as 8-byte {two bf16 values, tag} granules with write-through (sc1)
+//     stores -- a lane's four channels are one 16-byte store {v01, tag, v23, tag} -- into a two-slot ring (slot = block parity),
+//     and SWEEPS the ring pixels of its neighbours with sc1 loads until every tag equals the expected epoch: the data is the
+//     flag (cdna_hip_programming.md section 6, Guideline 16, form R2): no fence, no flag word, no L1/L2 maintenance;
+//   * write-through stores are what the fabric is slow at (1 MB of them per block over the chip took ~1 us, session D), and a
+//     workgroup's neighbours mostly sit on ITS OWN XCD (an XCD owns a contiguous range of tiles): so there are two rings -- P,
+//     written with PLAIN stores (they reach the XCD's L2, which is the coherence point of its CUs: an L1-bypassing load of a
+//     workgroup on the same XCD sees them, 237 ns against 334 in tools/probe_handoff.hip) and read by same-XCD neighbours only,
+//     and S, written through (sc1) by exactly the lanes whose pixel a neighbour on ANOTHER XCD needs.  Which neighbour is where
+//     is not assumed: every workgroup publishes its hardware XCC id in a tagged word at launch and reads its neighbours';
+//   * two slots suffice: a workgroup writes block k + 1 into slot (k + 1) & 1 = (k - 1) & 1 only after it has read block k
+//     of ALL its neighbours, each of which produced block k only after reading this workgroup's block k - 1;
+//   * tags are monotonic ACROSS launches (tag = epoch base + block index + 1; the base lives in device memory and is advanced
+//     by the last workgroup to arrive at the end of a launch), so the ring is never cleared and a captured graph replays;
+//   * the weight stream does not depend on the hand-off: it is ONE stream over all blocks in consumption order with a prefetch
+//     distance, so block k + 1's first fragments fly while block k's outputs travel;
+//   * every spin is bounded: a workgroup that gives up counts itself in ctrl[2], stops waiting and runs on (garbage, no hang).
+// Requires all workgroups co-resident: ntiles <= number of CUs (checked on the host; one workgroup always fits beside the
+// capped side-stream kernels, and those terminate on their own).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#define RC_MAXB 16
+
+struct RcP {
+  const void* x;                // [N,H,W,64] bf16: input of the first block processed
+  const void* w1[RC_MAXB];      // per block, in processing order: fragment-order weights of the FIRST conv applied
+  const void* w2[RC_MAXB];      // ... of the second
+  const float* b1[RC_MAXB];     // nullable
+  const float* b2[RC_MAXB];     // nullable
+  const void* aux1[RC_MAXB];    // backward: the saved relu(conv_1) output of the block (level-1 mask)
+  void* mid[RC_MAXB];           // level-1 result (nullable per block)
+  void* out[RC_MAXB];           // block output
+  const void* aux2;             // nullable: mask on the LAST block's output (backward: the ReLU of the input stage)
+  unsigned* ctrl;               // [0] epoch base  [1] arrivals  [2] give-ups (sticky)
+  unsigned long long* xccw;     // [tiles] {tag, XCC id} words
+  void* gran;                   // granule rings P (plain stores), S (write-through): 2 x 2 slots x [tiles] x 4 KB (rc_ring_off)
+  int nb, N, H, W, flip;
+  float nslope1;
+  int tiles_y, tiles_x, ntiles;
+  unsigned bytes;               // extent of every [N,H,W,64] tensor
+  unsigned gslot;               // bytes of one ring slot = tiles * 4096
+  unsigned spin_limit;
+  int prio;
+  int noweights;                // trace builds: zero-length weight descriptors (timing without the weight stream; results are wrong)
+};
+
+typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int RC_P = 160;                       // bytes per LDS position (64 bf16 + 32 pad): resblock_lat.hip's layout
+constexpr int RC_XR = 8, RC_XPOS = 8 * 8 + 2;
+constexpr int RC_HR = 12, RC_HPOS = 6 * 12;
+constexpr unsigned RC_OOB = 0x80000000u;
+constexpr int RC_SC1 = 16;                      // buffer aux: sc1 (agent scope: write-through store / L1-bypassing load)
+constexpr int RC_HL = 6;                        // level-2 LDS fragment look-ahead
+}  // namespace
+
+#ifdef TG_RC_TRACE
+// [wave 0..4][block 0..15][stamp 0..7] of the middle workgroup
+__device__ unsigned long long tg_rc_trace_buf[5 * 16 * 8];
+#define RC_STAMP(k, i)                                                                                                  \
+  do {                                                                                                                  \
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) tg_rc_trace_buf[(wave * 16 + (k)) * 8 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
+#define RC_STAT(k) ((blockIdx.x == gridDim.x / 2 && lane == 0) ? &tg_rc_trace_buf[(wave * 16 + (k)) * 8 + 7] : nullptr)
+extern "C" int tg_debug_rc_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_rc_trace_buf), sizeof(unsigned long long) * 5 * 16 * 8);
+}
+#else
+#define RC_STAMP(k, i) do { } while (0)
+#define RC_STAT(k) nullptr
+#endif
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void rc_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    rc_static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ u32x2c rc_pack4(const float (&v)[4]) {
+  u32x2c o;
+  o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+  o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  return o;
+}
+__device__ __forceinline__ void rc_unpack4(const u32x2c& a, float (&f)[4]) {
+  f[0] = __uint_as_float(a.x << 16);
+  f[1] = __uint_as_float(a.x & 0xffff0000u);
+  f[2] = __uint_as_float(a.y << 16);
+  f[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+
+// The ring of the 8x8 region around a 4x4 tile: 48 positions.  hi -> (row, column) of the region.
+__device__ __forceinline__ void rc_ring_pos(int hi, int& ry, int& rx) {
+  if (hi < 16) {
+    ry = hi >> 3; rx = hi & 7;
+  } else if (hi < 32) {
+    const int j = hi - 16, c = j & 3;
+    ry = 2 + (j >> 2); rx = c < 2 ? c : c + 4;
+  } else {
+    const int j = hi - 32;
+    ry = 6 + (j >> 3); rx = j & 7;
+  }
+}
+
+// Ring layout (per slot): [tile][wave 4][pixel 16][fg 4] x 16 B -- a publishing wave's store instruction covers ONE contiguous
+// KiB (8 whole cache lines; as [pixel][channel] it was 16 half lines per instruction, and a write-through store of part of a line
+// is what the fabric is slow at).  Offset of chunk c (= 4 channels: wave c / 4, fg c % 4) of image pixel (gy, gx):
+__device__ __forceinline__ unsigned rc_ring_off(int n, int gy, int gx, int c, int tiles_y, int tiles_x) {
+  const int t = (n * tiles_y + (gy >> 2)) * tiles_x + (gx >> 2);
+  return (unsigned)(t * 4096 + (c >> 2) * 1024 + ((gy & 3) * 4 + (gx & 3)) * 64 + (c & 3) * 16);
+}
+
+// Sweep of NI 16-byte granule pairs per lane until every tag equals `tag` (wave-uniform result), then the 8 payload bytes of each
+// go to LDS.  goff: byte offset inside a ring slot (RC_OOB: position outside the image, nothing to wait for, the LDS position
+// keeps the zeros of the first staging), lpos: LDS byte address of the 8 payload bytes.
+template <int NI>
+__device__ __forceinline__ bool rc_sweep(const __amdgpu_buffer_rsrc_t& rsG, const unsigned (&goff)[NI], const int (&lpos)[NI],
+                                         unsigned char* xs, unsigned soff, unsigned tag, unsigned limit,
+                                         unsigned long long* stat = nullptr) {
+  // TWO polls in flight, half a round trip apart (a poll's round trip is ~560 cycles, a neighbour's granules become visible
+  // ~300 after its stores: one poll at a time samples the ring every ~620 cycles, two every ~300).  While it waits a wave runs
+  // at priority 0 and backs off after 32 round trips: co-resident work of other kernels -- whose progress is what frees a
+  // compute unit for a workgroup of THIS launch that is not resident yet -- is not starved by the pollers (session F: a variant
+  // small enough to stack five workgroups per compute unit beside a GEMM gave up for exactly that reason).
+  u32x4c ga[NI], gb[NI];
+  limit = __builtin_amdgcn_readfirstlane(limit);
+#ifdef TG_RC_TRACE
+  const unsigned long long t0 = clock64();
+#endif
+  auto issue = [&](u32x4c (&g)[NI]) {
+    asm volatile("" ::: "memory");                 // (a poll is re-issued: the loads may not be hoisted or merged)
+#pragma unroll
+    for (int k = 0; k < NI; ++k) g[k] = __builtin_amdgcn_raw_buffer_load_b128(rsG, (int)goff[k], (int)soff, RC_SC1);
+  };
+  auto complete = [&](const u32x4c (&g)[NI]) {
+    unsigned bad = 0;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) bad |= (goff[k] != RC_OOB ? 0xffffffffu : 0u) & ((g[k].y ^ tag) | (g[k].w ^ tag));
+    return !__any(bad != 0);                       // wave-uniform
+  };
+  __builtin_amdgcn_s_setprio(0);
+  issue(ga);
+  __builtin_amdgcn_s_sleep(4);
+  bool ok = false, useb = false;
+  unsigned spins = 0;
+  for (; spins <= limit; ++spins) {
+    issue(gb);
+    if (complete(ga)) { ok = true; break; }
+    issue(ga);
+    if (complete(gb)) { ok = true; useb = true; break; }
+    if (spins > 32) __builtin_amdgcn_s_sleep(32);
+  }
+  if (!ok) return false;
+  auto deliver = [&](const u32x4c (&g)[NI]) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (goff[k] != RC_OOB) *reinterpret_cast<u32x2c*>(xs + lpos[k]) = u32x2c{g[k].x, g[k].z};
+  };
+  if (useb) deliver(gb);                           // (two code paths: a select between the register sets became a scratch array)
+  else deliver(ga);
+#ifdef TG_RC_TRACE
+  if (stat) *stat = ((unsigned long long)(clock64() - t0) << 32) | (2 * spins + 1 + (useb ? 1 : 0));      // cycles | polls checked
+#endif
+  (void)stat;
+  return true;
+}
+
+// HAS_AUX1: level-1 mask (the input-gradient form); DIST: prefetch distance of the weight stream in fragments (36 per block).
+// (A fifth wave that only sweeps -- its own memory queue -- was measured and lost: polling from barrier A on, 2 - 4 polls per
+//  sweep, every block 3 - 6 % slower, profiles/r06a_mb_chain.txt.)
+template <bool HAS_AUX1, int DIST>
+__global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[RC_XPOS * RC_P];
+  __shared__ __attribute__((aligned(16))) unsigned char hs[RC_HPOS * RC_P];
+  static_assert(DIST >= 1 && DIST <= 35, "prefetch distance in fragments");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fg = lane >> 4;
+
+  int b = blockIdx.x;
+  if ((p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);      // an XCD owns a contiguous range of tiles (resblock_lat.hip)
+  const int tx = b % p.tiles_x, t1 = b / p.tiles_x;
+  const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
+  const int y0 = ty * 4, x0 = tx * 4;
+  const int nb = p.nb;
+
+  // epoch base of this launch (every workgroup reads it before any workgroup can have arrived at the end)
+  const unsigned epoch0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.gran, 0, (int)(4u * p.gslot), 0x00020000);
+  const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
+  if (nb > 1 && tid == 0)
+    __hip_atomic_store(p.xccw + b, ((unsigned long long)(epoch0 + 1u) << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned limit = p.spin_limit;                                            // 0 once this workgroup has given up
+
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.bytes, 0x00020000);
+  const int cbyte = (wave * 16 + fg * 4) * 2;       // byte offset of this lane's four output channels inside a pixel
+
+  // ---- loads that do not depend on the block ----------------------------------------------------------------------------------
+  u32x4c xr[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = tid + k * 256;
+    const int pix = item >> 3, ch = item & 7;
+    const int gy = y0 - 2 + (pix >> 3), gx = x0 - 2 + (pix & 7);
+    const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + ch * 16) : RC_OOB), 0, 0);
+  }
+  const int oy = y0 + (frow >> 2), ox = x0 + (frow & 3);
+  const bool out_ok = oy < p.H && ox < p.W;
+  const unsigned out_off = out_ok ? (unsigned)(((n * p.H + oy) * p.W + ox) * 128 + cbyte) : RC_OOB;
+  const unsigned pub_off = out_ok ? rc_ring_off(n, oy, ox, wave * 4 + fg, p.tiles_y, p.tiles_x) : RC_OOB;
+  unsigned m1off[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int ry = 2 * t + (frow >> 3), rx = frow & 7;
+    const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+    const bool ok = rx < 6 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    m1off[t] = ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + cbyte) : RC_OOB;
+  }
+  // the ring items of this lane (3 per lane) and the tile that owns each
+  unsigned goff[3], xoff[6];
+  int lpos[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int item = tid + k * 256;
+    int ry, rx;
+    rc_ring_pos(item >> 4, ry, rx);
+    const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
+    const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    goff[k] = ok ? rc_ring_off(n, gy, gx, item & 15, p.tiles_y, p.tiles_x) : RC_OOB;
+    xoff[k] = ok ? (unsigned)(((n * p.tiles_y + (gy >> 2)) * p.tiles_x + (gx >> 2)) * 8) : RC_OOB;
+    lpos[k] = (ry * RC_XR + rx) * RC_P + (item & 15) * 8;
+  }
+  // the three neighbour tiles that need this lane's pixel (its quadrant of the tile: vertical, horizontal, diagonal neighbour)
+  {
+    const int dy = (frow >> 2) < 2 ? -1 : 1, dx = (frow & 3) < 2 ? -1 : 1;
+    const bool vy = (unsigned)(ty + dy) < (unsigned)p.tiles_y, vx = (unsigned)(tx + dx) < (unsigned)p.tiles_x;
+    xoff[3] = vy ? (unsigned)(((n * p.tiles_y + ty + dy) * p.tiles_x + tx) * 8) : RC_OOB;
+    xoff[4] = vx ? (unsigned)(((n * p.tiles_y + ty) * p.tiles_x + tx + dx) * 8) : RC_OOB;
+    xoff[5] = vy && vx ? (unsigned)(((n * p.tiles_y + ty + dy) * p.tiles_x + tx + dx) * 8) : RC_OOB;
+  }
+
+  // ---- per-block operands: descriptors of block k (cur) and k + 1 (nxt: the weight stream runs ahead) ------------------------
+  auto rsrc_w = [&](const void* w) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, w && !p.noweights ? 9 * 64 * 64 * 2 : 0, 0x00020000); };
+  auto rsrc_b = [&](const float* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q), 0, q ? 256 : 0, 0x00020000); };
+  auto rsrc_t = [&](const void* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q), 0, q ? (int)p.bytes : 0, 0x00020000); };
+  auto rsW1 = rsrc_w(p.w1[0]), rsW2 = rsrc_w(p.w2[0]);
+  auto rsW1n = rsrc_w(nb > 1 ? p.w1[1] : nullptr), rsW2n = rsrc_w(nb > 1 ? p.w2[1] : nullptr);
+
+  // weight stream: position i of a block: i < 18 step i of the first conv (wA[i]), else step i - 18 of the second (wB[i - 18]);
+  // positions 36 .. 36 + 35 are the NEXT block's (same registers: a slot is re-requested DIST - 36 positions after its last use)
+  u32x4c wA[18], wB[18];
+  const int wlane = wave * 1024 + lane * 16;
+  auto wload = [&](const auto& rs, int s) {
+    const int tap = s >> 1, kk = s & 1;
+    const int wtap = p.flip ? 8 - tap : tap;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, (wtap * 2 + kk) * 4096, 0);
+  };
+#define RC_WISSUE(i)                                                                                   \
+  do {                                                                                                 \
+    if constexpr ((i) < 18) wA[(i) < 18 ? (i) : 0] = wload(rsW1, (i));                                 \
+    else if constexpr ((i) < 36) wB[(i) >= 18 && (i) < 36 ? (i) - 18 : 0] = wload(rsW2, (i) - 18);     \
+    else if constexpr ((i) < 54) wA[(i) >= 36 && (i) < 54 ? (i) - 36 : 0] = wload(rsW1n, (i) - 36);    \
+    else wB[(i) >= 54 && (i) < 72 ? (i) - 54 : 0] = wload(rsW2n, (i) - 54);                            \
+  } while (0)
+  rc_static_for<0, DIST>([&](auto i) { RC_WISSUE(decltype(i)::value); });
+
+  // biases and level-1 masks of the first block (those of block k + 1 are requested at the start of level 2 of block k)
+  u32x4c bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b1[0]), (wave * 16 + fg * 4) * 4, 0, 0);
+  u32x4c bq2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b2[0]), (wave * 16 + fg * 4) * 4, 0, 0);
+  u32x2c m1[3];
+  if constexpr (HAS_AUX1) {
+    const auto rsA1 = rsrc_t(p.aux1[0]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) m1[t] = __builtin_amdgcn_raw_buffer_load_b64(rsA1, (int)m1off[t], 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- who is where: the neighbours' XCC ids (published at their launch; one sweep per launch, behind the first loads) ---------
+  unsigned pubS_off = RC_OOB;                      // write-through copy of this lane's granule: only if a cross-XCD neighbour needs it
+  if (nb > 1) {
+    const auto rsXW = __builtin_amdgcn_make_buffer_rsrc(p.xccw, 0, p.ntiles * 8, 0x00020000);
+    u32x2c xw[6];
+    bool got = false;
+    const unsigned lim = __builtin_amdgcn_readfirstlane(limit);
+    for (unsigned spins = 0; spins <= lim; ++spins) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b64(rsXW, (int)xoff[j], 0, RC_SC1);
+      unsigned bad = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bad |= (xoff[j] != RC_OOB ? 0xffffffffu : 0u) & (xw[j].y ^ (epoch0 + 1u));
+      if (!__any(bad != 0)) { got = true; break; }
+      if (spins > 32) __builtin_amdgcn_s_sleep(32);
+      else __builtin_amdgcn_s_sleep(1);
+    }
+    if (!got) {
+      limit = 0;
+      if (lane == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (goff[k] != RC_OOB && (xw[k].x & 15u) != my_xcc) goff[k] += 2u * p.gslot;                 // ring S
+    bool needS = false;
+#pragma unroll
+    for (int j = 3; j < 6; ++j) needS = needS || (xoff[j] != RC_OOB && (xw[j].x & 15u) != my_xcc);
+    if (needS) pubS_off = pub_off;
+  }
+  if (p.prio) __builtin_amdgcn_s_setprio(3);       // (the matrix phases; the sweeps drop to 0)
+
+  // ---- input region of the first block -> LDS (positions outside the image hold zeros from here on) --------------------------
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = tid + k * 256;
+    *reinterpret_cast<u32x4c*>(xs + (item >> 3) * RC_P + (item & 7) * 16) = xr[k];
+  }
+  __syncthreads();
+
+  const unsigned char* xb = xs + ((frow >> 3) * RC_XR + (frow & 7)) * RC_P + fg * 16;
+  const unsigned char* hb = hs + ((frow >> 2) * RC_HR + (frow & 3)) * RC_P + fg * 16;
+  unsigned char* ctr = xs + (((frow >> 2) + 2) * RC_XR + (frow & 3) + 2) * RC_P + cbyte;     // this lane's element of the centre
+
+  for (int k = 0; k < nb; ++k) {
+    RC_STAMP(k, 0);
+    const bool last = k + 1 >= nb;
+    const float bv1[4] = {__uint_as_float(bq1.x), __uint_as_float(bq1.y), __uint_as_float(bq1.z), __uint_as_float(bq1.w)};
+    const float bv2[4] = {__uint_as_float(bq2.x), __uint_as_float(bq2.y), __uint_as_float(bq2.z), __uint_as_float(bq2.w)};
+
+    // ---- level 1: first conv on the 6x6 region, three 2x8 pixel tiles (resblock_lat.hip) --------------------------------------
+    f32x4 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto xfrag = [&](int s, int t) {
+      const int tap = s >> 1, kk = s & 1;
+      return *reinterpret_cast<const uint4*>(xb + ((2 * t + tap / 3) * RC_XR + tap % 3) * RC_P + kk * 64);
+    };
+    uint4 bf[3], nbf[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bf[t] = xfrag(0, t);
+    rc_static_for<0, 18>([&](auto sv) {
+      constexpr int s = decltype(sv)::value;
+      RC_WISSUE(s + DIST);
+      if constexpr (s < 17) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) nbf[t] = xfrag(s + 1, t);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wA[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
+                                                         acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bf[t] = nbf[t];
+    });
+    RC_STAMP(k, 1);
+    const auto rsM = __builtin_amdgcn_make_buffer_rsrc(p.mid[k], 0, p.mid[k] ? (int)p.bytes : 0, 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(p.out[k], 0, (int)p.bytes, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int ry = 2 * t + (frow >> 3), rx = frow & 7;
+      const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+      const bool inimg = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[t][r] + bv1[r];
+        v[r] = fmaxf(v[r], v[r] * p.nslope1);
+      }
+      if constexpr (HAS_AUX1) {
+        float a[4];
+        rc_unpack4(m1[t], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= a[r] > 0.f ? 1.f : 0.f;
+      }
+      u32x2c o = rc_pack4(v);
+      if (!inimg) o = u32x2c{0u, 0u};
+      *reinterpret_cast<u32x2c*>(hs + (ry * RC_HR + rx) * RC_P + cbyte) = o;
+      const bool own = inimg && ry >= 1 && ry <= 4 && rx >= 1 && rx <= 4;
+      __builtin_amdgcn_raw_buffer_store_b64(o, rsM, (int)(own ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + cbyte) : RC_OOB), 0, 0);
+    }
+    __syncthreads();                                                         // barrier A
+    RC_STAMP(k, 2);
+
+    // the next block's small operands (biases, level-1 masks; nothing for the last block: zero-length descriptors); this block's
+    // were consumed above (bv1, m1) or copied (bv2)
+    {
+      const int kn = last ? k : k + 1;
+      bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(last ? nullptr : p.b1[kn]), (wave * 16 + fg * 4) * 4, 0, 0);
+      bq2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(last ? nullptr : p.b2[kn]), (wave * 16 + fg * 4) * 4, 0, 0);
+      if constexpr (HAS_AUX1) {
+        const auto rsA1n = rsrc_t(last ? nullptr : p.aux1[kn]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) m1[t] = __builtin_amdgcn_raw_buffer_load_b64(rsA1n, (int)m1off[t], 0, 0);
+      }
+    }
+    // mask of the last block's output (zero-length descriptor otherwise: reads zeros, ignored below)
+    const bool use_m2 = last && p.aux2 != nullptr;
+    const u32x2c m2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_t(use_m2 ? p.aux2 : nullptr), (int)out_off, 0, 0);
+
+    // ---- level 2: second conv on the 4x4 tile, one accumulator, 18 dependent MFMAs --------------------------------------------
+    f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto hfrag = [&](int s) {
+      return *reinterpret_cast<const uint4*>(hb + ((s / 6) * RC_HR + (s >> 1) % 3) * RC_P + (s & 1) * 64);
+    };
+    uint4 hf[RC_HL];
+#pragma unroll
+    for (int s = 0; s < RC_HL; ++s) hf[s] = hfrag(s);
+    rc_static_for<0, 18>([&](auto sv) {
+      constexpr int s = decltype(sv)::value;
+      RC_WISSUE(18 + s + DIST);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&hf[s % RC_HL]),
+                                                     acc2, 0, 0, 0);
+      if constexpr (s + RC_HL < 18) hf[s % RC_HL] = hfrag(s + RC_HL);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    RC_STAMP(k, 3);
+    // level-2 epilogue: bias, skip (the centre of the region), mask, store; publish; the centre of the next block's region
+    {
+      const u32x2c sk = *reinterpret_cast<const u32x2c*>(ctr);
+      float s[4], v[4];
+      rc_unpack4(sk, s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc2[r] + bv2[r];
+        v[r] += s[r];
+      }
+      float a[4];
+      rc_unpack4(m2, a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= (a[r] > 0.f || !use_m2) ? 1.f : 0.f;
+      const u32x2c o = rc_pack4(v);
+      const unsigned tag = epoch0 + (unsigned)k + 1u;
+      const u32x4c gr = u32x4c{o.x, tag, o.y, tag};
+      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last ? RC_OOB : pubS_off), (int)((unsigned)(2 + (k & 1)) * p.gslot), RC_SC1);
+      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last ? RC_OOB : pub_off), (int)((unsigned)(k & 1) * p.gslot), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(o, rsO, (int)out_off, 0, 0);
+      *reinterpret_cast<u32x2c*>(ctr) = out_ok ? o : u32x2c{0u, 0u};   // (a partial tile's pixels outside the image stay the next conv's zero padding)
+    }
+    // the weight descriptors move on: what was "next" is current, block k + 2 becomes next
+    rsW1 = rsW1n; rsW2 = rsW2n;
+    rsW1n = rsrc_w(k + 2 < nb ? p.w1[k + 2 < nb ? k + 2 : 0] : nullptr);
+    rsW2n = rsrc_w(k + 2 < nb ? p.w2[k + 2 < nb ? k + 2 : 0] : nullptr);
+    RC_STAMP(k, 4);
+
+    // ---- hand-off: the ring of block k + 1's input region from the neighbours' block-k outputs --------------------------------
+    if (!last && limit) {
+      if (!rc_sweep<3>(rsG, goff, lpos, xs, (unsigned)(k & 1) * p.gslot, epoch0 + (unsigned)k + 1u, limit, RC_STAT(k))) {
+        limit = 0;
+        if (lane == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (p.prio) __builtin_amdgcn_s_setprio(3);
+    }
+    RC_STAMP(k, 5);
+    __syncthreads();                                                         // barrier B
+    RC_STAMP(k, 6);
+  }
+#undef RC_WISSUE
+
+  // ---- arrival: the last workgroup advances the epoch base for the next launch -------------------------------------------------
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(p.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)p.ntiles - 1u) {
+      __hip_atomic_store(p.ctrl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.ctrl, epoch0 + (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+extern "C" int tg_resblock_chain_scratch_bytes(int N, int H, int W, int64_t* bytes) {
+  TG_CHECK_ARG(bytes && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
+  const int64_t nt = (int64_t)N * ((H + 3) / 4) * ((W + 3) / 4);
+  *bytes = 256 + ((nt * 8 + 255) / 256) * 256 + 4 * nt * 4096;      // control words, XCC words, rings P and S (2 slots each)
+  return TG_OK;
+}
+
+extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const void* const* w1, const float* const* b1,
+                                 const void* const* w2, const float* const* b2, const void* const* aux1, const void* aux2_last,
+                                 void* const* mid, void* const* out, void* scratch, int N, int H, int W, int C, int dtype,
+                                 int variant, void* stream) {
+  TG_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (input gradient)");
+  TG_CHECK_ARG(dtype == TG_BF16 && C == 64, "bf16 tensors with 64 channels only");
+  TG_CHECK_ARG(nblocks >= 1 && nblocks <= RC_MAXB, "1 .. 16 blocks per launch");
+  TG_CHECK_ARG(x && w1 && w2 && out && scratch && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
+  TG_CHECK_ARG((mode == 1) == (aux1 != nullptr), "aux1 (the saved relu(conv_1) outputs) belongs to mode 1");
+  TG_CHECK_ARG((((uintptr_t)x | (uintptr_t)scratch | (uintptr_t)aux2_last) & 15) == 0, "pointers must be 16-byte aligned");
+  const int64_t bytes = (int64_t)N * H * W * 128;
+  TG_CHECK_ARG(bytes * 4 < ((int64_t)1 << 31), "tensor too large for 32-bit buffer offsets");
+  RcP p;
+  p.x = x;
+  for (int k = 0; k < RC_MAXB; ++k) {
+    const bool on = k < nblocks;
+    p.w1[k] = on ? w1[k] : nullptr; p.w2[k] = on ? w2[k] : nullptr;
+    p.b1[k] = on && b1 ? b1[k] : nullptr; p.b2[k] = on && b2 ? b2[k] : nullptr;
+    p.aux1[k] = on && aux1 ? aux1[k] : nullptr;
+    p.mid[k] = on && mid ? mid[k] : nullptr; p.out[k] = on ? out[k] : nullptr;
+    if (on) {
+      TG_CHECK_ARG(p.w1[k] && p.w2[k] && p.out[k] && (mode == 0 || p.aux1[k]), "null per-block pointer");
+      TG_CHECK_ARG((((uintptr_t)p.w1[k] | (uintptr_t)p.w2[k] | (uintptr_t)p.out[k] | (uintptr_t)p.mid[k] | (uintptr_t)p.aux1[k]) & 15) == 0,
+                   "pointers must be 16-byte aligned");
+    }
+  }
+  p.aux2 = aux2_last;
+  p.ctrl = static_cast<unsigned*>(scratch);
+  p.nb = nblocks; p.N = N; p.H = H; p.W = W;
+  p.flip = mode;
+  p.nslope1 = mode == 0 ? 0.f : 1.f;
+  p.tiles_y = (H + 3) / 4; p.tiles_x = (W + 3) / 4;
+  const int64_t nt = (int64_t)N * p.tiles_y * p.tiles_x;
+  TG_CHECK_ARG(nt <= tg_num_cus(), "more tiles than compute units: the hand-offs need every workgroup resident (use tg_resblock)");
+  p.ntiles = (int)nt;
+  p.bytes = (unsigned)bytes;
+  p.gslot = (unsigned)(nt * 4096);
+  p.xccw = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(scratch) + 256);
+  p.gran = static_cast<unsigned char*>(scratch) + 256 + ((nt * 8 + 255) / 256) * 256;
+  p.spin_limit = 1u << 16;                      // ~0.2 s of backed-off polling before a workgroup gives up
+  p.prio = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double px = (double)N * H * W;
+  const double fl = 2.0 * 2.0 * px * 64.0 * 576.0 * nblocks;
+  const double by = nblocks * (px * 128.0 * (2 + (mid != nullptr) + (aux1 != nullptr)) + 2.0 * 73728.0) + (aux2_last ? px * 128.0 : 0.0);
+  const int dist = (variant >> 1) & 63;          // 0: default
+#ifdef TG_RC_TRACE
+  p.noweights = (variant >> 8) & 1;
+#else
+  p.noweights = 0;
+#endif
+  auto go = [&](auto atag, auto dtag) {
+    constexpr bool A = decltype(atag)::value;
+    constexpr int D = decltype(dtag)::value;
+    TG_LAUNCH(A ? "resblock_chain<bwd>" : "resblock_chain<fwd>", fl, by, (resblock_chain_kernel<A, D>), dim3(p.ntiles), dim3(256), 0, st, p);
+  };
+  using T = std::true_type;
+  using Fa = std::false_type;
+  auto pick = [&](auto atag) {
+    if (dist == 14) go(atag, std::integral_constant<int, 14>{});
+    else if (dist == 4) go(atag, std::integral_constant<int, 4>{});
+    else if (dist == 35) go(atag, std::integral_constant<int, 35>{});
+    else go(atag, std::integral_constant<int, 28>{});
+  };
+  if (mode == 1) pick(T{});
+  else pick(Fa{});
+  TG_CHECK_LAUNCH();
+}

@@ -188,6 +188,47 @@ def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out, w_frag=False):
     return out
 
 
+def resblock_chain_ok(N, H, W):
+    """tg_resblock_chain needs every 4x4-pixel tile's workgroup resident at once: at most one tile per compute unit."""
+    return N * ((H + 3) // 4) * ((W + 3) // 4) <= torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+
+
+def resblock_chain_scratch(N, H, W, device):
+    """The exchange scratch of tg_resblock_chain (control words + granule ring), zeroed once; one per stream."""
+    n = C.c_int64(0)
+    check(lib().tg_resblock_chain_scratch_bytes(N, H, W, C.byref(n)), "tg_resblock_chain_scratch_bytes")
+    return torch.zeros(n.value // 4, dtype=torch.int32, device=device)
+
+
+class ChainArgs:
+    """The per-block pointer arrays of one tg_resblock_chain call, built once (the tensors they point to are kept alive here)."""
+
+    def __init__(self, mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant=0):
+        nb = len(w1)
+        assert nb == len(w2) == len(out) and 1 <= nb <= 16
+        self.keep = (x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch)
+        arr = lambda ts: None if ts is None else (C.c_void_p * nb)(*[None if t is None else _p(t) for t in ts])   # noqa: E731
+        self.a = (arr(w1), arr(b1), arr(w2), arr(b2), arr(aux1), arr(mid), arr(out))
+        self.mode, self.nb, self.variant = mode, nb, variant
+        self.x, self.aux2, self.scratch = x, aux2_last, scratch
+        N, H, W, Cn = x.shape
+        for t in [x] + list(out) + [t for t in (mid or []) if t is not None] + [t for t in (aux1 or []) if t is not None]:
+            assert tuple(t.shape) == (N, H, W, Cn) and t.dtype == x.dtype
+
+    def launch(self):
+        N, H, W, Cn = self.x.shape
+        w1, b1, w2, b2, aux1, mid, out = self.a
+        check(lib().tg_resblock_chain(self.mode, _p(self.x), self.nb, w1, b1, w2, b2, aux1, _p(self.aux2), mid, out, _p(self.scratch),
+                                      N, H, W, Cn, dt(self.x), self.variant, _stream()), "tg_resblock_chain")
+
+
+def resblock_chain(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant=0):
+    """nb residual blocks (mode 0) / their input-gradient chain (mode 1) as ONE persistent launch (csrc/resblock_chain.hip):
+    lists of per-block tensors in processing order, fragment-order weights.  Returns out[-1]."""
+    ChainArgs(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant).launch()
+    return out[-1]
+
+
 def conv3x3_c64_frag_ok(N, H, W):
     """The throughput regime of tg_conv3x3_c64_frag: at least 256 tiles of 8x16 pixels."""
     return N * ((H + 7) // 8) * ((W + 15) // 16) >= 256

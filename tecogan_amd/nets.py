@@ -171,6 +171,11 @@ class Generator:
         self.fused_block = True        # throughput regime (inference): a residual block as ONE launch (csrc/resblock_thr.hip)
         self.input_in_group = True     # the input conv's weight gradient as a narrower last group of the trunk's grouped launch
         self.resblock_lat = self.hr_fwd_lat = self.hr_bwd_lat = True
+        # resblock_chain : the whole residual trunk of a frame (and its input-gradient chain) as ONE persistent launch with neighbour
+        #                 hand-offs instead of kernel boundaries (csrc/resblock_chain.hip; bit-identical to the per-block launches);
+        #                 needs one 4x4 tile per compute unit at most (the training crops: [4,32,32] = 256 tiles)
+        self.resblock_chain = True
+        self.chain_variant = 14 << 1            # prefetch distance of the weight stream (tools/mb_chain.py)
         self.resblock_max_tiles = 1024          # 4x4-pixel tiles up to which one workgroup per tile is the latency-optimal shape
         # scheduling hint for the recurrence's own launches (forward_t / backward_t): K.CONV_COEXIST when throughput work
         # of another stream shares the chip, so that the chain's bigger launches (HR deconv, output conv) also pick tile
@@ -248,8 +253,47 @@ class Generator:
         q["g_t1"], q["g_t2"] = buf(2 * h, 2 * w, 64), buf(4 * h, 4 * w, 64)
         q["g_out"] = buf(4 * h, 4 * w, 8)                       # 3 real channels, zero-padded: 16-B rows for the MFMA paths
         q["dx_in"] = torch.empty(B, h, w, GEN_CPAD, device=dev, dtype=dt)
+        q["chain"] = {}                                         # (mode, t) -> K.ChainArgs, built on first use
+        q["chain_scratch"] = None
         self.seq = q
         return q
+
+    def _chain(self, mode, t):
+        """The trunk of frame t as one persistent launch: pointer arrays built once per (direction, frame)."""
+        ps, p, q, n = self.ps, self.P, self.seq, self.nres
+        ca = q["chain"].get((mode, t))
+        if ca is None:
+            if q["chain_scratch"] is None:
+                q["chain_scratch"] = K.resblock_chain_scratch(q["B"], q["h"], q["w"], q["a"][0].device)
+            cas = []
+            order = list(range(1, n + 1)) if mode == 0 else list(range(n, 0, -1))
+            for c0 in range(0, n, 16):                          # at most 16 blocks per launch
+                blk = order[c0:c0 + 16]
+                nm = [p + "resblock_%d/" % i for i in blk]
+                if mode == 0:
+                    x = q["a"][blk[0] - 1][t]
+                    cas.append(K.ChainArgs(0, x, [ps.packed_frag(s + "conv_1/Conv/weights", True) for s in nm],
+                                           [ps.view(s + "conv_1/Conv/biases") for s in nm],
+                                           [ps.packed_frag(s + "conv_2/Conv/weights", True) for s in nm],
+                                           [ps.view(s + "conv_2/Conv/biases") for s in nm], None, None,
+                                           [q["r"][i][t] for i in blk], [q["a"][i][t] for i in blk], q["chain_scratch"],
+                                           self.chain_variant))
+                else:
+                    x = q["g_c2"][blk[0]][t]
+                    cas.append(K.ChainArgs(1, x, [ps.packed_frag(s + "conv_2/Conv/weights", False) for s in nm], None,
+                                           [ps.packed_frag(s + "conv_1/Conv/weights", False) for s in nm], None,
+                                           [q["r"][i][t] for i in blk], q["a"][0][t] if blk[-1] == 1 else None,
+                                           [q["g_c1"][i][t] for i in blk],
+                                           [q["g_c2"][i - 1][t] if i > 1 else q["g_in"][t] for i in blk], q["chain_scratch"],
+                                           self.chain_variant))
+            ca = q["chain"][(mode, t)] = cas
+        for c in ca:
+            c.launch()
+
+    def _chained(self):
+        q = self.seq
+        return (self._fused_blocks() and self.resblock_chain and self.nres >= 2 and self.ps.frag
+                and K.resblock_chain_ok(q["B"], q["h"], q["w"]))
 
     def _fused_blocks(self):
         """True when the recurrence runs its residual blocks as one launch each: bf16 frames whose 4x4-pixel tiles are few
@@ -266,7 +310,11 @@ class Generator:
         a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
                      out=q["a"][0][t], flags=cf)
         fused = self._fused_blocks()
-        for i in range(1, self.nres + 1):
+        chained = self._chained()
+        if chained:
+            self._chain(0, t)
+            a = q["a"][self.nres][t]
+        for i in range(1, 0 if chained else self.nres + 1):
             s = p + "resblock_%d/" % i
             if fused:
                 a = K.resblock(0, a, ps.packed_frag(s + "conv_1/Conv/weights", True), ps.view(s + "conv_1/Conv/biases"),
@@ -311,7 +359,11 @@ class Generator:
         if n == 0:
             g = K.act_backward(g, q["a"][0][t], g, ACT_RELU)
         fused = self._fused_blocks()
-        for i in range(n, 0, -1):
+        chained = self._chained()
+        if chained:
+            self._chain(1, t)
+            g = q["g_in"][t]
+        for i in range(n if not chained else 0, 0, -1):
             sc = p + "resblock_%d/" % i
             if fused:
                 # d r = bwd(conv_2)(g) * relu'(r) -> g_c1 (conv_1's weight gradient reads it); d a_{i-1} = bwd(conv_1)(d r) + g

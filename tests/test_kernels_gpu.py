@@ -1548,6 +1548,94 @@ def test_resblock_one_launch_input_gradient_is_bit_identical_to_two_launches_and
     close(dx, dx_o, 1e-2, "resblock d x %s" % (shape,))
 
 
+# ---- csrc/resblock_chain.hip: the whole residual trunk of a frame as ONE persistent launch -------------------------------------
+RC_SHAPES = [(4, 32, 32), (2, 8, 8), (1, 5, 7), (3, 6, 6), (1, 13, 9), (1, 4, 4), (2, 3, 2), (1, 64, 60)]
+
+
+@pytest.mark.parametrize("nb", [16, 5, 2, 1])
+@pytest.mark.parametrize("shape", RC_SHAPES)
+def test_resblock_chain_forward_is_bit_identical_to_per_block_launches_and_matches_oracle(shape, nb):
+    """lib/frvsr.py:66-70: `for i in range(1, num_resblock + 1): net = residual_block(net, ...)`.  ONE launch (tg_resblock_chain:
+    neighbour hand-offs instead of kernel boundaries) against nb x tg_resblock -- every intermediate and every block output bit for
+    bit, launched three times on the same scratch (the epochs advance; odd lengths change the slot parity) -- and the last output
+    against the oracle on bf16-rounded operands, the activations rounded to bf16 where the kernels store them."""
+    N, H, W = shape
+    if not K.resblock_chain_ok(N, H, W):
+        pytest.skip("more 4x4 tiles than compute units: the engine runs tg_resblock per block there")
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    x = bf(rnd(N, H, W, 64, seed=31))
+    ws = [bf(rnd(3, 3, 64, 64, seed=40 + i, scale=0.05)) for i in range(2 * nb)]
+    bs = [rnd(64, seed=80 + i, scale=0.2) for i in range(2 * nb)]
+    wt = lambda w: K.frag_order(w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16))      # noqa: E731
+    wf, bd, xd = [wt(w) for w in ws], [b.to(DEV) for b in bs], _dev_bf(x)
+    r_ref = [torch.empty_like(xd) for _ in range(nb)]
+    a_ref = [torch.empty_like(xd) for _ in range(nb)]
+    a = xd
+    for i in range(nb):
+        a = K.resblock(0, a, wf[2 * i], bd[2 * i], wf[2 * i + 1], bd[2 * i + 1], None, None, r_ref[i], a_ref[i], w_frag=True)
+    scratch = K.resblock_chain_scratch(N, H, W, DEV)
+    for rep in range(3):
+        r = [torch.full_like(xd, 7.0) for _ in range(nb)]
+        o = [torch.full_like(xd, 7.0) for _ in range(nb)]
+        K.resblock_chain(0, xd, wf[0::2], bd[0::2], wf[1::2], bd[1::2], None, None, r, o, scratch)
+        torch.cuda.synchronize()
+        assert int(scratch[2]) == 0, "a workgroup gave up waiting for a neighbour"
+        assert int(scratch[0]) == (rep + 1) * nb and int(scratch[1]) == 0            # epoch base advanced, arrivals reset
+        for i in range(nb):
+            assert torch.equal(r[i].view(torch.int16), r_ref[i].view(torch.int16)), "intermediate of block %d (launch %d)" % (i, rep)
+            assert torch.equal(o[i].view(torch.int16), a_ref[i].view(torch.int16)), "output of block %d (launch %d)" % (i, rep)
+    K.resblock_chain(0, xd, wf[0::2], bd[0::2], wf[1::2], bd[1::2], None, None, None, o, scratch)       # stateless: no intermediates
+    torch.cuda.synchronize()
+    assert torch.equal(o[-1].view(torch.int16), a_ref[-1].view(torch.int16))
+    a_o = x
+    for i in range(nb):
+        r_o = torch.relu(O.conv2(a_o, ws[2 * i], bs[2 * i], 1)).bfloat16().float()
+        a_o = bf(a_o + O.conv2(r_o, ws[2 * i + 1], bs[2 * i + 1], 1))
+    close(o[-1], a_o, 2e-2, "trunk output %s x %d" % (shape, nb))
+
+
+@pytest.mark.parametrize("nb", [16, 3])
+@pytest.mark.parametrize("shape", [(4, 32, 32), (1, 5, 7), (3, 6, 6), (1, 13, 9)])
+def test_resblock_chain_input_gradient_is_bit_identical_to_per_block_launches(shape, nb):
+    """tf.gradients through the trunk (lib/Teco.py:441-449), blocks in reverse order: d r_i = bwd(conv_2)(g) * relu'(r_i),
+    g <- g + bwd(conv_1)(d r_i), the last one masked by the input stage's ReLU.  One launch against nb x tg_resblock(mode 1)."""
+    N, H, W = shape
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    g0 = _dev_bf(bf(rnd(N, H, W, 64, seed=51)))
+    wn = lambda w: K.frag_order(w.reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16))      # noqa: E731
+    wf = [wn(bf(rnd(3, 3, 64, 64, seed=60 + i, scale=0.05))) for i in range(2 * nb)]           # [conv_2, conv_1] per block processed
+    rs = [_dev_bf(bf(rnd(N, H, W, 64, seed=100 + i))) for i in range(nb)]
+    a0 = _dev_bf(bf(rnd(N, H, W, 64, seed=99)))
+    dr_ref = [torch.empty_like(g0) for _ in range(nb)]
+    dx_ref = [torch.empty_like(g0) for _ in range(nb)]
+    g = g0
+    for i in range(nb):
+        g = K.resblock(1, g, wf[2 * i], None, wf[2 * i + 1], None, rs[i], a0 if i == nb - 1 else None, dr_ref[i], dx_ref[i], w_frag=True)
+    scratch = K.resblock_chain_scratch(N, H, W, DEV)
+    for rep in range(2):
+        dr = [torch.full_like(g0, 7.0) for _ in range(nb)]
+        dx = [torch.full_like(g0, 7.0) for _ in range(nb)]
+        K.resblock_chain(1, g0, wf[0::2], None, wf[1::2], None, rs, a0, dr, dx, scratch)
+        torch.cuda.synchronize()
+        assert int(scratch[2]) == 0
+        for i in range(nb):
+            assert torch.equal(dr[i].view(torch.int16), dr_ref[i].view(torch.int16)), "d r of block %d" % i
+            assert torch.equal(dx[i].view(torch.int16), dx_ref[i].view(torch.int16)), "d x of block %d" % i
+
+
+def test_resblock_chain_rejects_what_it_does_not_cover():
+    from tecogan_amd._lib import TecoHipError
+    x = torch.zeros(8, 32, 32, 64, device=DEV, dtype=torch.bfloat16)               # 512 tiles: more than compute units
+    w = torch.zeros(9 * 64 * 64, device=DEV, dtype=torch.bfloat16)
+    assert not K.resblock_chain_ok(8, 32, 32)
+    with pytest.raises(TecoHipError):
+        K.resblock_chain(0, x, [w, w], None, [w, w], None, None, None, None, [torch.empty_like(x), torch.empty_like(x)],
+                         K.resblock_chain_scratch(8, 32, 32, DEV))
+    xf = torch.zeros(1, 4, 4, 64, device=DEV)
+    with pytest.raises(TecoHipError):                                              # fp32: the per-conv launches, not this kernel
+        K.resblock_chain(0, xf, [w], None, [w], None, None, None, None, [torch.empty_like(xf)], K.resblock_chain_scratch(1, 4, 4, DEV))
+
+
 def test_resblock_rejects_what_it_does_not_cover():
     from tecogan_amd._lib import TecoHipError
     x = torch.zeros(1, 4, 4, 64, device=DEV)

@@ -117,16 +117,21 @@ def test_bf16_recurrence_with_one_launch_residual_blocks_equals_the_two_launch_r
     F = OT.frvsr_flags(batch_size=2, RNN_N=4, crop_size=32, num_resblock=3)
     x, y = make_batch(F.batch_size, F.RNN_N, F.crop_size)
     res = []
-    for blocks, tails in ((True, False), (False, False), (True, True)):
+    for blocks, tails, chain in ((True, False, True), (False, False, False), (True, True, True), (True, False, False)):
         eng = TrainEngine(F, DEV, gan=False, act_dtype=torch.bfloat16, seed=7, use_graph=False)
         eng.ps.load(damp_values(eng.ps.state_dict()))
         eng.G.resblock_lat = blocks
+        eng.G.resblock_chain = chain          # round 6: the whole trunk of a frame as one persistent launch (csrc/resblock_chain.hip)
         eng.G.hr_fwd_lat = eng.G.hr_bwd_lat = tails
         eng.step(x.to(DEV), y.to(DEV))
         torch.cuda.synchronize()
-        assert eng.G._fused_blocks() is blocks
+        assert eng.G._fused_blocks() is blocks and eng.G._chained() is chain
+        if chain:
+            assert int(eng.G.seq["chain_scratch"][2]) == 0, "a trunk workgroup gave up waiting for a neighbour"
         res.append((eng.gen.clone(), eng.ps.grad.clone(), eng.G.seq["g_in"].clone()))
-    (ga, gra, gia), (gb, grb, gib), (gc, grc, gic) = res
+    (ga, gra, gia), (gb, grb, gib), (gc, grc, gic), (gd, grd, gid) = res
+    assert torch.equal(ga, gd), "HR frames differ between the one-launch trunk and the one-launch-per-block recurrence"
+    assert torch.equal(gia.view(torch.int16), gid.view(torch.int16)) or rel_err(gia, gid) < 2e-2
     assert torch.equal(ga, gb), "HR frames differ between the one-launch and the two-launch recurrence"
     assert torch.equal(gia.view(torch.int16), gib.view(torch.int16)) or rel_err(gia, gib) < 2e-2   # scatter atomics feed the BPTT
     assert rel_err(gra, grb) < 2e-2
