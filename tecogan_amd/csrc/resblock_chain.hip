@@ -185,11 +185,17 @@ __device__ __forceinline__ bool rc_sweep(const __amdgpu_buffer_rsrc_t& rsG, cons
 // HAS_AUX1: level-1 mask (the input-gradient form); DIST: prefetch distance of the weight stream in fragments (36 per block).
 // (A fifth wave that only sweeps -- its own memory queue -- was measured and lost: polling from barrier A on, 2 - 4 polls per
 //  sweep, every block 3 - 6 % slower, profiles/r06a_mb_chain.txt.)
-template <bool HAS_AUX1, int DIST>
+// TR (trace builds): 1 = the weight loads are not even issued (what the matrix phases cost without the stream; results are wrong)
+template <bool HAS_AUX1, int DIST, int TR = 0>
 __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[RC_XPOS * RC_P];
   __shared__ __attribute__((aligned(16))) unsigned char hs[RC_HPOS * RC_P];
-  static_assert(DIST >= 1 && DIST <= 35, "prefetch distance in fragments");
+  // DIST == 0: ALL of a block's weight loads are issued in level 1 -- step s requests the SECOND conv's fragment s of this block
+  // and, once its own fragment has been used, the FIRST conv's fragment s of the next block -- and none in level 2: level 1 is
+  // bound by its LDS fragment reads (12 KB per step against 128 B/clk) and hides the issue of a load (~40 cycles), level 2 is a
+  // chain of 18 dependent MFMAs that hides nothing (1400 -> 650 cycles without loads, profiles/r06k_trace_chain.txt); and by the
+  // time the block's output is published the youngest load has landed, so the polls of the sweep do not queue behind the stream.
+  static_assert(DIST >= 0 && DIST <= 35, "prefetch distance in fragments");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fg = lane >> 4;
@@ -267,6 +273,13 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   // weight stream: position i of a block: i < 18 step i of the first conv (wA[i]), else step i - 18 of the second (wB[i - 18]);
   // positions 36 .. 36 + 35 are the NEXT block's (same registers: a slot is re-requested DIST - 36 positions after its last use)
   u32x4c wA[18], wB[18];
+  if constexpr (TR >= 1) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      wA[i] = wB[i] = u32x4c{(unsigned)lane, 0x3c003c00u, 0x3c003c00u, (unsigned)i};
+      asm volatile("" : "+v"(wA[i]), "+v"(wB[i]));
+    }
+  }
   const int wlane = wave * 1024 + lane * 16;
   auto wload = [&](const auto& rs, int s) {
     const int tap = s >> 1, kk = s & 1;
@@ -275,12 +288,13 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   };
 #define RC_WISSUE(i)                                                                                   \
   do {                                                                                                 \
+    if constexpr (TR >= 1) break;                                                                      \
     if constexpr ((i) < 18) wA[(i) < 18 ? (i) : 0] = wload(rsW1, (i));                                 \
     else if constexpr ((i) < 36) wB[(i) >= 18 && (i) < 36 ? (i) - 18 : 0] = wload(rsW2, (i) - 18);     \
     else if constexpr ((i) < 54) wA[(i) >= 36 && (i) < 54 ? (i) - 36 : 0] = wload(rsW1n, (i) - 36);    \
     else wB[(i) >= 54 && (i) < 72 ? (i) - 54 : 0] = wload(rsW2n, (i) - 54);                            \
   } while (0)
-  rc_static_for<0, DIST>([&](auto i) { RC_WISSUE(decltype(i)::value); });
+  rc_static_for<0, (DIST == 0 ? 18 : DIST)>([&](auto i) { RC_WISSUE(decltype(i)::value); });
 
   // biases and level-1 masks of the first block (those of block k + 1 are requested at the start of level 2 of block k)
   u32x4c bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b1[0]), (wave * 16 + fg * 4) * 4, 0, 0);
@@ -347,27 +361,55 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
     f32x4 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto xfrag = [&](int s, int t) {
-      const int tap = s >> 1, kk = s & 1;
-      return *reinterpret_cast<const uint4*>(xb + ((2 * t + tap / 3) * RC_XR + tap % 3) * RC_P + kk * 64);
+    // The three taps of a kernel row read the SAME LDS rows shifted by one / two columns, and a pixel tile's 16 lanes of one
+    // K group are two region rows of 8 columns: the fragment of tap column dx is the fragment of column 0 shifted by dx lanes
+    // inside its 16-lane row (DPP row_shl; lanes shifted in from the next tile row are what the LDS read at column 8, 9 -- the
+    // next row's columns 0, 1 -- returned, lanes without a source belong to the padding columns 6, 7).  One LDS read per (kernel
+    // row, K half, tile) instead of three: level 1 was bound by its 216 KB of fragment reads (12 KB per step against 128 B/clk).
+    auto xbase = [&](int dy, int kk, int t) {
+      return *reinterpret_cast<const uint4*>(xb + ((2 * t + dy) * RC_XR) * RC_P + kk * 64);
     };
-    uint4 bf[3], nbf[3];
+    auto shl = [&](const uint4& v, auto dxv) {
+      constexpr int dx = decltype(dxv)::value;
+      if constexpr (dx == 0) return v;
+      else {
+        uint4 o;
+        o.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x100 + dx, 0xf, 0xf, true);
+        o.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x100 + dx, 0xf, 0xf, true);
+        o.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x100 + dx, 0xf, 0xf, true);
+        o.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x100 + dx, 0xf, 0xf, true);
+        return o;
+      }
+    };
+    uint4 base[2][3], nbase[2][3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) bf[t] = xfrag(0, t);
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) base[kk][t] = xbase(0, kk, t);
     rc_static_for<0, 18>([&](auto sv) {
       constexpr int s = decltype(sv)::value;
-      RC_WISSUE(s + DIST);
-      if constexpr (s < 17) {
+      constexpr int tap = s >> 1, kk = s & 1, dy = tap / 3, dx = tap % 3;
+      if constexpr (DIST == 0) RC_WISSUE(18 + s);
+      else RC_WISSUE(s + DIST);
+      if constexpr (dx == 0 && dy < 2 && TR != 2) {             // the next kernel row's fragments: a whole row of MFMAs ahead
 #pragma unroll
-        for (int t = 0; t < 3; ++t) nbf[t] = xfrag(s + 1, t);
+        for (int t = 0; t < 3; ++t) nbase[kk][t] = xbase(dy + 1, kk, t);
       }
+      uint4 bf[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bf[t] = TR == 2 ? base[0][t] : shl(base[kk][t], std::integral_constant<int, dx>{});
 #pragma unroll
       for (int t = 0; t < 3; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wA[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
                                                          acc[t], 0, 0, 0);
+      if constexpr (DIST == 0) RC_WISSUE(36 + s);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (dx == 2 && kk == 1 && dy < 2 && TR != 2) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) bf[t] = nbf[t];
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) base[q][t] = nbase[q][t];
+      }
     });
     RC_STAMP(k, 1);
     const auto rsM = __builtin_amdgcn_make_buffer_rsrc(p.mid[k], 0, p.mid[k] ? (int)p.bytes : 0, 0x00020000);
@@ -424,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
     for (int s = 0; s < RC_HL; ++s) hf[s] = hfrag(s);
     rc_static_for<0, 18>([&](auto sv) {
       constexpr int s = decltype(sv)::value;
-      RC_WISSUE(18 + s + DIST);
+      if constexpr (DIST != 0) RC_WISSUE(18 + s + DIST);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&hf[s % RC_HL]),
                                                      acc2, 0, 0, 0);
       if constexpr (s + RC_HL < 18) hf[s % RC_HL] = hfrag(s + RC_HL);
@@ -549,7 +591,16 @@ extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const voi
   using T = std::true_type;
   using Fa = std::false_type;
   auto pick = [&](auto atag) {
+#ifdef TG_RC_TRACE
+    if ((variant >> 9) & 1) {
+      constexpr bool A = decltype(atag)::value;
+      if ((variant >> 10) & 1) TG_LAUNCH("resblock_chain<trace2>", fl, by, (resblock_chain_kernel<A, 14, 2>), dim3(p.ntiles), dim3(256), 0, st, p);
+      else TG_LAUNCH("resblock_chain<trace>", fl, by, (resblock_chain_kernel<A, 14, 1>), dim3(p.ntiles), dim3(256), 0, st, p);
+      return;
+    }
+#endif
     if (dist == 14) go(atag, std::integral_constant<int, 14>{});
+    else if (dist == 63) go(atag, std::integral_constant<int, 0>{});
     else if (dist == 4) go(atag, std::integral_constant<int, 4>{});
     else if (dist == 35) go(atag, std::integral_constant<int, 35>{});
     else go(atag, std::integral_constant<int, 28>{});

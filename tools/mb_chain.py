@@ -68,7 +68,7 @@ def same(a, b):
     return all(torch.equal(p.view(torch.int16), q.view(torch.int16)) for p, q in zip(a, b))
 
 
-VARIANTS = [(0, "prefetch distance 28"), (4 << 1, "prefetch distance 4"), (14 << 1, "prefetch distance 14"), (35 << 1, "prefetch distance 35")]
+VARIANTS = [(63 << 1, "all loads in level 1"), (14 << 1, "prefetch distance 14"), (0, "prefetch distance 28")]
 print("residual trunk [%d,%d,%d,64] x %d blocks: ONE persistent launch (tg_resblock_chain) against %d launches (tg_resblock)" % (N, H, W, NB, NB))
 scratch = K.resblock_chain_scratch(N, H, W, DEV)
 side = torch.cuda.Stream()
@@ -108,7 +108,7 @@ for mode, label in ((0, "forward"), (1, "input gradient")):
               % (label, vlabel, ok_idle, ok_load, nbs_ok, int(scratch[2]), int(scratch[0]), " ".join(detail)))
 
 if TRACE:
-    VARIANTS += [(256, "NO WEIGHT STREAM, distance 28")]
+    VARIANTS += [(256, "NO WEIGHT STREAM, distance 28"), (512, "NO WEIGHT LOADS ISSUED"), (512 | 1024, "... AND NO LEVEL-1 LDS READS")]
 print("time per block, graph of 4 trunks x %d blocks (each trunk = one frame's chain):" % NB)
 for mode, label in ((0, "forward"), (1, "input gradient")):
     mid, out = bufs(), bufs()
