@@ -58,6 +58,10 @@ int tg_prof_collect(tg_prof_entry* out, int max_entries, int* count /* total dis
 /* *dst (device, uint64) = the device's 100 MHz wall clock when the stream reaches this point; capturable, so it can mark
  * segment boundaries inside a replayed hipGraph. */
 int tg_prof_stamp(void* dst, void* stream);
+/* Census of a captured hipGraph (a hipGraph_t passed as void*): number of nodes and of kernel nodes.  Host-only, no launch.  The
+ * data-parallel engine (no counterpart in the reference, which has no multi-GPU code) checks with it that its captured exchange
+ * segments hold the collective's kernels: RCCL elides them for a one-rank communicator and the captured graph is empty. */
+int tg_graph_node_count(void* graph, int* total, int* kernels);
 
 /* ------------------------------------------------------------------------ *
  * Convolution engine (implicit GEMM on MFMA).

@@ -98,6 +98,7 @@ SIGNATURES["tg_frame_to_u8"] = [_P, _P, _L, _I, _P]
 SIGNATURES["tg_prof_enable"] = [_I]
 SIGNATURES["tg_prof_collect"] = [C.POINTER(ProfEntry), _I, C.POINTER(C.c_int)]
 SIGNATURES["tg_prof_stamp"] = [_P, _P]
+SIGNATURES["tg_graph_node_count"] = [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
 _lib = None
 

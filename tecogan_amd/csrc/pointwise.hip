@@ -565,6 +565,9 @@ __global__ __launch_bounds__(256) void bn_stats_x8_kernel(const u16* __restrict_
 
 // stats[r][0][c] / stats[r][1][c], r < TG_BN_STAT_REPLICAS: partial E[x] / E[x^2] accumulated by the producing conv's epilogue
 // -> stats[0] = [mean, biased variance E[x^2] - mean^2]
+// Deliberate deviation from tf.nn.moments (two-pass, lib/ops.py:89 through slim.batch_norm): single-pass moments of the conv's fp32
+// accumulators, clamped at 0.  The cancellation error is eps_fp32 * mean^2 absolute; held by
+// tests/test_kernels_gpu.py::test_conv4x4s2_fused_bn_statistics_with_large_mean_small_variance_channels at |mean| / std = 80 (1 %).
 __global__ __launch_bounds__(256) void bn_moment_to_var_kernel(float* __restrict__ stats, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;

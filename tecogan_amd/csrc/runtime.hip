@@ -118,3 +118,30 @@ extern "C" int tg_prof_stamp(void* dst, void* stream) {
   TG_CHECK_LAUNCH();
   return TG_OK;
 }
+
+// Node census of a captured hipGraph (the handle torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph() returns): total nodes and
+// kernel nodes.  The multi-GPU engine asserts with it that a captured exchange segment really carries its RCCL kernels -- a
+// one-rank communicator elides them and the captured graph is EMPTY, which an 8-GPU node must not discover by a wrong result.
+extern "C" int tg_graph_node_count(void* graph, int* total, int* kernels) {
+  TG_CHECK_ARG(graph != nullptr && total != nullptr && kernels != nullptr, "null pointer");
+  size_t n = 0;
+  if (hipGraphGetNodes(static_cast<hipGraph_t>(graph), nullptr, &n) != hipSuccess) {
+    tg_set_error("tg_graph_node_count: hipGraphGetNodes failed: %s", hipGetErrorString(hipGetLastError()));
+    return TG_ELAUNCH;
+  }
+  std::vector<hipGraphNode_t> nodes(n);
+  int k = 0;
+  if (n > 0) {
+    if (hipGraphGetNodes(static_cast<hipGraph_t>(graph), nodes.data(), &n) != hipSuccess) {
+      tg_set_error("tg_graph_node_count: hipGraphGetNodes failed: %s", hipGetErrorString(hipGetLastError()));
+      return TG_ELAUNCH;
+    }
+    for (size_t i = 0; i < n; ++i) {
+      hipGraphNodeType t;
+      if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k;
+    }
+  }
+  *total = (int)n;
+  *kernels = k;
+  return TG_OK;
+}

@@ -143,9 +143,15 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         self._announced = None                          # (tensor, its _version) announced as next_targets: identity check in step()
         self._hold = []
         self.comm_stream = _shared_stream(self.dev, "C") if self.world > 1 else None
-        # captured exchange segments are launched from their own host thread (segments.SegmentRunner); TG_COMM_THREAD=0 keeps
-        # their just-in-time waits on the caller's thread (the round-4 behaviour) should a backend object to the second thread
-        self.comm_thread = os.environ.get("TG_COMM_THREAD", "1") != "0"
+        # Captured exchange segments can be launched from their own host thread (segments.SegmentRunner), so that the just-in-time
+        # wait in front of a collective does not hold up the other streams' launches.  That thread has only ever launched the
+        # stand-in kernels (no multi-GPU node was available to the builder), so with a REAL process group the default is the
+        # caller's thread until a 2+ rank RCCL run has exercised it; TG_COMM_THREAD=1 / 0 decides explicitly.
+        env = os.environ.get("TG_COMM_THREAD")
+        self.comm_thread = (env != "0") if env is not None else (self.pg is None)
+        # a captured exchange segment without a kernel node is an error whenever real ranks depend on it
+        self.require_exchange_nodes = self.pg is not None and self.world > 1
+        self.exchange_nodes = {}                 # segment -> (nodes, kernel nodes) of its captured graph
         self.exchange_segments = []              # names of the communication-stream segments of the captured program
         self.streams = {"S": self.side_stream, "C": self.comm_stream}
         # a step that uses a second stream (overlap pieces, RCCL) is replayed as a DAG of single-stream graph segments

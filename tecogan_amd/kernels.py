@@ -188,6 +188,13 @@ def resblock(mode, x, w1, b1, w2, b2, aux1, aux2, mid, out, w_frag=False):
     return out
 
 
+def graph_node_count(raw_graph):
+    """(nodes, kernel nodes) of a captured graph: raw_graph = torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()."""
+    n, k = C.c_int(0), C.c_int(0)
+    check(lib().tg_graph_node_count(C.c_void_p(int(raw_graph)), C.byref(n), C.byref(k)), "tg_graph_node_count")
+    return n.value, k.value
+
+
 def resblock_chain_ok(N, H, W):
     """tg_resblock_chain needs every 4x4-pixel tile's workgroup resident at once: at most one tile per compute unit."""
     return N * ((H + 3) // 4) * ((W + 3) // 4) <= torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
@@ -250,12 +257,16 @@ def pack_wide_frag(w, w_frag, Cout, Cin, flip):
     return w_frag
 
 
-def conv3x3_wide_frag_ok(desc):
-    """Shapes tg_conv3x3_wide_frag covers: wide 3x3 stride-1 SAME bf16 layers on images larger than 8x8, or of exactly 8x8
-    pixels (packed tiles)."""
-    return (desc.KH == 3 and desc.KW == 3 and desc.stride == 1 and desc.Cin % 32 == 0 and desc.Cin > 64 and desc.Cout % 64 == 0
-            and desc.in_dtype == 1 and desc.out_dtype == 1
-            and ((desc.Hin > 8 and desc.Win > 8) or (desc.Hin == 8 and desc.Win == 8)))
+def conv3x3_wide_frag_ok(desc, res=None):
+    """What tg_conv3x3_wide_frag covers (the mirror of its argument checks, so that anything else falls back to tg_conv_forward
+    instead of raising): wide 3x3 stride-1 SAME bf16 layers with a none / ReLU / LeakyReLU epilogue on images larger than 8x8, or of
+    exactly 8x8 pixels (packed tiles: no residual operand)."""
+    if not (desc.KH == 3 and desc.KW == 3 and desc.stride == 1 and desc.Cin % 32 == 0 and desc.Cin > 64 and desc.Cout % 64 == 0
+            and desc.in_dtype == 1 and desc.out_dtype == 1 and desc.act < L.ACT_TANH):
+        return False
+    if desc.Hin == 8 and desc.Win == 8:
+        return res is None
+    return desc.Hin > 8 and desc.Win > 8
 
 
 def conv3x3_wide_frag(desc, x, w_frag, bias, res, aux, out, tile_rows=0, ksplit=0):
@@ -280,14 +291,17 @@ def pack_taps_frag_multi(src_t, src_n, dst, tab, count):
     check(lib().tg_pack_taps_frag_multi(_p(src_t), _p(src_n), _p(dst), _p(tab), count, _stream()), "tg_pack_taps_frag_multi")
 
 
-def conv4x4s2_frag_ok(desc):
-    """Shapes tg_conv4x4s2_frag covers: the discriminator's 4x4 stride-2 bf16 convs (even sizes) and their input gradients."""
+def conv4x4s2_frag_ok(desc, bias=None, aux=None):
+    """What tg_conv4x4s2_frag covers (the mirror of its argument checks): the discriminator's 4x4 stride-2 bf16 convs (even sizes;
+    epilogue bias, none / ReLU / LeakyReLU, residual -- no mask operand) and their input gradients (residual and activation mask
+    only: no bias, no activation)."""
     if not (desc.KH == 4 and desc.KW == 4 and desc.stride == 2 and desc.pad_t == 1 and desc.pad_l == 1 and desc.Cin % 32 == 0
             and desc.Cout % 64 == 0 and desc.in_dtype == 1 and desc.out_dtype == 1):
         return False
     if desc.mode == 0:
-        return desc.Hin % 2 == 0 and desc.Win % 2 == 0 and desc.Hout * 2 == desc.Hin and desc.Wout * 2 == desc.Win
-    return desc.Hout == 2 * desc.Hin and desc.Wout == 2 * desc.Win
+        return (aux is None and desc.act < L.ACT_TANH
+                and desc.Hin % 2 == 0 and desc.Win % 2 == 0 and desc.Hout * 2 == desc.Hin and desc.Wout * 2 == desc.Win)
+    return bias is None and desc.act == L.ACT_NONE and desc.Hout == 2 * desc.Hin and desc.Wout == 2 * desc.Win
 
 
 def conv4x4s2_frag(desc, x, w_frag, bias, res, aux, out, bn_stats=None):

