@@ -40,7 +40,7 @@ struct ConvP {
   float mask_alpha;
   int vec;  // Cin % (16B worth) == 0 -> 16-byte loads
   float nslope, mslope;  // act(v) = max(v, v*nslope); mask = aux > 0 ? 1 : mslope
-  int direct_epi;        // always 0 (the LDS-staged rows won; kept for the fp32 path)
+  int direct_epi;        // per-lane fp32 epilogue: launches with a residual / LeakyReLU-mask operand (one rounding), and the fp32 path
   unsigned in_bytes, w_bytes;   // != 0: both operands < 2^31 bytes -> bounds-checked buffer loads (see load_vec)
   int sinv;                     // ceil(2^16 / stride)
 };
@@ -393,7 +393,9 @@ extern "C" int tg_conv_forward(const tg_conv_desc* d, const void* in, const void
   p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.s = d->stride; p.pt = d->pad_t; p.pl = d->pad_l; p.mode = d->mode;
   p.act = d->act; p.act_alpha = d->act_alpha; p.mask_act = d->mask_act; p.mask_alpha = d->mask_alpha;
-  const int direct = 0;
+  // (a residual or LeakyReLU-mask operand: the fp32 register epilogue, ONE rounding -- the staged one would round the tile to bf16
+  //  first and the sum again; see conv3x3.hip)
+  const int direct = (res != nullptr || (aux != nullptr && d->mask_act == TG_ACT_LRELU)) ? 1 : 0;
   p.direct_epi = direct;
   p.nslope = d->act == TG_ACT_RELU ? 0.f : (d->act == TG_ACT_LRELU ? d->act_alpha : 1.f);
   p.mslope = d->mask_act == TG_ACT_RELU ? 0.f : (d->mask_act == TG_ACT_LRELU ? d->mask_alpha : 1.f);
