@@ -24,7 +24,31 @@ from tecogan_amd.engine import TrainEngine  # noqa: E402
 from tecogan_amd.params import damp_values  # noqa: E402
 
 
+def ratios(blob, out):
+    """One deterministic-mode C3 step from the weights / batch / oracle gradients the parity test saved: per gradient tensor
+    [relative L2, max-norm] of this path against the fp64 oracle, and the fp32 oracle's own two figures."""
+    import json
+    d = torch.load(blob)
+    F = OT.default_flags()
+    eng = TrainEngine(F, "cuda:0", gan=True, act_dtype=torch.float32, seed=7, use_graph=False)
+    eng.ps.load(d["P_init"])
+    eng.vps.load(d["vgg"])
+    eng.step(d["x"].cuda(), d["y"].cuda())
+    torch.cuda.synchronize()
+    res = {}
+    for name, ref in d["g64"].items():
+        ref = ref.double()
+        mine, o32 = eng.ps.gview(name).detach().cpu().double(), d["g32"][name].double()
+        nrm, mxn = ref.norm().clamp_min(1e-30), ref.abs().max().clamp_min(1e-30)
+        res[name] = [((mine - ref).norm() / nrm).item(), ((mine - ref).abs().max() / mxn).item(),
+                     ((o32 - ref).norm() / nrm).item(), ((o32 - ref).abs().max() / mxn).item()]
+    json.dump(res, open(out, "w"), indent=0, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--ratios":
+        assert os.environ.get("TG_DETERMINISTIC") == "1", "the frozen numbers belong to the ordered-reduction parity mode"
+        return ratios(sys.argv[2], sys.argv[3])
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c3", choices=["c3", "small"])
     ap.add_argument("--runs", type=int, default=6)
