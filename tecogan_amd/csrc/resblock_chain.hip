@@ -130,13 +130,15 @@ __device__ __forceinline__ unsigned rc_ring_off(int n, int gy, int gx, int c, in
 // Sweep of NI 16-byte granule pairs per lane until every tag equals `tag` (wave-uniform result), then the 8 payload bytes of each
 // go to LDS.  goff: byte offset inside a ring slot (RC_OOB: position outside the image, nothing to wait for, the LDS position
 // keeps the zeros of the first staging), lpos: LDS byte address of the 8 payload bytes.
-template <int NI>
+// SM (sweep mode): 3 = two polls in flight; 0 / 1 / 2 = one poll at a time, the first one 0 / 128 / 256 cycles after the publish
+template <int NI, int SM = 0>
 __device__ __forceinline__ bool rc_sweep(const __amdgpu_buffer_rsrc_t& rsG, const unsigned (&goff)[NI], const int (&lpos)[NI],
                                          unsigned char* xs, unsigned soff, unsigned tag, unsigned limit,
                                          unsigned long long* stat = nullptr) {
-  // TWO polls in flight, half a round trip apart (a poll's round trip is ~560 cycles, a neighbour's granules become visible
-  // ~300 after its stores: one poll at a time samples the ring every ~620 cycles, two every ~300).  While it waits a wave runs
-  // at priority 0 and backs off after 32 round trips: co-resident work of other kernels -- whose progress is what frees a
+  // One poll at a time (round trip ~560 cycles; a neighbour's granules become visible ~300 after its stores).  Two polls in
+  // flight half a round trip apart (SM = 3) and a delayed first poll (SM = 1, 2) were measured: 3.39 / 3.32 / 3.31 against 3.30 us
+  // per block (profiles/r06t_trace_chain.txt) -- what a sweep waits for is the LAST of eight neighbours, not the poll phase.
+  // While it waits a wave runs at priority 0 and backs off after 32 round trips: co-resident work of other kernels -- whose progress is what frees a
   // compute unit for a workgroup of THIS launch that is not resident yet -- is not starved by the pollers (session F: a variant
   // small enough to stack five workgroups per compute unit beside a GEMM gave up for exactly that reason).
   u32x4c ga[NI], gb[NI];
@@ -156,16 +158,27 @@ __device__ __forceinline__ bool rc_sweep(const __amdgpu_buffer_rsrc_t& rsG, cons
     return !__any(bad != 0);                       // wave-uniform
   };
   __builtin_amdgcn_s_setprio(0);
-  issue(ga);
-  __builtin_amdgcn_s_sleep(4);
   bool ok = false, useb = false;
   unsigned spins = 0;
-  for (; spins <= limit; ++spins) {
-    issue(gb);
-    if (complete(ga)) { ok = true; break; }
+  if constexpr (SM == 3) {
     issue(ga);
-    if (complete(gb)) { ok = true; useb = true; break; }
-    if (spins > 32) __builtin_amdgcn_s_sleep(32);
+    __builtin_amdgcn_s_sleep(4);
+    for (; spins <= limit; ++spins) {
+      issue(gb);
+      if (complete(ga)) { ok = true; break; }
+      issue(ga);
+      if (complete(gb)) { ok = true; useb = true; break; }
+      if (spins > 32) __builtin_amdgcn_s_sleep(32);
+    }
+  } else {
+    if constexpr (SM == 1) __builtin_amdgcn_s_sleep(2);
+    if constexpr (SM == 2) __builtin_amdgcn_s_sleep(4);
+    for (; spins <= limit; ++spins) {
+      issue(ga);
+      if (complete(ga)) { ok = true; break; }
+      if (spins > 32) __builtin_amdgcn_s_sleep(32);
+      else __builtin_amdgcn_s_sleep(1);
+    }
   }
   if (!ok) return false;
   auto deliver = [&](const u32x4c (&g)[NI]) {
@@ -186,7 +199,7 @@ __device__ __forceinline__ bool rc_sweep(const __amdgpu_buffer_rsrc_t& rsG, cons
 // (A fifth wave that only sweeps -- its own memory queue -- was measured and lost: polling from barrier A on, 2 - 4 polls per
 //  sweep, every block 3 - 6 % slower, profiles/r06a_mb_chain.txt.)
 // TR (trace builds): 1 = the weight loads are not even issued (what the matrix phases cost without the stream; results are wrong)
-template <bool HAS_AUX1, int DIST, int TR = 0>
+template <bool HAS_AUX1, int DIST, int TR = 0, int SM = 0>
 __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[RC_XPOS * RC_P];
   __shared__ __attribute__((aligned(16))) unsigned char hs[RC_HPOS * RC_P];
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
 
     // ---- hand-off: the ring of block k + 1's input region from the neighbours' block-k outputs --------------------------------
     if (!last && limit) {
-      if (!rc_sweep<3>(rsG, goff, lpos, xs, (unsigned)(k & 1) * p.gslot, epoch0 + (unsigned)k + 1u, limit, RC_STAT(k))) {
+      if (!rc_sweep<3, SM>(rsG, goff, lpos, xs, (unsigned)(k & 1) * p.gslot, epoch0 + (unsigned)k + 1u, limit, RC_STAT(k))) {
         limit = 0;
         if (lane == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -592,6 +605,14 @@ extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const voi
   using Fa = std::false_type;
   auto pick = [&](auto atag) {
 #ifdef TG_RC_TRACE
+    if ((variant >> 11) & 3) {
+      constexpr bool A = decltype(atag)::value;
+      const int sm = ((variant >> 11) & 3) - 1;
+      if (sm == 0) TG_LAUNCH("resblock_chain<sm3>", fl, by, (resblock_chain_kernel<A, 14, 0, 3>), dim3(p.ntiles), dim3(256), 0, st, p);
+      else if (sm == 1) TG_LAUNCH("resblock_chain<sm1>", fl, by, (resblock_chain_kernel<A, 14, 0, 1>), dim3(p.ntiles), dim3(256), 0, st, p);
+      else TG_LAUNCH("resblock_chain<sm2>", fl, by, (resblock_chain_kernel<A, 14, 0, 2>), dim3(p.ntiles), dim3(256), 0, st, p);
+      return;
+    }
     if ((variant >> 9) & 1) {
       constexpr bool A = decltype(atag)::value;
       if ((variant >> 10) & 1) TG_LAUNCH("resblock_chain<trace2>", fl, by, (resblock_chain_kernel<A, 14, 2>), dim3(p.ntiles), dim3(256), 0, st, p);

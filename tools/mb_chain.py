@@ -108,7 +108,8 @@ for mode, label in ((0, "forward"), (1, "input gradient")):
               % (label, vlabel, ok_idle, ok_load, nbs_ok, int(scratch[2]), int(scratch[0]), " ".join(detail)))
 
 if TRACE:
-    VARIANTS += [(256, "NO WEIGHT STREAM, distance 28"), (512, "NO WEIGHT LOADS ISSUED"), (512 | 1024, "... AND NO LEVEL-1 LDS READS")]
+    VARIANTS += [(1 << 11, "two polls in flight"), (2 << 11, "one poll at a time, after 128"), (3 << 11, "one poll at a time, after 256"),
+                 (256, "NO WEIGHT STREAM, distance 28"), (512, "NO WEIGHT LOADS ISSUED"), (512 | 1024, "... AND NO LEVEL-1 LDS READS")]
 print("time per block, graph of 4 trunks x %d blocks (each trunk = one frame's chain):" % NB)
 for mode, label in ((0, "forward"), (1, "input gradient")):
     mid, out = bufs(), bufs()
