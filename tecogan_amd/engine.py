@@ -124,6 +124,7 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         # (round 4: default 103, i.e. bit 8 off -- D's own-gradient passes on the MAIN stream, in the ~1.1 ms it would otherwise
         #  wait for the last chunk's VGG pass, instead of beside the BPTT: 9.15 / 9.18 -> 9.07 / 9.09 ms, profiles/r04k_ab.txt)
         self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "103")) & 111) if self.overlap else 0
+        self.wgrad_cut = 0                       # BPTT cut for early generator weight gradients (see _program_compute); 0 = off
         # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Measured in
         # round 4 (same box, profiles/r04a_ab.txt): 10.97 -> 10.66 ms per TecoGAN step; TG_VGGT_DEDUP=0 is the A/B switch.
@@ -414,16 +415,26 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
                 K.pack_d_input_backward(dx, gen, gd["args"][0], gd["args"][1], gd["args"][2], gd["args"][3], d_gen, B, h, h,
                                         gd["off"], gd["merge"])
                 hold.append(dx)
+        # BPTT cut (round 6, `wgrad_cut` = c > 0): the generator's weight gradients of frames c .. T-1 on the side stream beside
+        # the BPTT of frames c-1 .. 0 -- the side stream idles there once the target lookahead is through -- so that the tail
+        # beside FNet's backward pass carries the weight gradients of c frames only.  (Round 4 measured this a loss with the
+        # per-block chain, profiles/r04u_ab.txt; re-measured with the one-launch trunk: profiles/r06w_ab.txt.)
+        wcut = self.wgrad_cut if (gw_side and 0 < self.wgrad_cut < T) else 0
         with seg("bwd_b", "M", vgg_segs):
             if self.use_vgg:
                 K.lincomb(d_vgg, None, d_gen, 1.0, 0.0, accumulate=True)           # the chunks' perceptual-loss gradients
-            backward_frames(T, 0)
+            backward_frames(T, wcut)
             if not tail_split and not gw_side:
                 self.G.wgrad_sequence(0, T)
                 self.Fn.backward(fsaved, d_flow)
+        if wcut:
+            with seg("wgrad_a", "S", ["bwd_b", "vggt_next"]):
+                self.G.wgrad_sequence(wcut, T, flags=K.CONV_COEXIST)
+            with seg("bwd_c", "M", []):
+                backward_frames(wcut, 0)
         if tail_split or gw_side:
-            with seg("wgrad", "S" if gw_side else "M", ["bwd_b"]):       # (bit 32: beside FNet's backward pass)
-                self.G.wgrad_sequence(0, T)
+            with seg("wgrad", "S" if gw_side else "M", ["bwd_c" if wcut else "bwd_b", "wgrad_a"]):       # (bit 32: beside FNet's backward pass)
+                self.G.wgrad_sequence(0, wcut if wcut else T)
             self._exchange_seg("ar_g", ["generator"], ["wgrad"])        # overlaps the FNet backward pass
             # (FNet's 14 weight gradients behind the generator's on the side stream, its input-gradient chain alone on the
             #  main stream: measured no gain -- 12.69 vs 12.73 ms, profiles/r03j_ab.txt -- the pieces serialise on each other.

@@ -64,11 +64,22 @@ def chain_args(mode, mid, out, scratch, variant, nb=NB):
     return K.ChainArgs(1, x, wf[0:2 * nb:2], None, wf[1:2 * nb:2], None, aux[:nb], aux[NB], mid[:nb], out[:nb], scratch, variant)
 
 
+WORST = [0.0]
+
+
 def same(a, b):
-    return all(torch.equal(p.view(torch.int16), q.view(torch.int16)) for p, q in zip(a, b))
+    """Bit-identical, or (the eight-wave kernel: two partial sums per conv) within 2 % of the tensor maximum after 16 blocks --
+    the figure is printed; the per-element bound against the oracle is the tests' business."""
+    ok = True
+    for p, q in zip(a, b):
+        if not torch.equal(p.view(torch.int16), q.view(torch.int16)):
+            d = float((p.float() - q.float()).abs().max() / q.float().abs().max().clamp_min(1e-30))
+            WORST[0] = max(WORST[0], d)
+            ok = ok and d < 2e-2
+    return ok
 
 
-VARIANTS = [(63 << 1, "all loads in level 1"), (14 << 1, "prefetch distance 14"), (0, "prefetch distance 28")]
+VARIANTS = [(14 << 1, "4 waves, prefetch distance 14"), (128, "8 waves, K halves")]
 print("residual trunk [%d,%d,%d,64] x %d blocks: ONE persistent launch (tg_resblock_chain) against %d launches (tg_resblock)" % (N, H, W, NB, NB))
 scratch = K.resblock_chain_scratch(N, H, W, DEV)
 side = torch.cuda.Stream()
@@ -104,8 +115,10 @@ for mode, label in ((0, "forward"), (1, "input gradient")):
             chain_args(mode, mid_c, out_c, scratch, variant, nb).launch()
             torch.cuda.synchronize()
             nbs_ok &= same(mid_c[:nb], mid_s[:nb]) and same(out_c[:nb], out_s[:nb])
-        print("  %-14s %-30s bit-identical: idle %s, beside a GEMM %s, 1/2/5-block chains %s; give-ups %d, epoch %d  [%s]"
-              % (label, vlabel, ok_idle, ok_load, nbs_ok, int(scratch[2]), int(scratch[0]), " ".join(detail)))
+        print("  %-14s %-30s equal to the per-block launches (worst relative difference %.1e; 0 = bit-identical): idle %s, beside a GEMM %s, "
+              "1/2/5-block chains %s; give-ups %d, epoch %d  [%s]"
+              % (label, vlabel, WORST[0], ok_idle, ok_load, nbs_ok, int(scratch[2]), int(scratch[0]), " ".join(detail)))
+        WORST[0] = 0.0
 
 if TRACE:
     VARIANTS += [(1 << 11, "two polls in flight"), (2 << 11, "one poll at a time, after 128"), (3 << 11, "one poll at a time, after 256"),
@@ -140,7 +153,7 @@ for mode, label in ((0, "forward"), (1, "input gradient")):
         if TRACE:
             lib = C.CDLL(so)
             lib.tg_debug_rc_trace.argtypes = [C.POINTER(C.c_ulonglong)]
-            buf = (C.c_ulonglong * (5 * 16 * 8))()
+            buf = (C.c_ulonglong * (8 * 16 * 8))()
             assert lib.tg_debug_rc_trace(buf) == 0
             t = list(buf)
             names = ["level-1 MFMAs", "epilogue 1 + barrier A", "level-2 MFMAs", "epilogue 2 + publish", "sweep (hand-off wait)", "barrier B"]
