@@ -204,10 +204,9 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[RC_XPOS * RC_P];
   __shared__ __attribute__((aligned(16))) unsigned char hs[RC_HPOS * RC_P];
   // DIST == 0: ALL of a block's weight loads are issued in level 1 -- step s requests the SECOND conv's fragment s of this block
-  // and, once its own fragment has been used, the FIRST conv's fragment s of the next block -- and none in level 2: level 1 is
-  // bound by its LDS fragment reads (12 KB per step against 128 B/clk) and hides the issue of a load (~40 cycles), level 2 is a
-  // chain of 18 dependent MFMAs that hides nothing (1400 -> 650 cycles without loads, profiles/r06k_trace_chain.txt); and by the
-  // time the block's output is published the youngest load has landed, so the polls of the sweep do not queue behind the stream.
+  // and, once its own fragment has been used, the FIRST conv's fragment s of the next block -- and none in level 2, a chain of
+  // 18 dependent MFMAs that hides nothing (1400 -> 650 cycles without loads, profiles/r06k_trace_chain.txt).  Measured: the
+  // time moves with the loads (level 1 1900 -> 2500), 6.6k vs 6.7k cycles per block (r06l_trace_chain.txt): kept as a variant.
   static_assert(DIST >= 0 && DIST <= 35, "prefetch distance in fragments");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -539,308 +538,12 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// EIGHT waves: two per SIMD, the K dimension of both convs split between them.
-// Lesson 37: one wave per SIMD issues its MFMAs, LDS / DPP and memory instructions one after the other (34 cycles per MFMA in
-// level 1 against 16 of the pipe).  Here the two waves of a SIMD own the SAME 16 output channels and split every conv's reduction
-// by K half: wave `half` takes input channels 32 half .. + 32 of all nine taps (9 of a conv's 18 weight fragments: no weight is
-// loaded twice, the per-CU weight stream is unchanged), so one wave's fragment reads / shifts / loads issue under the other's
-// MFMAs.  The upper half hands its fp32 partial sums over through LDS (12 KB for level 1, 4 KB for level 2) and the lower half
-// finishes the tile as the four-wave kernel does.  Same products, fp32 accumulation in TWO partial sums instead of one: not
-// bit-identical to tg_resblock any more, held to the same per-element bound against the oracle.
-template <bool HAS_AUX1>
-__global__ __launch_bounds__(512, 2) void resblock_chain8_kernel(RcP p) {
-  __shared__ __attribute__((aligned(16))) unsigned char xs[RC_XPOS * RC_P];
-  __shared__ __attribute__((aligned(16))) unsigned char hs[RC_HPOS * RC_P];
-  __shared__ __attribute__((aligned(16))) f32x4 part[4 * 3 * 64];          // upper half's partial sums: [cg][tile][lane]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave & 3, half = wave >> 2;
-  const int frow = lane & 15, fg = lane >> 4;
-
-  int b = blockIdx.x;
-  if ((p.ntiles & 7) == 0) b = (b & 7) * (p.ntiles >> 3) + (b >> 3);
-  const int tx = b % p.tiles_x, t1 = b / p.tiles_x;
-  const int ty = t1 % p.tiles_y, n = t1 / p.tiles_y;
-  const int y0 = ty * 4, x0 = tx * 4;
-  const int nb = p.nb;
-
-  const unsigned epoch0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const auto rsG = __builtin_amdgcn_make_buffer_rsrc(p.gran, 0, (int)(4u * p.gslot), 0x00020000);
-  const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;
-  if (nb > 1 && tid == 0)
-    __hip_atomic_store(p.xccw + b, ((unsigned long long)(epoch0 + 1u) << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned limit = p.spin_limit;
-
-  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.bytes, 0x00020000);
-  const int cbyte = (cg * 16 + fg * 4) * 2;
-  // ---- block-independent descriptors -------------------------------------------------------------------------------------------
-  u32x4c xr;
-  {
-    const int pix = tid >> 3, ch = tid & 7;                  // 512 16-byte items of the 8x8 input region: one per thread
-    const int gy = y0 - 2 + (pix >> 3), gx = x0 - 2 + (pix & 7);
-    const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    xr = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + ch * 16) : RC_OOB), 0, 0);
-  }
-  const int oy = y0 + (frow >> 2), ox = x0 + (frow & 3);
-  const bool out_ok = oy < p.H && ox < p.W;
-  const unsigned out_off = out_ok ? (unsigned)(((n * p.H + oy) * p.W + ox) * 128 + cbyte) : RC_OOB;
-  const unsigned pub_off = out_ok ? rc_ring_off(n, oy, ox, cg * 4 + fg, p.tiles_y, p.tiles_x) : RC_OOB;
-  unsigned m1off[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int ry = 2 * t + (frow >> 3), rx = frow & 7;
-    const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
-    const bool ok = rx < 6 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    m1off[t] = ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + cbyte) : RC_OOB;
-  }
-  // ring items (swept by the lower half's 256 threads: 3 per lane) and the tiles the XCC ids are needed of
-  const int stid = tid & 255;
-  unsigned goff[3], xoff[6];
-  int lpos[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int item = stid + k * 256;
-    int ry, rx;
-    rc_ring_pos(item >> 4, ry, rx);
-    const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
-    const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    goff[k] = ok ? rc_ring_off(n, gy, gx, item & 15, p.tiles_y, p.tiles_x) : RC_OOB;
-    xoff[k] = ok ? (unsigned)(((n * p.tiles_y + (gy >> 2)) * p.tiles_x + (gx >> 2)) * 8) : RC_OOB;
-    lpos[k] = (ry * RC_XR + rx) * RC_P + (item & 15) * 8;
-  }
-  {
-    const int dy = (frow >> 2) < 2 ? -1 : 1, dx = (frow & 3) < 2 ? -1 : 1;
-    const bool vy = (unsigned)(ty + dy) < (unsigned)p.tiles_y, vx = (unsigned)(tx + dx) < (unsigned)p.tiles_x;
-    xoff[3] = vy ? (unsigned)(((n * p.tiles_y + ty + dy) * p.tiles_x + tx) * 8) : RC_OOB;
-    xoff[4] = vx ? (unsigned)(((n * p.tiles_y + ty) * p.tiles_x + tx + dx) * 8) : RC_OOB;
-    xoff[5] = vy && vx ? (unsigned)(((n * p.tiles_y + ty + dy) * p.tiles_x + tx + dx) * 8) : RC_OOB;
-  }
-
-  auto rsrc_w = [&](const void* w) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, w ? 9 * 64 * 64 * 2 : 0, 0x00020000); };
-  // (small operands only the finishing half needs: zero-length descriptors for the other one -- no traffic, no branch around a load)
-  auto rsrc_b = [&](const float* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q), 0, q && !half ? 256 : 0, 0x00020000); };
-  auto rsrc_t = [&](const void* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q), 0, q && !half ? (int)p.bytes : 0, 0x00020000); };
-  auto rsW1 = rsrc_w(p.w1[0]), rsW2 = rsrc_w(p.w2[0]);
-  auto rsW1n = rsrc_w(nb > 1 ? p.w1[1] : nullptr);
-
-  // weight stream of this wave: position i < 9 tap i of the first conv (wA[i]), i >= 9 tap i - 9 of the second (wB[i - 9]), each the
-  // K half `half`; a conv's nine fragments are requested during the phase BEFORE the one that uses them (distance 9)
-  u32x4c wA[9], wB[9];
-  const int wlane = cg * 1024 + lane * 16;
-  auto wload = [&](const auto& rs, int tap) {
-    const int wtap = p.flip ? 8 - tap : tap;
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, (wtap * 2 + half) * 4096, 0);
-  };
-  rc_static_for<0, 9>([&](auto i) { wA[decltype(i)::value] = wload(rsW1, decltype(i)::value); });
-  u32x4c bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b1[0]), (cg * 16 + fg * 4) * 4, 0, 0);
-  u32x4c bq2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b2[0]), (cg * 16 + fg * 4) * 4, 0, 0);
-  u32x2c m1[3];
-  if constexpr (HAS_AUX1) {
-    const auto rsA1 = rsrc_t(p.aux1[0]);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) m1[t] = __builtin_amdgcn_raw_buffer_load_b64(rsA1, (int)m1off[t], 0, 0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- the neighbours' XCC ids ---------------------------------------------------------------------------------------------------
-  unsigned pubS_off = RC_OOB;
-  if (nb > 1) {
-    const auto rsXW = __builtin_amdgcn_make_buffer_rsrc(p.xccw, 0, p.ntiles * 8, 0x00020000);
-    u32x2c xw[6];
-    bool got = false;
-    const unsigned lim = __builtin_amdgcn_readfirstlane(limit);
-    for (unsigned spins = 0; spins <= lim; ++spins) {
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < 6; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b64(rsXW, (int)xoff[j], 0, RC_SC1);
-      unsigned bad = 0;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) bad |= (xoff[j] != RC_OOB ? 0xffffffffu : 0u) & (xw[j].y ^ (epoch0 + 1u));
-      if (!__any(bad != 0)) { got = true; break; }
-      if (spins > 32) __builtin_amdgcn_s_sleep(32);
-      else __builtin_amdgcn_s_sleep(1);
-    }
-    if (!got) {
-      limit = 0;
-      if (lane == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (goff[k] != RC_OOB && (xw[k].x & 15u) != my_xcc) goff[k] += 2u * p.gslot;
-    bool needS = false;
-#pragma unroll
-    for (int j = 3; j < 6; ++j) needS = needS || (xoff[j] != RC_OOB && (xw[j].x & 15u) != my_xcc);
-    if (needS) pubS_off = pub_off;
-  }
-  if (p.prio) __builtin_amdgcn_s_setprio(3);
-
-  *reinterpret_cast<u32x4c*>(xs + (tid >> 3) * RC_P + (tid & 7) * 16) = xr;
-  __syncthreads();
-
-  const unsigned char* xb = xs + ((frow >> 3) * RC_XR + (frow & 7)) * RC_P + fg * 16 + half * 64;
-  const unsigned char* hb = hs + ((frow >> 2) * RC_HR + (frow & 3)) * RC_P + fg * 16 + half * 64;
-  unsigned char* ctr = xs + (((frow >> 2) + 2) * RC_XR + (frow & 3) + 2) * RC_P + cbyte;
-  f32x4* const mypart = part + (cg * 3) * 64 + lane;
-
-  for (int k = 0; k < nb; ++k) {
-    RC_STAMP(k, 0);
-    const bool last = k + 1 >= nb;
-    const float bv1[4] = {__uint_as_float(bq1.x), __uint_as_float(bq1.y), __uint_as_float(bq1.z), __uint_as_float(bq1.w)};
-    const float bv2[4] = {__uint_as_float(bq2.x), __uint_as_float(bq2.y), __uint_as_float(bq2.z), __uint_as_float(bq2.w)};
-
-    // ---- level 1, this wave's K half: nine taps x three pixel tiles -------------------------------------------------------------
-    f32x4 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto xbase = [&](int dy, int t) { return *reinterpret_cast<const uint4*>(xb + ((2 * t + dy) * RC_XR) * RC_P); };
-    auto shl = [&](const uint4& v, auto dxv) {
-      constexpr int dx = decltype(dxv)::value;
-      if constexpr (dx == 0) return v;
-      else {
-        uint4 o;
-        o.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x100 + dx, 0xf, 0xf, true);
-        o.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x100 + dx, 0xf, 0xf, true);
-        o.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x100 + dx, 0xf, 0xf, true);
-        o.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x100 + dx, 0xf, 0xf, true);
-        return o;
-      }
-    };
-    uint4 base[3], nbase[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) base[t] = xbase(0, t);
-    rc_static_for<0, 9>([&](auto sv) {
-      constexpr int tap = decltype(sv)::value, dy = tap / 3, dx = tap % 3;
-      wB[tap] = wload(rsW2, tap);                              // the second conv's fragment of this block, a phase ahead
-      if constexpr (dx == 0 && dy < 2) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) nbase[t] = xbase(dy + 1, t);
-      }
-      uint4 bf[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) bf[t] = shl(base[t], std::integral_constant<int, dx>{});
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wA[tap]), *reinterpret_cast<bf16x8*>(&bf[t]),
-                                                         acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (dx == 2 && dy < 2) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) base[t] = nbase[t];
-      }
-    });
-    RC_STAMP(k, 1);
-    if (half) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) mypart[t * 64] = acc[t];
-    }
-    __syncthreads();                                                         // partial sums of level 1 are in LDS
-    const auto rsM = __builtin_amdgcn_make_buffer_rsrc(p.mid[k], 0, p.mid[k] ? (int)p.bytes : 0, 0x00020000);
-    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(p.out[k], 0, (int)p.bytes, 0x00020000);
-    if (!half) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const f32x4 o2 = mypart[t * 64];
-        const int ry = 2 * t + (frow >> 3), rx = frow & 7;
-        const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
-        const bool inimg = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = (acc[t][r] + o2[r]) + bv1[r];
-          v[r] = fmaxf(v[r], v[r] * p.nslope1);
-        }
-        if constexpr (HAS_AUX1) {
-          float a[4];
-          rc_unpack4(m1[t], a);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= a[r] > 0.f ? 1.f : 0.f;
-        }
-        u32x2c o = rc_pack4(v);
-        if (!inimg) o = u32x2c{0u, 0u};
-        *reinterpret_cast<u32x2c*>(hs + (ry * RC_HR + rx) * RC_P + cbyte) = o;
-        const bool own = inimg && ry >= 1 && ry <= 4 && rx >= 1 && rx <= 4;
-        __builtin_amdgcn_raw_buffer_store_b64(o, rsM, (int)(own ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + cbyte) : RC_OOB), 0, 0);
-      }
-    }
-    __syncthreads();                                                         // barrier A: the intermediate region is complete
-    RC_STAMP(k, 2);
-
-    // the next block's small operands (zero-length descriptors for the last block and for the upper half)
-    {
-      const int kn = last ? k : k + 1;
-      bq1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(last ? nullptr : p.b1[kn]), (cg * 16 + fg * 4) * 4, 0, 0);
-      bq2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(last ? nullptr : p.b2[kn]), (cg * 16 + fg * 4) * 4, 0, 0);
-      if constexpr (HAS_AUX1) {
-        const auto rsA1n = rsrc_t(last ? nullptr : p.aux1[kn]);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) m1[t] = __builtin_amdgcn_raw_buffer_load_b64(rsA1n, (int)m1off[t], 0, 0);
-      }
-    }
-    const bool use_m2 = last && p.aux2 != nullptr;
-    const u32x2c m2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_t(use_m2 ? p.aux2 : nullptr), (int)out_off, 0, 0);
-
-    // ---- level 2, this wave's K half: nine dependent MFMAs ----------------------------------------------------------------------
-    f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 hf[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) hf[tap] = *reinterpret_cast<const uint4*>(hb + ((tap / 3) * RC_HR + tap % 3) * RC_P);
-    rc_static_for<0, 9>([&](auto sv) {
-      constexpr int tap = decltype(sv)::value;
-      wA[tap] = wload(rsW1n, tap);                             // the first conv's fragment of the NEXT block
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[tap]), *reinterpret_cast<bf16x8*>(&hf[tap]),
-                                                     acc2, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    RC_STAMP(k, 3);
-    if (half) mypart[0] = acc2;
-    __syncthreads();                                                         // partial sums of level 2 are in LDS
-    if (!half) {
-      const f32x4 o2 = mypart[0];
-      const u32x2c sk = *reinterpret_cast<const u32x2c*>(ctr);
-      float s[4], v[4];
-      rc_unpack4(sk, s);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = (acc2[r] + o2[r]) + bv2[r];
-        v[r] += s[r];
-      }
-      float a[4];
-      rc_unpack4(m2, a);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= (a[r] > 0.f || !use_m2) ? 1.f : 0.f;
-      const u32x2c o = rc_pack4(v);
-      const unsigned tag = epoch0 + (unsigned)k + 1u;
-      const u32x4c gr = u32x4c{o.x, tag, o.y, tag};
-      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last ? RC_OOB : pubS_off), (int)((unsigned)(2 + (k & 1)) * p.gslot), RC_SC1);
-      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last ? RC_OOB : pub_off), (int)((unsigned)(k & 1) * p.gslot), 0);
-      __builtin_amdgcn_raw_buffer_store_b64(o, rsO, (int)out_off, 0, 0);
-      *reinterpret_cast<u32x2c*>(ctr) = out_ok ? o : u32x2c{0u, 0u};
-    }
-    rsW1 = rsW1n;
-    rsW2 = rsrc_w(k + 1 < nb ? p.w2[k + 1 < nb ? k + 1 : 0] : nullptr);
-    rsW1n = rsrc_w(k + 2 < nb ? p.w1[k + 2 < nb ? k + 2 : 0] : nullptr);
-    RC_STAMP(k, 4);
-    if (!half && !last && limit) {
-      if (!rc_sweep<3, 0>(rsG, goff, lpos, xs, (unsigned)(k & 1) * p.gslot, epoch0 + (unsigned)k + 1u, limit, RC_STAT(k))) {
-        limit = 0;
-        if (lane == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (p.prio) __builtin_amdgcn_s_setprio(3);
-    }
-    RC_STAMP(k, 5);
-    __syncthreads();                                                         // barrier B
-    RC_STAMP(k, 6);
-  }
-
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(p.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == (unsigned)p.ntiles - 1u) {
-      __hip_atomic_store(p.ctrl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.ctrl, epoch0 + (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
+// (Round 6, session Y: an EIGHT-wave form -- two waves per SIMD owning the same 16 output channels, every conv's reduction split
+//  between them by K half, partial sums handed over through LDS -- was built on lesson 37 and measured: correct (1.2e-2 of the
+//  tensor maximum from the per-block path after 16 blocks: two partial sums per conv), level 1 1700 -> 1060 and level 2 1360 ->
+//  970 cycles per wave, but the two hand-over barriers cost ~1000 cycles each because the waves of a SIMD do not interleave --
+//  the pair's second wave finishes its half as late as one wave finishes the whole -- 3.65 against 3.34 us per block
+//  (profiles/r06y_trace_chain.txt).  Deleted; commit 34adc01 has the code.)
 
 extern "C" int tg_resblock_chain_scratch_bytes(int N, int H, int W, int64_t* bytes) {
   TG_CHECK_ARG(bytes && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
@@ -908,11 +611,6 @@ extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const voi
   using T = std::true_type;
   using Fa = std::false_type;
   auto pick = [&](auto atag) {
-    if ((variant >> 7) & 1) {
-      constexpr bool A = decltype(atag)::value;
-      TG_LAUNCH(A ? "resblock_chain8<bwd>" : "resblock_chain8<fwd>", fl, by, (resblock_chain8_kernel<A>), dim3(p.ntiles), dim3(512), 0, st, p);
-      return;
-    }
 #ifdef TG_RC_TRACE
     if ((variant >> 11) & 3) {
       constexpr bool A = decltype(atag)::value;

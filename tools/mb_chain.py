@@ -79,7 +79,7 @@ def same(a, b):
     return ok
 
 
-VARIANTS = [(14 << 1, "4 waves, prefetch distance 14"), (128, "8 waves, K halves")]
+VARIANTS = [(14 << 1, "prefetch distance 14"), (0, "prefetch distance 28"), (63 << 1, "all loads in level 1")]
 print("residual trunk [%d,%d,%d,64] x %d blocks: ONE persistent launch (tg_resblock_chain) against %d launches (tg_resblock)" % (N, H, W, NB, NB))
 scratch = K.resblock_chain_scratch(N, H, W, DEV)
 side = torch.cuda.Stream()
