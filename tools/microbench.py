@@ -65,11 +65,37 @@ def wgrad_case(N, H, W, Cin, Cout, k=3, s=1, dtype=torch.bfloat16):
     return (lambda: K.conv_wgrad(d, x, gy, dw, db)), 2.0 * N * Ho * Wo * Cout * k * k * Cin
 
 
+def graph_chain_probes():
+    """--graph: three questions about dependent kernel chains inside a hipGraph (rounds 2-3, DESIGN lessons 1, 5): the per-node
+    floor, whether it grows with the graph's length, whether alternating kernels cost more than homogeneous chains."""
+    from tecogan_amd import kernels as K
+    a, b = torch.ones(64, device="cuda"), torch.ones(64, device="cuda")
+    print("graph node floor (tiny dependent kernel): %.2f us" % graph_timeit(lambda: K.lincomb(a, b, a, 0.5, 0.5)))
+    n = 4 * 32 * 32 * 64
+    x, y = torch.ones(n, device="cuda"), torch.ones(n, device="cuda")
+    print("1 MiB fp32 lincomb node: %.2f us" % graph_timeit(lambda: K.lincomb(x, y, x, 0.5, 0.5)))
+    fn, _ = conv_case(4, 32, 32, 64, 64)
+    for chain in (50, 200, 600, 1500, 3000):
+        print("chain %5d nodes: %.3f us per conv node" % (chain, graph_timeit(fn, chain=chain, iters=10)))
+    c8, _ = conv_case(4, 128, 128, 8, 64)
+    wg, _ = wgrad_case(40, 32, 32, 64, 64)
+    ta, tb, tc = (graph_timeit(f, chain=100, iters=10) for f in (fn, c8, wg))
+    print("alone: LR conv %.2f  c8 conv %.2f  wgrad %.2f us" % (ta, tb, tc))
+    for name, f, g, s in (("LRconv+c8", fn, c8, ta + tb), ("LRconv+wgrad", fn, wg, ta + tc)):
+        def pair(f=f, g=g):
+            f()
+            g()
+        print("%-14s alternating %.2f us per pair vs %.2f summed" % (name, graph_timeit(pair, chain=100, iters=10), s))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="", help="substring filter on the case name")
+    ap.add_argument("--graph", action="store_true", help="the hipGraph chain probes instead of the kernel table")
     a = ap.parse_args()
+    if a.graph:
+        return graph_chain_probes()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cases = [
         ("conv3x3 gen  [4,32,32,64->64]", conv_case(4, 32, 32, 64, 64, dtype=dt)),

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 export TMPDIR=/tmp
 T=${1:-z}
-( time timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=25 --durations=6 ) > $O/r06${T}_pytest_gpu.log 2>&1; grep -E "passed|failed" $O/r06${T}_pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O/r06${T}_pytest_gpu.log | cut -c1-200
+[ -n "$SKIP_SUITE" ] || ( time timeout 1500 python -m pytest tests -m gpu -q -s --maxfail=25 --durations=6 ) > $O/r06${T}_pytest_gpu.log 2>&1; grep -E "passed|failed" $O/r06${T}_pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O/r06${T}_pytest_gpu.log | cut -c1-200
 ( time timeout 700 python bench.py ) > $O/r06${T}_bench.json 2> $O/r06${T}_bench.err; cut -c1-400 $O/r06${T}_bench.json; tail -3 $O/r06${T}_bench.err
 cd /tmp
 B="python $R/bench.py --no-sub --no-roofline --no-cpu-baseline"
