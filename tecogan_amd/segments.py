@@ -183,7 +183,7 @@ class SegmentRunner:
         return torch.cuda.stream(st)
 
     def _replay(self):
-        main = self._current_stream()
+        main = getattr(self, "_current_stream", torch.cuda.current_stream)()
         evs, pending = {}, {}                                   # pending: segment name -> threading.Event set once its CUDA event is recorded
 
         def ev_of(name):
@@ -206,7 +206,7 @@ class SegmentRunner:
             if st is st_main:
                 seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
             else:
-                with self._stream_ctx(st):
+                with getattr(self, "_stream_ctx", torch.cuda.stream)(st):
                     seg["graph"].replay() if seg["fn"] is None else seg["fn"]()
             seg["event"].record(st)
             evs[seg["name"]] = seg["event"]
