@@ -107,6 +107,26 @@ def test_frvsr_generator_and_fnet_drop_in():
     close(out2, ON.generator_F(cpu_vars("generator/"), gi, 2), 1e-4)
 
 
+def test_generator_single_frame_raw_xavier_weights_at_baseline_size():
+    """every BASELINE-size parity test and the bench run DAMPED weights (params.damp_values: the 19-frame
+    recurrence is expansive with the raw init).  Without a recurrence nothing needs damping: ONE frame of generator_F
+    (lib/frvsr.py:44-88) at the training shape [4,32,32,51], num_resblock = 16, seeded raw xavier weights exactly as
+    lib/ops.py:40,52 draws them, fp32 mode, against the oracle in float64 with north_star's per-pixel criterion."""
+    import lib.frvsr as Fr
+    import lib.ops as L
+    from tecogan_amd.flags import defaults
+    from util import assert_close_per_elem
+    FL = defaults(num_resblock=16)
+    g = torch.Generator().manual_seed(11)
+    gi = torch.cat((torch.rand(4, 32, 32, 3, generator=g), torch.rand(4, 32, 32, 48, generator=g)), -1)     # LR frame | s2d(warped HR)
+    with L.variable_scope("generator"):
+        out = Fr.generator_F(gi.cuda(), 3, reuse=False, FLAGS=FL)
+    ref = ON.generator_F({k: v.double() for k, v in cpu_vars("generator/").items()}, gi.double(), 16)
+    assert float(ref.abs().max()) > 1.0                                        # raw xavier: the output is not a small residual
+    worst = assert_close_per_elem(out, ref, 1e-3, 1e-3, what="generator_F, raw xavier, one frame")
+    print("\n[generator_F raw xavier, [4,32,32], nres 16] worst per-pixel error %.2e, frame maximum %.2f" % (worst, float(ref.abs().max())))
+
+
 def test_teco_discriminator_vgg_and_network_tuple():
     import lib.ops as L
     import lib.Teco as T

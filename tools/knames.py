@@ -13,6 +13,9 @@ def tg_name(k):
     if m:
         tags = [t for t, on in (("res", m.group(1)), ("aux", m.group(2)), ("frag", m.group(3))) if on == "true"]
         return "conv3x3_ws<%s>" % ",".join(tags)
+    m = re.search(r"resblock_chain_kernel<(true|false)", k)                    # <HAS_AUX1, DIST, TR, SM>
+    if m:
+        return "resblock_chain<bwd>" if m.group(1) == "true" else "resblock_chain<fwd>"
     m = re.search(r"resblock_lat_kernel<(true|false), (true|false)", k)        # <HAS_AUX1, HAS_AUX2, FRAG, DIST>
     if m:
         return {("false", "false"): "resblock_lat<fwd>", ("true", "false"): "resblock_lat<bwd>",
