@@ -115,7 +115,6 @@ def test_generator_single_frame_raw_xavier_weights_at_baseline_size():
     import lib.frvsr as Fr
     import lib.ops as L
     from tecogan_amd.flags import defaults
-    from util import assert_close_per_elem
     FL = defaults(num_resblock=16)
     g = torch.Generator().manual_seed(11)
     gi = torch.cat((torch.rand(4, 32, 32, 3, generator=g), torch.rand(4, 32, 32, 48, generator=g)), -1)     # LR frame | s2d(warped HR)
@@ -123,8 +122,17 @@ def test_generator_single_frame_raw_xavier_weights_at_baseline_size():
         out = Fr.generator_F(gi.cuda(), 3, reuse=False, FLAGS=FL)
     ref = ON.generator_F({k: v.double() for k, v in cpu_vars("generator/").items()}, gi.double(), 16)
     assert float(ref.abs().max()) > 1.0                                        # raw xavier: the output is not a small residual
-    worst = assert_close_per_elem(out, ref, 1e-3, 1e-3, what="generator_F, raw xavier, one frame")
-    print("\n[generator_F raw xavier, [4,32,32], nres 16] worst per-pixel error %.2e, frame maximum %.2f" % (worst, float(ref.abs().max())))
+    # 35 fp32 convolutions deep with values up to 12: pixels near zero are differences of large terms, and the fp32 ORACLE itself is
+    # not within 1e-3 of its float64 run on every pixel -- the bound is derived from it as in the BASELINE-size step tests:
+    # max(1e-3, 1.5 x the fp32 oracle's own worst pixel), measured 1.3e-3 against the oracle's 2.2e-3
+    from util import per_elem_err
+    o32 = ON.generator_F(cpu_vars("generator/"), gi, 16)
+    worst = per_elem_err(out, ref, 1e-3).max().item()
+    worst_o = per_elem_err(o32, ref, 1e-3).max().item()
+    print("\n[generator_F raw xavier, [4,32,32], nres 16] worst per-pixel error %.2e (fp32 oracle: %.2e), frame maximum %.2f"
+          % (worst, worst_o, float(ref.abs().max())))
+    assert worst <= max(1e-3, 1.5 * worst_o), (worst, worst_o)
+    assert float((per_elem_err(out, ref, 1e-3) > 1e-3).double().mean()) < 1e-3        # ... and all but a handful of pixels within 1e-3
 
 
 def test_teco_discriminator_vgg_and_network_tuple():
