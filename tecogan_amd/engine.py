@@ -123,7 +123,11 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
         # of the late frames beside D's generator-side backward pass (before the BPTT)
         # (round 4: default 103, i.e. bit 8 off -- D's own-gradient passes on the MAIN stream, in the ~1.1 ms it would otherwise
         #  wait for the last chunk's VGG pass, instead of beside the BPTT: 9.15 / 9.18 -> 9.07 / 9.09 ms, profiles/r04k_ab.txt)
-        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "103")) & 111) if self.overlap else 0
+        # (round 6: default 111, bit 8 ON again -- with the one-launch trunk the side stream's VGG passes are the critical path of the
+        #  middle window and D's own-gradient passes beside the last of them cost it 0.3 ms (vgg_1 2.00 -> 1.70 ms without them);
+        #  beside the BPTT they cost the BPTT 0.44 ms but the side stream has the room: 7.679 / 7.670 -> 7.608 / 7.601 ms and, another
+        #  box, 7.485 / 7.480 -> 7.432 / 7.448; behind the target lookahead instead of in front of it: 7.455; profiles/r06aa_ab.txt)
+        self.ov_parts = (int(os.environ.get("TG_OVERLAP_PARTS", "111")) & 111) if self.overlap else 0
         self.wgrad_cut = 0                       # BPTT cut for early generator weight gradients (see _program_compute); 0 = off
         # Ping-pong sequences repeat their first T0-1 TARGET frames in reverse (lib/Teco.py:80-85), so the VGG features of the
         # targets (lib/Teco.py:174-176) need computing for the T0 distinct frames only; the mirrored ones are copies.  Measured in

@@ -716,7 +716,7 @@ def test_host_jitter_before_exchange_segments_standin_world8():
     rng, slept = random.Random(1), []
 
     def jitter(name):
-        assert name.startswith("ar_") or name in ("vggt", "vggt_pre", "dreal", "vgg_0", "vgg_1", "vggt_next", "wgrad"), name
+        assert name.startswith("ar_") or name in ("vggt", "vggt_pre", "dreal", "vgg_0", "vgg_1", "vggt_next", "wgrad", "down"), name
         if not name.startswith("ar_"):
             return 0.0
         slept.append(rng.uniform(0.0, 200e-6))
