@@ -291,6 +291,11 @@ int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const 
  * conv applied, b1 / b2 nullable (arrays or entries), aux1 (mode 1 only) the saved relu(conv_1) outputs, mid nullable; aux2_last
  * (nullable) masks the output of the last block processed (mode 1: the ReLU output of the input stage).  x = input of the first
  * block processed; out[k] may not alias it.
+ * pre_x (mode 0, nullable): the generator input [N,H,W,pre_cpad] bf16 (51 channels padded to 56, lib/frvsr.py:47-49) -- the
+ * input-stage conv + ReLU (lib/frvsr.py:60-63) then runs in the same launch in front of the first block, on the 8x8 region that
+ * block needs (no exchange), bit-identical to its own tg_conv_forward launch; pre_w_frag its [tap][64][64] fragment-order copy
+ * (input channels zero-padded; tg_pack_weights_frag with Cin in the table), pre_b nullable, pre_out [N,H,W,64] its output
+ * (stored: the weight gradients and the input-gradient chain's mask need it); x is ignored then.
  * scratch: the byte count tg_resblock_chain_scratch_bytes reports, device memory, ZEROED ONCE by the caller at allocation and then
  * owned by these calls (control words + granule ring; epochs advance from launch to launch, so it is never cleared again and a
  * captured launch replays); one scratch per stream -- two launches sharing it may not overlap.
@@ -301,12 +306,13 @@ int tg_resblock(int mode, const void* x, const void* w1, const float* b1, const 
 int tg_resblock_chain_scratch_bytes(int N, int H, int W, int64_t* bytes);
 int tg_resblock_chain(int mode, const void* x, int nblocks, const void* const* w1, const float* const* b1,
                       const void* const* w2, const float* const* b2, const void* const* aux1, const void* aux2_last,
-                      void* const* mid, void* const* out, void* scratch, int N, int H, int W, int C, int dtype, int variant,
-                      void* stream);
+                      void* const* mid, void* const* out, void* scratch, const void* pre_x, int pre_cpad, const void* pre_w_frag,
+                      const float* pre_b, void* pre_out, int N, int H, int W, int C, int dtype, int variant, void* stream);
 /* Fragment-order bf16 copies of `count` 64 -> 64 3x3 weights (the residual-block convs of lib/frvsr.py:50-57) for tg_resblock:
  * copy[2 tap + kk][wave][lane][j] = W[tap][row = 16 wave + lane % 16][k = 32 kk + 8 (lane / 16) + j]; dst_t: row = output channel
- * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 2 x int64 per tensor -- offset of the
- * HWIO fp32 tensor in src_base, offset (elements) of its 36864-element copy in dst_t / dst_n. */
+ * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 3 x int64 per tensor -- offset of the
+ * HWIO fp32 tensor [3,3,Cin,64] in src_base, offset (elements) of its 36864-element copy in dst_t / dst_n, Cin (<= 64: the
+ * generator's input conv has 51; input channels beyond Cin are zero in the copies). */
 int tg_pack_weights_frag(const float* src_base, void* dst_t, void* dst_n, const int64_t* tab, int count, void* stream);
 
 /* Input-gradient chain of generator_F's HR tail (reference lib/frvsr.py:73-87 under tf.gradients, lib/Teco.py:441-449) as ONE

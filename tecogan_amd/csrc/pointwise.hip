@@ -750,14 +750,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // k = in channel), z = 1: the input-gradient operand (row = in channel, k = out channel); src is TF's HWIO fp32 master copy.
 __global__ __launch_bounds__(256) void pack_weights_frag_kernel(const float* __restrict__ src, u16* __restrict__ dstT,
                                                                 u16* __restrict__ dstN, const int64_t* __restrict__ tab) {
-  const int64_t* t = tab + (int64_t)blockIdx.y * 2;
+  const int64_t* t = tab + (int64_t)blockIdx.y * 3;
   const float* __restrict__ s0 = src + t[0];
+  const unsigned cin = (unsigned)t[2];                      // HWIO [3,3,cin,64]; channels cin .. 63 of the copies are zero
   u16* __restrict__ d0 = (blockIdx.z == 0 ? dstT : dstN) + t[1];
   for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < 9u * 64u * 64u; e += gridDim.x * blockDim.x) {
     const unsigned j = e & 7, lane = (e >> 3) & 63, wave = (e >> 9) & 3, s = e >> 11;
     const unsigned tap = s >> 1, kk = s & 1;
     const unsigned r = wave * 16 + (lane & 15), k = kk * 32 + (lane >> 4) * 8 + j;
-    const float v = blockIdx.z == 0 ? s0[(tap * 64 + k) * 64 + r] : s0[(tap * 64 + r) * 64 + k];
+    const unsigned ci = blockIdx.z == 0 ? k : r, co = blockIdx.z == 0 ? r : k;
+    const float v = ci < cin ? s0[(tap * cin + ci) * 64 + co] : 0.f;
     d0[e] = f2bf(v);
   }
 }
@@ -1072,7 +1074,7 @@ extern "C" int tg_pack_weights_both(const float* src_base, void* dst_t, void* ds
 }
 
 // fragment-order bf16 copies (forward and input-gradient operand) of `count` 64 -> 64 3x3 weights; tab: 2 x int64 per tensor
-// (src offset in the flat fp32 buffer, dst offset in elements, 36864 per tensor)
+// (src offset in the flat fp32 buffer, dst offset in elements, 36864 per tensor, input channels)
 extern "C" int tg_pack_weights_frag(const float* src_base, void* dst_t, void* dst_n, const int64_t* tab, int count, void* stream) {
   TG_CHECK_ARG(src_base && dst_t && dst_n && tab && count > 0, "bad argument");
   hipLaunchKernelGGL(pack_weights_frag_kernel, dim3(8, count, 2), dim3(256), 0, ST(stream), src_base, (u16*)dst_t, (u16*)dst_n, tab);

@@ -43,6 +43,11 @@ struct RcP {
   const void* aux1[RC_MAXB];    // backward: the saved relu(conv_1) output of the block (level-1 mask)
   void* mid[RC_MAXB];           // level-1 result (nullable per block)
   void* out[RC_MAXB];           // block output
+  const void* pre_x;            // forward only, nullable: [N,H,W,pre_cpad] bf16 -- the generator input; the input-stage conv + ReLU
+  const void* pre_w;            //   (lib/frvsr.py:60-63) runs in this launch, on the 8x8 region the first block needs (no exchange)
+  const float* pre_b;           //   pre_w: fragment-order [tap][64][64-padded Cin] copy, pre_out: [N,H,W,64] its output (stored: the
+  void* pre_out;                //   weight gradients and the BPTT's mask need it); x is ignored then
+  int pre_cpad;
   const void* aux2;             // nullable: mask on the LAST block's output (backward: the ReLU of the input stage)
   unsigned* ctrl;               // [0] epoch base  [1] arrivals  [2] give-ups (sticky)
   unsigned long long* xccw;     // [tiles] {tag, XCC id} words
@@ -199,10 +204,12 @@ __device__ __forceinline__ bool rc_sweep(const __amdgpu_buffer_rsrc_t& rsG, cons
 // (A fifth wave that only sweeps -- its own memory queue -- was measured and lost: polling from barrier A on, 2 - 4 polls per
 //  sweep, every block 3 - 6 % slower, profiles/r06a_mb_chain.txt.)
 // TR (trace builds): 1 = the weight loads are not even issued (what the matrix phases cost without the stream; results are wrong)
-template <bool HAS_AUX1, int DIST, int TR = 0, int SM = 0>
+// PRE: the input-stage conv of generator_F in front of the first block (forward launches of the training recurrence)
+template <bool HAS_AUX1, int DIST, int TR = 0, int SM = 0, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[RC_XPOS * RC_P];
   __shared__ __attribute__((aligned(16))) unsigned char hs[RC_HPOS * RC_P];
+  __shared__ __attribute__((aligned(16))) unsigned char ps_[PRE ? 100 * RC_P : 16];        // 10x10 region of the generator input
   // DIST == 0: ALL of a block's weight loads are issued in level 1 -- step s requests the SECOND conv's fragment s of this block
   // and, once its own fragment has been used, the FIRST conv's fragment s of the next block -- and none in level 2, a chain of
   // 18 dependent MFMAs that hides nothing (1400 -> 650 cycles without loads, profiles/r06k_trace_chain.txt).  Measured: the
@@ -232,13 +239,36 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
 
   // ---- loads that do not depend on the block ----------------------------------------------------------------------------------
   u32x4c xr[2];
+  if constexpr (!PRE) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int item = tid + k * 256;
-    const int pix = item >> 3, ch = item & 7;
-    const int gy = y0 - 2 + (pix >> 3), gx = x0 - 2 + (pix & 7);
-    const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + ch * 16) : RC_OOB), 0, 0);
+    for (int k = 0; k < 2; ++k) {
+      const int item = tid + k * 256;
+      const int pix = item >> 3, ch = item & 7;
+      const int gy = y0 - 2 + (pix >> 3), gx = x0 - 2 + (pix & 7);
+      const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + ch * 16) : RC_OOB), 0, 0);
+    }
+  }
+  // PRE: the 10x10 region of the generator input (pre_cpad channels: the chunks beyond them read zeros), 800 16-byte items, and the
+  // input conv's 18 weight fragments -- requested BEFORE the trunk's weight stream starts (they are consumed first)
+  u32x4c pr[4], wP[PRE ? 18 : 1];
+  u32x4c bqP = u32x4c{0u, 0u, 0u, 0u};
+  if constexpr (PRE) {
+    const auto rsPX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.pre_x), 0, (int)((unsigned)(p.N * p.H * p.W) * (unsigned)p.pre_cpad * 2u), 0x00020000);
+    const int pchunks = p.pre_cpad >> 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int item = tid + k * 256;
+      const int pix = item >> 3, ch = item & 7;
+      const int gy = y0 - 3 + pix / 10, gx = x0 - 3 + pix % 10;
+      const bool ok = item < 800 && ch < pchunks && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      pr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsPX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * p.pre_cpad * 2 + ch * 16) : RC_OOB), 0, 0);
+    }
+    const auto rsPW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.pre_w), 0, 9 * 64 * 64 * 2, 0x00020000);
+#pragma unroll
+    for (int s2 = 0; s2 < 18; ++s2) wP[s2] = __builtin_amdgcn_raw_buffer_load_b128(rsPW, wave * 1024 + lane * 16, s2 * 4096, 0);
+    bqP = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pre_b), 0, p.pre_b ? 256 : 0, 0x00020000),
+                                                (wave * 16 + fg * 4) * 4, 0, 0);
   }
   const int oy = y0 + (frow >> 2), ox = x0 + (frow & 3);
   const bool out_ok = oy < p.H && ox < p.W;
@@ -352,12 +382,58 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
   if (p.prio) __builtin_amdgcn_s_setprio(3);       // (the matrix phases; the sweeps drop to 0)
 
   // ---- input region of the first block -> LDS (positions outside the image hold zeros from here on) --------------------------
+  if constexpr (!PRE) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int item = tid + k * 256;
-    *reinterpret_cast<u32x4c*>(xs + (item >> 3) * RC_P + (item & 7) * 16) = xr[k];
+    for (int k = 0; k < 2; ++k) {
+      const int item = tid + k * 256;
+      *reinterpret_cast<u32x4c*>(xs + (item >> 3) * RC_P + (item & 7) * 16) = xr[k];
+    }
+    __syncthreads();
+  } else {
+    // ... computed here: relu(conv3x3(generator input) + b) on the whole 8x8 region (four 2x8 pixel tiles; the ring is recomputed
+    // from the 10x10 input region instead of exchanged: 72 MFMAs per wave against a kernel boundary), taps and K halves in
+    // conv3x3_tile's order -> bit-identical to the input-stage launch it replaces
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int item = tid + k * 256;
+      if (item < 800) *reinterpret_cast<u32x4c*>(ps_ + (item >> 3) * RC_P + (item & 7) * 16) = pr[k];
+    }
+    __syncthreads();
+    const unsigned char* pb = ps_ + ((frow >> 3) * 10 + (frow & 7)) * RC_P + fg * 16;
+    f32x4 accp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rc_static_for<0, 18>([&](auto sv) {
+      constexpr int s2 = decltype(sv)::value, tap = s2 >> 1, kk = s2 & 1;
+      uint4 bfp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bfp[t] = *reinterpret_cast<const uint4*>(pb + ((2 * t + tap / 3) * 10 + tap % 3) * RC_P + kk * 64);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wP[s2]), *reinterpret_cast<bf16x8*>(&bfp[t]),
+                                                          accp[t], 0, 0, 0);
+    });
+    const auto rsPO = __builtin_amdgcn_make_buffer_rsrc(p.pre_out, 0, (int)p.bytes, 0x00020000);
+    const float bvp[4] = {__uint_as_float(bqP.x), __uint_as_float(bqP.y), __uint_as_float(bqP.z), __uint_as_float(bqP.w)};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ry = 2 * t + (frow >> 3), rx = frow & 7;
+      const int gy = y0 - 2 + ry, gx = x0 - 2 + rx;
+      const bool inimg = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = accp[t][r] + bvp[r];
+        v[r] = fmaxf(z, z * p.nslope1);             // (ReLU as conv3x3_tile writes it: -0 for a negative sum, bit for bit; nslope1 = 0 forward)
+      }
+      u32x2c o = rc_pack4(v);
+      if (!inimg) o = u32x2c{0u, 0u};
+      *reinterpret_cast<u32x2c*>(xs + (ry * RC_XR + rx) * RC_P + cbyte) = o;
+      const bool own = inimg && ry >= 2 && ry <= 5 && rx >= 2 && rx <= 5;
+      __builtin_amdgcn_raw_buffer_store_b64(o, rsPO, (int)(own ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + cbyte) : RC_OOB), 0, 0);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   const unsigned char* xb = xs + ((frow >> 3) * RC_XR + (frow & 7)) * RC_P + fg * 16;
   const unsigned char* hb = hs + ((frow >> 2) * RC_HR + (frow & 3)) * RC_P + fg * 16;
@@ -554,12 +630,16 @@ extern "C" int tg_resblock_chain_scratch_bytes(int N, int H, int W, int64_t* byt
 
 extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const void* const* w1, const float* const* b1,
                                  const void* const* w2, const float* const* b2, const void* const* aux1, const void* aux2_last,
-                                 void* const* mid, void* const* out, void* scratch, int N, int H, int W, int C, int dtype,
+                                 void* const* mid, void* const* out, void* scratch, const void* pre_x, int pre_cpad,
+                                 const void* pre_w_frag, const float* pre_b, void* pre_out, int N, int H, int W, int C, int dtype,
                                  int variant, void* stream) {
   TG_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (forward) or 1 (input gradient)");
   TG_CHECK_ARG(dtype == TG_BF16 && C == 64, "bf16 tensors with 64 channels only");
   TG_CHECK_ARG(nblocks >= 1 && nblocks <= RC_MAXB, "1 .. 16 blocks per launch");
-  TG_CHECK_ARG(x && w1 && w2 && out && scratch && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
+  TG_CHECK_ARG((x || pre_x) && w1 && w2 && out && scratch && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
+  TG_CHECK_ARG(!pre_x || (mode == 0 && pre_w_frag && pre_out && pre_cpad >= 8 && pre_cpad <= 64 && pre_cpad % 8 == 0),
+               "the input-stage conv in front of the trunk: forward launches, fragment-order weights, 8 .. 64 padded input channels");
+  TG_CHECK_ARG((((uintptr_t)pre_x | (uintptr_t)pre_w_frag | (uintptr_t)pre_out) & 15) == 0, "pointers must be 16-byte aligned");
   TG_CHECK_ARG((mode == 1) == (aux1 != nullptr), "aux1 (the saved relu(conv_1) outputs) belongs to mode 1");
   TG_CHECK_ARG((((uintptr_t)x | (uintptr_t)scratch | (uintptr_t)aux2_last) & 15) == 0, "pointers must be 16-byte aligned");
   const int64_t bytes = (int64_t)N * H * W * 128;
@@ -579,6 +659,7 @@ extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const voi
     }
   }
   p.aux2 = aux2_last;
+  p.pre_x = pre_x; p.pre_w = pre_w_frag; p.pre_b = pre_b; p.pre_out = pre_out; p.pre_cpad = pre_cpad;
   p.ctrl = static_cast<unsigned*>(scratch);
   p.nb = nblocks; p.N = N; p.H = H; p.W = W;
   p.flip = mode;
@@ -595,7 +676,7 @@ extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const voi
   p.prio = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double px = (double)N * H * W;
-  const double fl = 2.0 * 2.0 * px * 64.0 * 576.0 * nblocks;
+  const double fl = 2.0 * 2.0 * px * 64.0 * 576.0 * nblocks + (pre_x ? 2.0 * px * 64.0 * 9.0 * pre_cpad : 0.0);
   const double by = nblocks * (px * 128.0 * (2 + (mid != nullptr) + (aux1 != nullptr)) + 2.0 * 73728.0) + (aux2_last ? px * 128.0 : 0.0);
   const int dist = (variant >> 1) & 63;          // 0: default
 #ifdef TG_RC_TRACE
@@ -627,6 +708,13 @@ extern "C" int tg_resblock_chain(int mode, const void* x, int nblocks, const voi
       return;
     }
 #endif
+    if constexpr (!decltype(atag)::value) {
+      if (pre_x) {
+        TG_LAUNCH("resblock_chain<fwd,in>", fl, by + px * (2.0 * pre_cpad + 128.0), (resblock_chain_kernel<false, 14, 0, 0, true>), dim3(p.ntiles),
+                  dim3(256), 0, st, p);
+        return;
+      }
+    }
     if (dist == 14) go(atag, std::integral_constant<int, 14>{});
     else if (dist == 63) go(atag, std::integral_constant<int, 0>{});
     else if (dist == 4) go(atag, std::integral_constant<int, 4>{});

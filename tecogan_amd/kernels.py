@@ -210,10 +210,15 @@ def resblock_chain_scratch(N, H, W, device):
 class ChainArgs:
     """The per-block pointer arrays of one tg_resblock_chain call, built once (the tensors they point to are kept alive here)."""
 
-    def __init__(self, mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant=0):
+    def __init__(self, mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant=0, pre=None):
+        """pre (forward only): (generator input [N,H,W,Cpad], input conv's fragment-order weights, bias, a0 out [N,H,W,64]) -- the
+        input-stage conv runs in the same launch in front of the first block; `x` may then be None."""
         nb = len(w1)
         assert nb == len(w2) == len(out) and 1 <= nb <= 16
-        self.keep = (x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch)
+        self.keep = (x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, pre)
+        self.pre = pre
+        if x is None:
+            x = pre[3]
         arr = lambda ts: None if ts is None else (C.c_void_p * nb)(*[None if t is None else _p(t) for t in ts])   # noqa: E731
         self.a = (arr(w1), arr(b1), arr(w2), arr(b2), arr(aux1), arr(mid), arr(out))
         self.mode, self.nb, self.variant = mode, nb, variant
@@ -225,14 +230,16 @@ class ChainArgs:
     def launch(self):
         N, H, W, Cn = self.x.shape
         w1, b1, w2, b2, aux1, mid, out = self.a
+        px, pw, pb, po = self.pre if self.pre is not None else (None, None, None, None)
         check(lib().tg_resblock_chain(self.mode, _p(self.x), self.nb, w1, b1, w2, b2, aux1, _p(self.aux2), mid, out, _p(self.scratch),
+                                      _p(px), px.shape[-1] if px is not None else 0, _p(pw), _p(pb), _p(po),
                                       N, H, W, Cn, dt(self.x), self.variant, _stream()), "tg_resblock_chain")
 
 
-def resblock_chain(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant=0):
+def resblock_chain(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant=0, pre=None):
     """nb residual blocks (mode 0) / their input-gradient chain (mode 1) as ONE persistent launch (csrc/resblock_chain.hip):
     lists of per-block tensors in processing order, fragment-order weights.  Returns out[-1]."""
-    ChainArgs(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant).launch()
+    ChainArgs(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, variant, pre).launch()
     return out[-1]
 
 

@@ -179,6 +179,7 @@ class Generator:
         #                 needs one 4x4 tile per compute unit at most (the training crops: [4,32,32] = 256 tiles)
         self.resblock_chain = True
         self.chain_variant = 14 << 1            # prefetch distance of the weight stream (tools/mb_chain.py)
+        self.chain_input_conv = True            # ... with the input-stage conv in front of the first block, in the same launch
         self.resblock_max_tiles = 1024          # 4x4-pixel tiles up to which one workgroup per tile is the latency-optimal shape
         # scheduling hint for the recurrence's own launches (forward_t / backward_t): K.CONV_COEXIST when throughput work
         # of another stream shares the chip, so that the chain's bigger launches (HR deconv, output conv) also pick tile
@@ -275,12 +276,17 @@ class Generator:
                 nm = [p + "resblock_%d/" % i for i in blk]
                 if mode == 0:
                     x = q["a"][blk[0] - 1][t]
-                    cas.append(K.ChainArgs(0, x, [ps.packed_frag(s + "conv_1/Conv/weights", True) for s in nm],
+                    wi = p + "input_stage/conv/Conv/weights"
+                    pre = None
+                    if c0 == 0 and self.chain_input_conv and ps.packed_frag(wi, True) is not None:
+                        # the input-stage conv in front of the first block, in the same launch (a[0] is written by it)
+                        pre = (q["x_in"][t], ps.packed_frag(wi, True), ps.view(p + "input_stage/conv/Conv/biases"), x)
+                    cas.append(K.ChainArgs(0, None if pre else x, [ps.packed_frag(s + "conv_1/Conv/weights", True) for s in nm],
                                            [ps.view(s + "conv_1/Conv/biases") for s in nm],
                                            [ps.packed_frag(s + "conv_2/Conv/weights", True) for s in nm],
                                            [ps.view(s + "conv_2/Conv/biases") for s in nm], None, None,
                                            [q["r"][i][t] for i in blk], [q["a"][i][t] for i in blk], q["chain_scratch"],
-                                           self.chain_variant))
+                                           self.chain_variant, pre))
                 else:
                     x = q["g_c2"][blk[0]][t]
                     cas.append(K.ChainArgs(1, x, [ps.packed_frag(s + "conv_2/Conv/weights", False) for s in nm], None,
@@ -310,10 +316,12 @@ class Generator:
         ps, p, q = self.ps, self.P, self.seq
         x_in = q["x_in"][t]
         cf = self.chain_flags
-        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
-                     out=q["a"][0][t], flags=cf)
         fused = self._fused_blocks()
         chained = self._chained()
+        in_chain = chained and self.chain_input_conv and ps.packed_frag(p + "input_stage/conv/Conv/weights", True) is not None
+        if not in_chain:
+            a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU,
+                         out=q["a"][0][t], flags=cf)
         if chained:
             self._chain(0, t)
             a = q["a"][self.nres][t]

@@ -184,10 +184,14 @@ class ParamStore:
             for name, e in self.entries.items():
                 if ("/resblock_" in name or "/conv_tran" in name) and e.get("taps") == 9 and e["A"] == 64 and e["B"] == 64:
                     self.frag[name] = len(self.frag) * 36864
+                elif name.startswith("generator/") and "/input_stage/" in name and e.get("taps") == 9 and e["A"] <= 64 and e["B"] == 64:
+                    # the generator's input conv (51 -> 64): its copy has the input channels zero-padded to 64 (csrc/resblock_chain.hip
+                    # runs it in front of the trunk's first block)
+                    self.frag[name] = len(self.frag) * 36864
         nf = len(self.frag)
         self.wTf = torch.zeros(max(nf * 36864, 8), device=device, dtype=torch.bfloat16)
         self.wNf = torch.zeros(max(nf * 36864, 8), device=device, dtype=torch.bfloat16)
-        self.frag_table = torch.tensor([[self.entries[n]["offset"], o] for n, o in self.frag.items()] or [[0, 0]],
+        self.frag_table = torch.tensor([[self.entries[n]["offset"], o, self.entries[n]["A"]] for n, o in self.frag.items()] or [[0, 0, 64]],
                                        dtype=torch.int64, device=device).contiguous()
 
     # ---- views ------------------------------------------------------------------------------

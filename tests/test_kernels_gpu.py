@@ -1647,6 +1647,50 @@ def test_resblock_chain_forward_is_bit_identical_to_per_block_launches_and_match
     close(o[-1], a_o, 2e-2, "trunk output %s x %d" % (shape, nb))
 
 
+@pytest.mark.parametrize("nb", [16, 2])
+@pytest.mark.parametrize("shape", [(4, 32, 32), (1, 5, 7), (3, 6, 6), (1, 13, 9), (2, 8, 8)])
+def test_resblock_chain_with_the_input_conv_in_front_is_bit_identical(shape, nb):
+    """lib/frvsr.py:60-70: net = relu(conv2(gen_inputs, 3, 64, 1)); then the residual blocks.  The input-stage conv inside the trunk's
+    launch (tg_resblock_chain pre_x: computed on the 8x8 region the first block needs, no exchange) against its own tg_conv_forward
+    launch followed by nb x tg_resblock: a[0], every intermediate and every block output bit for bit; a[0] per element against the
+    oracle.  The generator input has 51 channels in 56-channel pixels; the fragment-order weight copy pads them to 64 with zeros."""
+    N, H, W = shape
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    xin = torch.zeros(N, H, W, 56)
+    xin[..., :51] = bf(rnd(N, H, W, 51, seed=7))
+    w_in, b_in = bf(rnd(3, 3, 51, 64, seed=8, scale=0.08)), rnd(64, seed=9, scale=0.2)
+    ws = [bf(rnd(3, 3, 64, 64, seed=40 + i, scale=0.05)) for i in range(2 * nb)]
+    bs = [rnd(64, seed=80 + i, scale=0.2) for i in range(2 * nb)]
+    wt = lambda w: K.frag_order(w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16))      # noqa: E731
+    wf, bd = [wt(w) for w in ws], [b.to(DEV) for b in bs]
+    xd = _dev_bf(xin)
+    w_rows = torch.zeros(9, 64, 56)
+    w_rows[:, :, :51] = w_in.permute(0, 1, 3, 2).reshape(9, 64, 51)
+    d0 = K.conv_desc(N, H, W, 56, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_RELU)
+    a0_ref = K.conv_forward(d0, xd, w_rows.to(DEV, torch.bfloat16), b_in.to(DEV), None, None, torch.empty(N, H, W, 64, device=DEV, dtype=torch.bfloat16))
+    w64 = torch.zeros(9, 64, 64)
+    w64[:, :, :51] = w_in.permute(0, 1, 3, 2).reshape(9, 64, 51)
+    win_f = K.frag_order(w64.to(DEV, torch.bfloat16))
+    r_ref = [torch.empty_like(a0_ref) for _ in range(nb)]
+    a_ref = [torch.empty_like(a0_ref) for _ in range(nb)]
+    a = a0_ref
+    for i in range(nb):
+        a = K.resblock(0, a, wf[2 * i], bd[2 * i], wf[2 * i + 1], bd[2 * i + 1], None, None, r_ref[i], a_ref[i], w_frag=True)
+    scratch = K.resblock_chain_scratch(N, H, W, DEV)
+    for rep in range(2):
+        a0 = torch.full_like(a0_ref, 7.0)
+        r = [torch.full_like(a0_ref, 7.0) for _ in range(nb)]
+        o = [torch.full_like(a0_ref, 7.0) for _ in range(nb)]
+        K.resblock_chain(0, None, wf[0::2], bd[0::2], wf[1::2], bd[1::2], None, None, r, o, scratch, pre=(xd, win_f, b_in.to(DEV), a0))
+        torch.cuda.synchronize()
+        assert int(scratch[2]) == 0
+        assert torch.equal(a0.view(torch.int16), a0_ref.view(torch.int16)), "input-stage output differs from tg_conv_forward's"
+        for i in range(nb):
+            assert torch.equal(r[i].view(torch.int16), r_ref[i].view(torch.int16)), "intermediate of block %d" % i
+            assert torch.equal(o[i].view(torch.int16), a_ref[i].view(torch.int16)), "output of block %d" % i
+    tight(a0, torch.relu(O.conv2(xin[..., :51], w_in, b_in, 1)), "input-stage conv %s" % (shape,))
+
+
 @pytest.mark.parametrize("nb", [16, 3])
 @pytest.mark.parametrize("shape", [(4, 32, 32), (1, 5, 7), (3, 6, 6), (1, 13, 9)])
 def test_resblock_chain_input_gradient_is_bit_identical_to_per_block_launches(shape, nb):
@@ -1704,12 +1748,22 @@ def test_pack_weights_frag_matches_the_host_permutation_of_both_operands():
     from tecogan_amd import params as P
     ps = P.ParamStore(OrderedDict(generator=P.generator_spec(2)), DEV, torch.bfloat16)
     ps.load(P.init_values(P.generator_spec(2), 5))
-    assert len(ps.frag) == 6 and sum('/resblock_' in n for n in ps.frag) == 4 and sum('/conv_tran' in n for n in ps.frag) == 2
+    # 2 residual blocks x 2 convs, the two transposed convs and (round 6) the input conv, whose 51 input channels are zero-padded to 64
+    assert len(ps.frag) == 7 and sum('/resblock_' in n for n in ps.frag) == 4 and sum('/conv_tran' in n for n in ps.frag) == 2
     for name in ps.frag:
         for tr in (True, False):
-            rows = ps.packed(name, tr).view(9, 64, 64)
+            e = ps.entries[name]
+            if "/input_stage/" in name:
+                w = ps.view(name).detach().float()                                   # HWIO [3,3,51,64]
+                rows = torch.zeros(9, 64, 64, device=DEV)
+                if tr:
+                    rows[:, :, :e["A"]] = w.reshape(9, e["A"], 64).permute(0, 2, 1)   # [tap][out][in]
+                else:
+                    rows[:, :e["A"], :] = w.reshape(9, e["A"], 64)                    # [tap][in][out]
+                rows = rows.bfloat16()
+            else:
+                rows = ps.packed(name, tr).view(9, 64, 64)
             assert torch.equal(ps.packed_frag(name, tr).view(torch.int16), K.frag_order(rows).view(torch.int16)), (name, tr)
-    assert ps.packed_frag("generator/generator_unit/input_stage/conv/Conv/weights", True) is None
     assert not P.ParamStore(OrderedDict(generator=P.generator_spec(1)), DEV, torch.float32).frag        # bf16 compute copies only
 
 
