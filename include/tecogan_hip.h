@@ -308,6 +308,21 @@ int tg_resblock_chain(int mode, const void* x, int nblocks, const void* const* w
                       const void* const* w2, const float* const* b2, const void* const* aux1, const void* aux2_last,
                       void* const* mid, void* const* out, void* scratch, const void* pre_x, int pre_cpad, const void* pre_w_frag,
                       const float* pre_b, void* pre_out, int N, int H, int W, int C, int dtype, int variant, void* stream);
+/* The residual trunk of generator_F -- reference lib/frvsr.py:50-57,66-70 -- of one frame of the INFERENCE step (main.py:195-216)
+ * as ONE persistent launch in the throughput regime (csrc/resblock_plane.hip): nblocks (1..16) x tg_resblock, bit-identical; one
+ * workgroup per 16x32-pixel tile keeps the tile's activations in LDS across all blocks, the one-pixel ring around the tile comes
+ * from the neighbour workgroups after every conv (tagged granules as in tg_resblock_chain).  w1 / b1 / w2 / b2: HOST arrays of
+ * device pointers per block (fragment-order weights, tg_pack_weights_frag; bias arrays or entries nullable); out [N,H,W,64] =
+ * the last block's output (may alias x: the input is read before any output is written -- every workgroup stages its tile first).
+ * scratch: tg_resblock_plane_scratch_bytes bytes of device memory, ZEROED ONCE at allocation, then owned by these calls (epochs
+ * advance from launch to launch; a captured launch replays); one scratch per stream.
+ * TG_EINVAL when N * ceil(H/16) * ceil(W/32) exceeds the number of compute units (every workgroup must be resident: run
+ * tg_resblock_c64_thr per block then).  Give-ups are counted in ((unsigned*)scratch)[2] (sticky).
+ * variant: 0 = default (weight prefetch distance 6 K steps); 1 = 9 steps. */
+int tg_resblock_plane_scratch_bytes(int N, int H, int W, int64_t* bytes);
+int tg_resblock_plane(const void* x, int nblocks, const void* const* w1, const float* const* b1, const void* const* w2,
+                      const float* const* b2, void* out, void* scratch, int N, int H, int W, int C, int dtype, int variant,
+                      void* stream);
 /* Fragment-order bf16 copies of `count` 64 -> 64 3x3 weights (the residual-block convs of lib/frvsr.py:50-57) for tg_resblock:
  * copy[2 tap + kk][wave][lane][j] = W[tap][row = 16 wave + lane % 16][k = 32 kk + 8 (lane / 16) + j]; dst_t: row = output channel
  * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 3 x int64 per tensor -- offset of the

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtecogan_hip.so")
-SOURCES = ["conv_igemm.hip", "conv3x3.hip", "conv3x3_ws.hip", "conv3x3_dma.hip", "conv3x3_wr.hip", "conv4x4s2.hip", "resblock_lat.hip", "resblock_chain.hip", "resblock_thr.hip", "hr_bwd_lat.hip", "hr_fwd_lat.hip", "conv_wgrad.hip", "conv_wgrad_tr.hip", "warp.hip", "pointwise.hip", "schedule.hip", "losses.hip", "runtime.hip"]
+SOURCES = ["conv_igemm.hip", "conv3x3.hip", "conv3x3_ws.hip", "conv3x3_dma.hip", "conv3x3_wr.hip", "conv4x4s2.hip", "resblock_lat.hip", "resblock_chain.hip", "resblock_plane.hip", "resblock_thr.hip", "hr_bwd_lat.hip", "hr_fwd_lat.hip", "conv_wgrad.hip", "conv_wgrad_tr.hip", "warp.hip", "pointwise.hip", "schedule.hip", "losses.hip", "runtime.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -16,7 +16,7 @@ def _newer(a, b):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "tecogan_hip.h")]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "handoff.h"), os.path.join(HERE, "..", "include", "tecogan_hip.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

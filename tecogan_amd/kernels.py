@@ -243,6 +243,45 @@ def resblock_chain(mode, x, w1, b1, w2, b2, aux1, aux2_last, mid, out, scratch, 
     return out[-1]
 
 
+def resblock_plane_ok(N, H, W):
+    """tg_resblock_plane: one 16x32-pixel tile per compute unit at most (every workgroup resident), and enough tiles to fill the
+    chip (below that the per-block launches use more of it)."""
+    nt = N * ((H + 15) // 16) * ((W + 31) // 32)
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return cus // 2 <= nt <= cus
+
+
+def resblock_plane_scratch(N, H, W, device):
+    """The exchange scratch of tg_resblock_plane (control words + granule ring), zeroed once; one per stream."""
+    n = C.c_int64(0)
+    check(lib().tg_resblock_plane_scratch_bytes(N, H, W, C.byref(n)), "tg_resblock_plane_scratch_bytes")
+    return torch.zeros(n.value // 4, dtype=torch.int32, device=device)
+
+
+class PlaneArgs:
+    """The per-block pointer arrays of one tg_resblock_plane call, built once (the tensors they point to are kept alive here)."""
+
+    def __init__(self, x, w1, b1, w2, b2, out, scratch, variant=0):
+        nb = len(w1)
+        assert nb == len(w2) and 1 <= nb <= 16 and tuple(out.shape) == tuple(x.shape) and out.dtype == x.dtype
+        self.keep = (x, w1, b1, w2, b2, out, scratch)
+        arr = lambda ts: None if ts is None else (C.c_void_p * nb)(*[None if t is None else _p(t) for t in ts])   # noqa: E731
+        self.a = (arr(w1), arr(b1), arr(w2), arr(b2))
+        self.nb, self.variant, self.x, self.out, self.scratch = nb, variant, x, out, scratch
+
+    def launch(self):
+        N, H, W, Cn = self.x.shape
+        w1, b1, w2, b2 = self.a
+        check(lib().tg_resblock_plane(_p(self.x), self.nb, w1, b1, w2, b2, _p(self.out), _p(self.scratch), N, H, W, Cn, dt(self.x),
+                                      self.variant, _stream()), "tg_resblock_plane")
+        return self.out
+
+
+def resblock_plane(x, w1, b1, w2, b2, out, scratch, variant=0):
+    """nb residual blocks of the stateless forward as ONE persistent launch (csrc/resblock_plane.hip); fragment-order weights."""
+    return PlaneArgs(x, w1, b1, w2, b2, out, scratch, variant).launch()
+
+
 def conv3x3_c64_frag_ok(N, H, W):
     """The throughput regime of tg_conv3x3_c64_frag: at least 256 tiles of 8x16 pixels."""
     return N * ((H + 7) // 8) * ((W + 15) // 16) >= 256
