@@ -60,18 +60,25 @@ constexpr int RP_LDS = RP_STG + 8 * 512;              // 160768
 }  // namespace
 
 #ifdef TG_RP_TRACE
-// [wave 0..7][block 0..15][stamp 0..7] of the middle workgroup
-__device__ unsigned long long tg_rp_trace_buf[8 * 16 * 8];
+// [wave 0..7][block 0..15][stamp 0..15] of the middle workgroup
+__device__ unsigned long long tg_rp_trace_buf[8 * 16 * 16];
 #define RP_STAMP(k, i)                                                                                                  \
   do {                                                                                                                  \
-    if (blockIdx.x == gridDim.x / 2 && lane == 0) tg_rp_trace_buf[(wave * 16 + (k)) * 8 + (i)] = (unsigned long long)clock64(); \
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) tg_rp_trace_buf[(wave * 16 + (k)) * 16 + (i)] = (unsigned long long)clock64(); \
   } while (0)
 extern "C" int tg_debug_rp_trace(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_rp_trace_buf), sizeof(unsigned long long) * 8 * 16 * 8);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_rp_trace_buf), sizeof(unsigned long long) * 8 * 16 * 16);
 }
 #else
 #define RP_STAMP(k, i) do { } while (0)
 #endif
+
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+// two fp32 -> two bf16 in one v_cvt_pk_bf16_f32 (round to nearest even, as f2bf)
+__device__ __forceinline__ unsigned rp_cvt2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2p{a, b}, bf16x2p));
+}
 
 // byte offset of 16-byte slot `slot` (8 channels) of plane position (r, c)
 __device__ __forceinline__ int rp_lds(int r, int c, int slot) { return (r * RP_PW + c) * 128 + ((slot ^ (((c >> 1) & 3) << 1)) << 4); }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
         const unsigned char* src = smem + (SECOND ? RP_PLANE : 0);
         unsigned char* dst = smem + (SECOND ? 0 : RP_PLANE);
         constexpr int G0 = SECOND ? 18 : 0;
-        RP_STAMP(k, SECOND ? 3 : 0);
+        RP_STAMP(k, SECOND ? 5 : 0);
         f32x4 acc[8][2];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -273,9 +280,11 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
           if constexpr (i == 7) RP_WISSUE(G0 + s + D);
           __builtin_amdgcn_sched_barrier(0);
         });
-        RP_STAMP(k, SECOND ? 4 : 1);
+        RP_STAMP(k, SECOND ? 6 : 1);
 
-        // ---- epilogue: bias, ReLU / skip, one rounding; pixels outside the image are the next conv's zero padding ---------------
+        // ---- epilogue: bias, ReLU / skip, one rounding; pixels outside the image are the next conv's zero padding.  All 16 results
+        //      first (the skip operands requested up front), then the publishes, then the LDS writes: what the neighbours wait for
+        //      leaves as early as it can
         const bool pub = !(SECOND && last);
         const unsigned e = 2u * (unsigned)k + (SECOND ? 1u : 0u);
         const unsigned tag = epoch0 + e + 1u;
@@ -287,48 +296,61 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
           bv[j][0] = __uint_as_float(q4.x); bv[j][1] = __uint_as_float(q4.y);
           bv[j][2] = __uint_as_float(q4.z); bv[j][3] = __uint_as_float(q4.w);
         }
+        auto elem = [&](int r, int h, int j) { return dst + (ea ^ (j * 32)) + (r * RP_PW + 16 * h) * 128; };
+        u32x2c o[4][2][2];
+        if constexpr (SECOND) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          u32x2c o[2][2];
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) o[r][h][j] = *reinterpret_cast<const u32x2c*>(elem(r, h, j));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const bool inimg = gyb + r < p.H && gxb + 16 * h < p.W;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              unsigned char* el = dst + (ea ^ (j * 32)) + (r * RP_PW + 16 * h) * 128;
               float v[4];
               if constexpr (SECOND) {
                 float sk[4];
-                rc_unpack4(*reinterpret_cast<const u32x2c*>(el), sk);
+                rc_unpack4(o[r][h][j], sk);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                   v[c] = acc[r * 2 + h][j][c] + bv[j][c];
                   v[c] += sk[c];
                 }
               } else {
+                // ReLU as resblock_lat.hip's fmaxf(v, v * 0) bit for bit (-0 for a negative sum, +0 for +0: v_max_f32 orders -0 < +0)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                  v[c] = acc[r * 2 + h][j][c] + bv[j][c];
-                  v[c] = fmaxf(v[c], v[c] * 0.f);
-                }
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[r * 2 + h][j][c] + bv[j][c], -0.f);
               }
-              o[h][j] = rc_pack4(v);
-              if (!inimg) o[h][j] = u32x2c{0u, 0u};
-              if (pub && ((r == 0 && pq == 0) || (r == 3 && pq == 3))) {
-                const u32x4c gr = u32x4c{o[h][j].x, tag, o[h][j].y, tag};
+              o[r][h][j] = inimg ? u32x2c{rp_cvt2(v[0], v[1]), rp_cvt2(v[2], v[3])} : u32x2c{0u, 0u};
+            }
+          }
+        RP_STAMP(k, SECOND ? 7 : 2);
+        if (pub) {
+          if (rowpub) {
+            const int rr = pq == 0 ? 0 : 3;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const u32x2c ov = rr == 0 ? o[0][h][j] : o[3][h][j];
+                const u32x4c gr = u32x4c{ov.x, tag, ov.y, tag};
                 const unsigned off = rowbase + h * 4096 + j * 1024;
                 __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(rowS[h] ? off + sring : RC_OOB), (int)soff, RC_SC1);
                 __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)off, (int)soff, 0);
               }
-              *reinterpret_cast<u32x2c*>(el) = o[h][j];
-            }
           }
-          if (pub && colsrc) {
+          if (colsrc) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x2c*>(stg_w + (r * 8 + j * 4) * 8) = frow == 0 ? o[0][j] : o[1][j];
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x2c*>(stg_w + (r * 8 + j * 4) * 8) = frow == 0 ? o[r][0][j] : o[r][1][j];
           }
-        }
-        if (pub) {
           __builtin_amdgcn_wave_barrier();                 // same-wave LDS operations are ordered; keep the compiler from mixing them
           const u32x2c oc = *reinterpret_cast<const u32x2c*>(stg + lane * 8);
           const u32x4c gr = u32x4c{oc.x, tag, oc.y, tag};
@@ -336,7 +358,14 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
           __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)colbase, (int)soff, 0);
           __builtin_amdgcn_wave_barrier();
         }
-        RP_STAMP(k, SECOND ? 5 : 2);
+        RP_STAMP(k, SECOND ? 8 : 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x2c*>(elem(r, h, j)) = o[r][h][j];
+        RP_STAMP(k, SECOND ? 9 : 4);
         // ---- hand-off: the ring of the destination plane from the neighbours' same conv ------------------------------------------
         if (pub && limit) {
           if (!rc_sweep<4, 0>(rsG, goff, lpos, dst, soff, tag, limit, nullptr)) {
@@ -349,7 +378,7 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
       };
       conv(std::false_type{});
       conv(std::true_type{});
-      RP_STAMP(k, 6);
+      RP_STAMP(k, 10);
       rsW1 = rsW1n;
       rsW2 = rsrc_w(last ? nullptr : p.w2[last ? 0 : k + 1]);
       rsW1n = rsrc_w(k + 2 < nb ? p.w1[k + 2 < nb ? k + 2 : 0] : nullptr);

@@ -172,6 +172,12 @@ class Generator:
         self.hr_tail = True
         self.ws_frag = True
         self.fused_block = True        # throughput regime (inference): a residual block as ONE launch (csrc/resblock_thr.hip)
+        # resblock_plane : throughput regime, the WHOLE trunk of a frame as one persistent launch with the activations resident in
+        #                 LDS (csrc/resblock_plane.hip; bit-identical to nb x tg_resblock); needs one 16x32-pixel tile per compute
+        #                 unit at most and at least half the chip's worth of tiles (1080p output: 255 tiles); else fused_block
+        self.resblock_plane = True
+        self.plane_variant = 0
+        self._plane_scratch = {}       # (N, H, W) -> exchange scratch, allocated (zeroed) on first use: in the eager warm-up run
         self.input_in_group = True     # the input conv's weight gradient as a narrower last group of the trunk's grouped launch
         self.resblock_lat = self.hr_fwd_lat = self.hr_bwd_lat = True
         # resblock_chain : the whole residual trunk of a frame (and its input-gradient chain) as ONE persistent launch with neighbour
@@ -199,7 +205,18 @@ class Generator:
         #  the gfx950 ds_read_b128 lane grouping; numbers and cycle stamps in profiles/r03p_resblock_ws.txt, kernel deleted)
         wsf = self.ws_frag and ps.frag and a.dtype == torch.bfloat16 and K.conv3x3_c64_frag_ok(*a.shape[:3])
         bufs = [torch.empty_like(a), torch.empty_like(a)] if (wsf and self.fused_block) else None
-        for i in range(1, self.nres + 1):
+        plane = wsf and self.resblock_plane and 1 <= self.nres <= 16 and K.resblock_plane_ok(*a.shape[:3])
+        if plane:
+            key = tuple(a.shape[:3])
+            if key not in self._plane_scratch:
+                assert not torch.cuda.is_current_stream_capturing(), "the exchange scratch is zeroed ONCE: allocate it in the eager warm-up"
+                self._plane_scratch[key] = K.resblock_plane_scratch(*key, a.device)
+            names = [p + "resblock_%d/" % i for i in range(1, self.nres + 1)]
+            a = K.resblock_plane(a, [ps.packed_frag(s + "conv_1/Conv/weights", True) for s in names],
+                                 [ps.view(s + "conv_1/Conv/biases") for s in names],
+                                 [ps.packed_frag(s + "conv_2/Conv/weights", True) for s in names],
+                                 [ps.view(s + "conv_2/Conv/biases") for s in names], a, self._plane_scratch[key], self.plane_variant)
+        for i in range(1, (0 if plane else self.nres) + 1):
             s = p + "resblock_%d/" % i
             if bufs is not None:
                 # the whole block in one launch, intermediate in LDS (csrc/resblock_thr.hip; not in place: ping-pong buffers)

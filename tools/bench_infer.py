@@ -11,9 +11,11 @@ ap.add_argument("--frames", type=int, default=60); ap.add_argument("--warmup", t
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--nres", type=int, default=16)
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--no-lookahead", action="store_true")
+ap.add_argument("--no-plane", action="store_true", help="the residual trunk as 16 tg_resblock_c64_thr launches instead of tg_resblock_plane")
 a = ap.parse_args()
 tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 eng = InferenceEngine(a.nres, a.h, a.w, "cuda", tdt, use_graph=not a.no_graph)
+eng.G.resblock_plane = not a.no_plane
 frames = torch.rand(8, 1, a.h, a.w, 3, device="cuda")
 nx = (lambda i: None) if a.no_lookahead else (lambda i: frames[(i + 1) % 8])
 for i in range(a.warmup):

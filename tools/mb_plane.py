@@ -114,14 +114,15 @@ for variant, label in ((0, "weight prefetch distance 6 steps"), (1, "9 steps")):
     if TRACE:
         lib = C.CDLL(so)
         lib.tg_debug_rp_trace.argtypes = [C.POINTER(C.c_ulonglong)]
-        buf = (C.c_ulonglong * (8 * 16 * 8))()
+        buf = (C.c_ulonglong * (8 * 16 * 16))()
         assert lib.tg_debug_rp_trace(buf) == 0
         t = list(buf)
-        names = ["conv_1 MFMAs", "epilogue 1", "hand-off + barrier", "conv_2 MFMAs", "epilogue 2", "hand-off + barrier"]
+        names = ["conv_1 MFMAs", "values", "publish", "LDS writes", "hand-off + barrier", "conv_2 MFMAs", "values", "publish", "LDS writes",
+                 "hand-off + barrier"]
         for wv in (0, 3, 6):
-            rows = [t[(wv * 16 + k) * 8:(wv * 16 + k) * 8 + 7] for k in range(NB)]
+            rows = [t[(wv * 16 + k) * 16:(wv * 16 + k) * 16 + 11] for k in range(NB)]
             for k in (1, 7, 14):
                 r = rows[k]
-                print("      wave %d block %2d: " % (wv, k) + "  ".join("%s %d" % (names[i], r[i + 1] - r[i]) for i in range(6)) +
+                print("      wave %d block %2d: " % (wv, k) + "  ".join("%s %d" % (names[i], r[i + 1] - r[i]) for i in range(10)) +
                       "  | block %d cycles" % (rows[k + 1][0] - r[0]))
             print("      wave %d: mean block %.0f cycles" % (wv, sum(rows[k + 1][0] - rows[k][0] for k in range(1, NB - 1)) / (NB - 2)))
