@@ -18,6 +18,15 @@ at the end of the step, both inside the one captured graph): the 14 small FNet c
 profiles/r03z_infer1080p_bf16_kernel_stats.txt) leave the frame's critical path.  The announced frame is a promise: the next call
 must pass that very memory, unmodified (checked by tecogan_amd/promise.py: data pointer, layout and torch's version counter, no
 sync; any other tensor makes the step compute its own flow first, as a call without `next_frame` does).
+
+Lookahead WINDOW (round 6).  Alone, FNet on one 1080p frame pair is a chain of ~30 latency-bound launches: 0.31 ms for 32 GFLOP, and
+since the generator's residual trunk became one persistent launch that owns every compute unit's LDS (csrc/resblock_plane.hip)
+nothing runs beside it any more -- the side stream bought nothing (0.675 ms with, 0.672 without).  The flows of the next K frames
+depend on LR frames only, so `step(frame, upcoming=[f1 .. fK])` runs FNet ONCE on the K pairs (frame, f1), (f1, f2), ... as a batch
+when its stock of flows is used up (the same kernels at 8 x the pixels per launch: throughput instead of latency), and the following
+K calls take their flow from the stock -- each against the same promise check as above: a frame that is not the announced memory
+drops the whole stock and the step computes its own flow.  The reference's loop holds the whole clip (lib/dataloader.py:30-60,
+main.py:253-260), so its driver can always announce.
 """
 from collections import OrderedDict
 
@@ -49,6 +58,12 @@ class InferenceEngine:
         self._have_flow = False                                                    # flow_next belongs to the coming step
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.use_graph, self.graphs = use_graph, {}
+        # lookahead window: FNet on the next `window` frame pairs as ONE batch (step(frame, upcoming=[...]))
+        self.window = 8
+        self._win_in = None                                                        # [window + 1, B, h, w, 3]: resident frame + announced ones
+        self._win_flows = None                                                     # [window, B, h', w', 2]
+        self._stock = []                                                           # [(promise, index into _win_flows)] in arrival order
+        self._win_graphs = {}
 
     def load(self, values):
         """values: TF-variable-name -> tensor for the 'generator' and 'fnet' scopes (main.py:221-224)."""
@@ -58,6 +73,7 @@ class InferenceEngine:
         self.pre_inputs.zero_()
         self.pre_gen.zero_()
         self._have_flow = False
+        self._stock = []
 
     def _flow(self, prev, cur):
         B, h, w = self.B, self.h, self.w
@@ -82,19 +98,61 @@ class InferenceEngine:
         if ahead:
             main.wait_stream(self.side)
 
-    def step(self, frame=None, next_frame=None):
+    def _window_flows(self, k):
+        """FNet on the k pairs (win_in[i], win_in[i + 1]) as one batch -> win_flows[:k]."""
+        B, h, w = self.B, self.h, self.w
+        fin = K.concat2_pad(self._win_in[:k].reshape(k * B, h, w, 3), self._win_in[1:k + 1].reshape(k * B, h, w, 3),
+                            torch.empty(k * B, h, w, FNET_CPAD, device=self.dev, dtype=self.act_dtype))
+        flows = self.Fn.forward(fin, keep=False)[0]
+        self._win_flows[:k].copy_(flows.view(k, B, *flows.shape[1:]))
+
+    def _refill(self, upcoming):
+        """The flows of the next frames (each against its predecessor; the first against the frame resident from this step)."""
+        k = min(len(upcoming), self.window)
+        if self._win_in is None:
+            self._win_in = torch.zeros(self.window + 1, *self.frame.shape, device=self.dev)
+            self._win_flows = torch.zeros(self.window, *self.flow_next.shape, device=self.dev)
+        self._win_in[0].copy_(self.frame)
+        for i in range(k):
+            self._win_in[i + 1].copy_(upcoming[i], non_blocking=True)
+        if not self.use_graph:
+            self._window_flows(k)
+        else:
+            if k not in self._win_graphs:
+                self._window_flows(k)                                              # eager warm-up (allocations, weight copies)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._window_flows(k)
+                self._win_graphs[k] = g
+            self._win_graphs[k].replay()
+        self._stock = [(promise.announce(upcoming[i]), i) for i in range(k)]
+
+    def step(self, frame=None, next_frame=None, upcoming=None):
         """frame: [B,h,w,3] fp32 in [0,1] (device tensor).  next_frame: the frame the NEXT call will pass (its flow is computed
-        beside this frame's generator).  Returns the HR frame [B,4h,4w,3] in [0,1] (a view of the recurrent state: copy it if
-        you keep it across steps)."""
+        beside this frame's generator).  upcoming: the frames the next calls will pass, in order (any number; the engine takes
+        `window` of them whenever its stock of precomputed flows is used up and runs FNet on them as one batch); with `upcoming`
+        the one-frame side-stream lookahead is not used.  Returns the HR frame [B,4h,4w,3] in [0,1] (a view of the recurrent
+        state: copy it if you keep it across steps)."""
         if frame is not None:
+            stocked = False
+            if self._stock:
+                if promise.kept(self._stock[0][0], frame):
+                    self.flow_next.copy_(self._win_flows[self._stock.pop(0)[1]], non_blocking=True)
+                    self._have_flow = stocked = True
+                else:
+                    self._stock = []                                               # not the announced frame: the stock is void
             # flow_next belongs to this frame only if it IS the announced tensor (same object, not written since): otherwise the
             # stored flow is dropped and the step computes its own (a caller that skips or reorders frames stays correct)
-            if self._have_flow and not promise.kept(self._announced, frame):
+            if not stocked and self._have_flow and not promise.kept(self._announced, frame):
                 self._have_flow = False
             self.frame.copy_(frame, non_blocking=True)
-        elif self._have_flow:
-            self._have_flow = False                                                # re-running the resident frame: not the announced one
-        ahead = self.lookahead and next_frame is not None
+        else:
+            self._stock = []
+            if self._have_flow:
+                self._have_flow = False                                            # re-running the resident frame: not the announced one
+        windowed = bool(self._stock) or bool(upcoming)
+        ahead = self.lookahead and next_frame is not None and not windowed
         self._announced = None
         if ahead:
             self.frame_next.copy_(next_frame, non_blocking=True)
@@ -120,4 +178,6 @@ class InferenceEngine:
                 self.graphs[key] = g
             self.graphs[key].replay()
         self._have_flow = ahead
+        if upcoming and not self._stock and self.lookahead:
+            self._refill(upcoming)
         return self.pre_gen
