@@ -331,17 +331,21 @@ def sub_inference(device, h=270, w=480, frames=120):
     from tecogan_amd.infer import InferenceEngine
     eng = InferenceEngine(16, h, w, device, torch.bfloat16)
     seq = torch.rand(8, 1, h, w, 3, device=device)
-    for i in range(3):                                # captures the hipGraphs (not timed frames; the reference's session
-        eng.step(seq[i], next_frame=seq[i + 1] if i < 2 else None)      # construction is not timed either): cold, steady, last
-    eng.reset()
+    K_ = eng.window = 16                              # lookahead window: FNet on the next 16 frame pairs as one batch
+    clip = [seq[i % 8] for i in range(frames)]        # the clip is known up front (lib/dataloader.py:30-60): the frames after i are announced
+
+    def run(n):
+        for i in range(n):
+            eng.step(clip[i], upcoming=clip[i + 1:i + 1 + K_])
+    run(2 * K_ + 2)                                   # captures the hipGraphs (not timed frames; the reference's session
+    eng.reset()                                       # construction is not timed either): cold / steady step, full window
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(frames):                           # the clip is known up front (lib/dataloader.py:30-60): frame i+1 is announced
-        eng.step(seq[i % 8], next_frame=seq[(i + 1) % 8] if i + 1 < frames else None)
+    run(frames)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"workload": "configs[4]: 4x inference %dx%d -> %dx%d, %d-frame stream, hipGraph step (next frame's FNet on a side stream), bf16, num_resblock=16"
-                        % (w, h, 4 * w, 4 * h, frames),
+    return {"workload": "configs[4]: 4x inference %dx%d -> %dx%d, %d-frame stream, hipGraph step (residual trunk as one persistent launch; "
+                        "FNet on the next %d frame pairs as one batch), bf16, num_resblock=16" % (w, h, 4 * w, 4 * h, frames, K_),
             "value": round(frames / dt, 2), "unit": "HR frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
             "frames": frames, "data": "synthetic uniform LR frames resident in HBM; HR frames stay on the device"}
 

@@ -178,15 +178,21 @@ def run_inference(FLAGS):
 def _inference_loop(FLAGS, data, eng, writer, image_dir, max_iter):
     srtime = 0.0
 
-    def upload(i):
-        return torch.from_numpy(data.inputs[i].copy()).float()[None].cuda() if i < max_iter else None
+    dev = {}
 
-    nxt = upload(0)
+    def upload(i):
+        if i < max_iter and i not in dev:
+            dev[i] = torch.from_numpy(data.inputs[i].copy()).float()[None].cuda()
+        return dev.get(i)
+
     for i in range(max_iter):
-        frame, nxt = nxt, upload(i + 1)           # the clip is known up front: the engine computes frame i+1's flow beside frame i
+        # the clip is known up front: the frames after i are announced, the engine runs FNet on a window of them as one batch
+        frame = upload(i)
+        ahead = [upload(j) for j in range(i + 1, min(i + 1 + eng.window, max_iter))]
+        dev.pop(i - 1, None)
         torch.cuda.synchronize()
         t0 = time.time()
-        out = eng.step(frame, next_frame=nxt)
+        out = eng.step(frame, upcoming=ahead)
         torch.cuda.synchronize()
         srtime += time.time() - t0
         if i >= 5:

@@ -59,7 +59,7 @@ class InferenceEngine:
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.use_graph, self.graphs = use_graph, {}
         # lookahead window: FNet on the next `window` frame pairs as ONE batch (step(frame, upcoming=[...]))
-        self.window = 8
+        self.window = 16
         self._win_in = None                                                        # [window + 1, B, h, w, 3]: resident frame + announced ones
         self._win_flows = None                                                     # [window, B, h', w', 2]
         self._stock = []                                                           # [(promise, index into _win_flows)] in arrival order
@@ -115,14 +115,15 @@ class InferenceEngine:
         self._win_in[0].copy_(self.frame)
         for i in range(k):
             self._win_in[i + 1].copy_(upcoming[i], non_blocking=True)
-        if not self.use_graph:
-            self._window_flows(k)
+        if not self.use_graph or k < self.window:
+            self._window_flows(k)                                                  # (a clip's last, shorter window: once per clip, eager)
         else:
             if k not in self._win_graphs:
                 self._window_flows(k)                                              # eager warm-up (allocations, weight copies)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # (thread-local capture mode: a caller's writer thread may be issuing its own copies meanwhile, main.py)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._window_flows(k)
                 self._win_graphs[k] = g
             self._win_graphs[k].replay()

@@ -87,6 +87,35 @@ def test_inference_frame_lookahead_is_bit_identical(act_dtype, use_graph):
         assert len(b.graphs) == 4 and len(a.graphs) == 1
 
 
+@pytest.mark.parametrize("act_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_inference_lookahead_window_is_bit_identical(act_dtype, use_graph):
+    """step(frame, upcoming=[...]): FNet on the next `window` frame pairs as ONE batch whenever the stock of flows is used up
+    (main.py:201-203: the flow depends on LR frames only; lib/dataloader.py:30-60: the loop holds the clip).  The same kernels on
+    the same operands per image -> every frame bit-identical to the plain stream; a frame that is not the announced memory (frame
+    6: a copy of equal values) voids the stock and the step computes its own flow; the last window is shorter."""
+    h, w, nres = 36, 45, 2
+    g = torch.Generator().manual_seed(11)
+    seq = [torch.rand(1, h, w, 3, generator=g).cuda() for _ in range(14)]
+    a = InferenceEngine(nres, h, w, "cuda", act_dtype, use_graph=use_graph)
+    b = InferenceEngine(nres, h, w, "cuda", act_dtype, use_graph=use_graph)
+    b.window = 4
+    stock = []
+    for i, f in enumerate(seq):
+        fa = a.step(f).clone()
+        fb = b.step(f.clone() if i == 6 else f, upcoming=seq[i + 1:])
+        stock.append(len(b._stock))
+        assert torch.equal(fa, fb), "frame %d" % i
+    assert stock == [4, 3, 2, 1, 4, 3, 4, 3, 2, 1, 3, 2, 1, 0]
+    b.reset()
+    b.step(seq[10], upcoming=seq[11:])
+    b.step(seq[11], upcoming=seq[12:])
+    assert len(b._stock) == 2
+    seq[12].add_(0.0)                                # an announced tensor written in place: the promise is void
+    b.step(seq[12], upcoming=seq[13:])               # (version counter moved) -> own flow, new window from here
+    assert len(b._stock) == 1
+
+
 def stream_parity(seq, h, w, nres, tag, tol=1e-3):
     """fp32 HIP stream vs the oracle on EVERY frame, per pixel: |a-b| <= tol * max(|b|, 1e-3 max|b|).  Damped xavier
     weights (params.damp_values): the regime of a trained generator, where the recurrence is well conditioned."""

@@ -1733,6 +1733,81 @@ def test_resblock_chain_rejects_what_it_does_not_cover():
         K.resblock_chain(0, xf, [w], None, [w], None, None, None, None, [torch.empty_like(xf)], K.resblock_chain_scratch(1, 4, 4, DEV))
 
 
+# ---- csrc/resblock_plane.hip: the residual trunk of an INFERENCE frame as ONE persistent launch, activations resident in LDS --------
+RP_SHAPES = [(1, 16, 32), (1, 48, 96), (1, 40, 70), (2, 33, 64), (1, 17, 33), (3, 5, 7), (1, 270, 480)]
+
+
+@pytest.mark.parametrize("nb", [16, 3, 1])
+@pytest.mark.parametrize("shape", RP_SHAPES)
+def test_resblock_plane_is_bit_identical_to_per_block_launches_and_matches_oracle(shape, nb):
+    """lib/frvsr.py:50-57,66-70 in the stateless forward (main.py:195-216).  ONE launch (tg_resblock_plane: 16x32-pixel tiles kept in
+    LDS across all blocks, the one-pixel ring from the neighbour workgroups after every conv) against nb x tg_resblock bit for bit --
+    launched three times on the same scratch (the epochs advance), both weight-prefetch variants, once in place (out = x) -- and
+    per block against the oracle at the tight bound (exact products, fp32 accumulation, one rounding) from the operand the kernels
+    read.  Shapes: one tile, 3 x 3 tiles, partial tiles in both directions, two images, one pixel past a tile, smaller than a tile,
+    and the 1080p frame of BASELINE configs[4] (255 tiles)."""
+    N, H, W = shape
+    if shape == (1, 270, 480) and nb == 3:
+        pytest.skip("the full frame runs with 16 blocks and with one")
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    x = bf(rnd(N, H, W, 64, seed=31))
+    ws = [bf(rnd(3, 3, 64, 64, seed=40 + i, scale=0.05)) for i in range(2 * nb)]
+    bs = [rnd(64, seed=80 + i, scale=0.2) for i in range(2 * nb)]
+    wt = lambda w: K.frag_order(w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16))      # noqa: E731
+    wf, bd, xd = [wt(w) for w in ws], [b.to(DEV) for b in bs], _dev_bf(x)
+    r_ref = [torch.empty_like(xd) for _ in range(nb)]
+    a_ref = [torch.empty_like(xd) for _ in range(nb)]
+    a = xd
+    for i in range(nb):
+        a = K.resblock(0, a, wf[2 * i], bd[2 * i], wf[2 * i + 1], bd[2 * i + 1], None, None, r_ref[i], a_ref[i], w_frag=True)
+    scratch = K.resblock_plane_scratch(N, H, W, DEV)
+    for rep in range(3):
+        o = K.resblock_plane(xd, wf[0::2], bd[0::2], wf[1::2], bd[1::2], torch.full_like(xd, 7.0), scratch, variant=rep & 1)
+        torch.cuda.synchronize()
+        assert int(scratch[2]) == 0, "a workgroup gave up waiting for a neighbour"
+        assert int(scratch[0]) == (rep + 1) * 2 * nb and int(scratch[1]) == 0          # epoch base advanced, arrivals reset
+        assert torch.equal(o.view(torch.int16), a_ref[-1].view(torch.int16)), "launch %d" % rep
+    xa = xd.clone()
+    K.resblock_plane(xa, wf[0::2], bd[0::2], wf[1::2], bd[1::2], xa, scratch)           # in place: every workgroup stages its tile first
+    torch.cuda.synchronize()
+    assert torch.equal(xa.view(torch.int16), a_ref[-1].view(torch.int16)), "in place"
+    if H * W <= 48 * 96:                                                                # (the oracle on the CPU: small shapes only)
+        a_k = x
+        for i in range(nb):
+            tight(r_ref[i], torch.relu(O.conv2(a_k, ws[2 * i], bs[2 * i], 1)), "block %d intermediate %s" % (i, shape))
+            tight(a_ref[i], a_k + O.conv2(r_ref[i].float().cpu(), ws[2 * i + 1], bs[2 * i + 1], 1), "block %d output %s" % (i, shape))
+            a_k = a_ref[i].float().cpu()
+
+
+def test_resblock_plane_beside_other_work_and_what_it_rejects():
+    """The launch needs every workgroup resident: it is refused (TG_EINVAL) when there are more 16x32 tiles than compute units, and
+    `resblock_plane_ok` keeps the engine on the per-block kernel below half a chip's worth of tiles.  Beside a GEMM on a second
+    stream (a workgroup becomes resident late) the result is still bit-identical, nobody gives up."""
+    assert K.resblock_plane_ok(1, 270, 480) and not K.resblock_plane_ok(1, 144, 180) and not K.resblock_plane_ok(2, 270, 480)
+    w = K.frag_order(_dev_bf(rnd(9, 64, 64, seed=1, scale=0.05)))
+    x = _dev_bf(rnd(2, 270, 480, 64, seed=2))
+    from tecogan_amd._lib import TecoHipError
+    with pytest.raises(TecoHipError, match="more tiles than compute units"):
+        K.resblock_plane(x, [w], None, [w], None, torch.empty_like(x), K.resblock_plane_scratch(2, 270, 480, DEV))
+    xf = rnd(1, 16, 32, 64, seed=2).to(DEV)
+    with pytest.raises(TecoHipError, match="bf16"):
+        K.resblock_plane(xf, [w], None, [w], None, torch.empty_like(xf), K.resblock_plane_scratch(1, 16, 32, DEV))
+    x = _dev_bf(rnd(1, 270, 480, 64, seed=3))
+    ws = [K.frag_order(_dev_bf(rnd(9, 64, 64, seed=10 + i, scale=0.05))) for i in range(8)]
+    a = x
+    for i in range(4):
+        a = K.resblock(0, a, ws[2 * i], None, ws[2 * i + 1], None, None, None, None, torch.empty_like(a), w_frag=True)
+    scratch = K.resblock_plane_scratch(1, 270, 480, DEV)
+    side, big = torch.cuda.Stream(), torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            big @ big
+        o = K.resblock_plane(x, ws[0::2], None, ws[1::2], None, torch.full_like(x, 7.0), scratch)
+        torch.cuda.synchronize()
+        assert int(scratch[2]) == 0 and torch.equal(o.view(torch.int16), a.view(torch.int16)), "launch %d beside a GEMM" % rep
+
+
+
 def test_resblock_rejects_what_it_does_not_cover():
     from tecogan_amd._lib import TecoHipError
     x = torch.zeros(1, 4, 4, 64, device=DEV)
