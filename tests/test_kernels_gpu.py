@@ -1958,6 +1958,32 @@ def test_hr_tail_outputs_are_optional_and_consistent(shape):
     assert torch.equal(st2, st)
 
 
+@pytest.mark.parametrize("shape", [(1, 540, 960), (1, 22, 36), (2, 40, 72), (1, 9, 17)])
+def test_hr_tail_tile_forms_are_bit_identical(shape, monkeypatch):
+    """The fused tail's two tile forms -- 4 x 8 input pixels per workgroup (latency regime: the training recurrence) and 8 x 16
+    (throughput regime: the 1080p inference frame, chosen from four rounds of such tiles per compute unit on) -- run the same
+    MFMAs in the same order per element: t2, frame and state bit for bit, at the 1080p shape and at shapes with partial tiles."""
+    N, h2, w2 = shape
+    h2, w2 = h2 - h2 % 2, w2 - w2 % 2
+    t1 = rnd(N, h2, w2, 64, seed=1).bfloat16().to(DEV)
+    w2t = rnd(9, 64, 64, seed=2, scale=0.06).bfloat16().to(DEV)
+    w3 = rnd(9, 3, 64, seed=4, scale=0.06).bfloat16().to(DEV)
+    bt, bo = rnd(64, seed=3, scale=0.1).to(DEV), rnd(3, seed=5, scale=0.1).to(DEV)
+    gen_in = rnd(N, h2 // 2, w2 // 2, 56, seed=6).bfloat16().to(DEV)
+    f2 = K.frag_order(w2t)
+    res = {}
+    for tile in ("4", "8"):
+        monkeypatch.setenv("TG_HR_TAIL_TILE", tile)
+        t2 = torch.full((N, 2 * h2, 2 * w2, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+        fr = torch.full((N, 2 * h2, 2 * w2, 3), 7.0, device=DEV)
+        st = torch.full_like(fr, 7.0)
+        K.hr_tail_train(t1, f2, bt, w3, bo, gen_in, t2, fr, st)
+        torch.cuda.synchronize()
+        res[tile] = (t2, fr, st)
+    for a, b, what in zip(res["4"], res["8"], ("t2", "frame", "state")):
+        assert torch.equal(a, b), "%s %s" % (what, shape)
+
+
 @pytest.mark.parametrize("mask", [False, True])
 @pytest.mark.parametrize("shape", [(4, 32, 32), (1, 5, 7), (2, 4, 8), (3, 9, 17), (4, 64, 64)])
 def test_deconv_latency_input_gradient_matches_autograd_and_the_generic_kernel(shape, mask):
