@@ -318,11 +318,15 @@ int tg_resblock_chain(int mode, const void* x, int nblocks, const void* const* w
  * advance from launch to launch; a captured launch replays); one scratch per stream.
  * TG_EINVAL when N * ceil(H/16) * ceil(W/32) exceeds the number of compute units (every workgroup must be resident: run
  * tg_resblock_c64_thr per block then).  Give-ups are counted in ((unsigned*)scratch)[2] (sticky).
+ * pre_x (nullable): the generator input [N,H,W,pre_cpad] bf16 (51 channels in 56-channel pixels, lib/frvsr.py:47-49) -- the
+ * input-stage conv + ReLU (lib/frvsr.py:60-63) then runs in the same launch in front of the first block: one more conv pass on the
+ * tile and one more hand-off; pre_w_frag its [tap][64][64] fragment-order copy (input channels zero-padded: tg_pack_weights_frag with
+ * Cin in the table), pre_b nullable; x is ignored then.
  * variant: 0 = default (weight prefetch distance 6 K steps); 1 = 9 steps. */
 int tg_resblock_plane_scratch_bytes(int N, int H, int W, int64_t* bytes);
 int tg_resblock_plane(const void* x, int nblocks, const void* const* w1, const float* const* b1, const void* const* w2,
-                      const float* const* b2, void* out, void* scratch, int N, int H, int W, int C, int dtype, int variant,
-                      void* stream);
+                      const float* const* b2, void* out, void* scratch, const void* pre_x, int pre_cpad, const void* pre_w_frag,
+                      const float* pre_b, int N, int H, int W, int C, int dtype, int variant, void* stream);
 /* Fragment-order bf16 copies of `count` 64 -> 64 3x3 weights (the residual-block convs of lib/frvsr.py:50-57) for tg_resblock:
  * copy[2 tap + kk][wave][lane][j] = W[tap][row = 16 wave + lane % 16][k = 32 kk + 8 (lane / 16) + j]; dst_t: row = output channel
  * (forward operand), dst_n: row = input channel (input-gradient operand).  tab (device): 3 x int64 per tensor -- offset of the

@@ -53,7 +53,7 @@ SIGNATURES = {
     "tg_resblock_chain_scratch_bytes": [_I, _I, _I, C.POINTER(C.c_int64)],
     "tg_resblock_chain": [_I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tg_resblock_plane_scratch_bytes": [_I, _I, _I, C.POINTER(C.c_int64)],
-    "tg_resblock_plane": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tg_resblock_plane": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tg_pack_weights_frag": [_P, _P, _P, _P, _I, _P],
     "tg_hr_tail_backward": [_P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tg_deconv_lat_forward": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -39,6 +39,10 @@ struct RpP {
   const float* b1[RP_MAXB];     // nullable
   const float* b2[RP_MAXB];     // nullable
   void* out;                    // [N,H,W,64] bf16: output of the last block
+  const void* pre_x;            // nullable: [N,H,W,pre_cpad] bf16 -- the generator input; the input-stage conv + ReLU (lib/frvsr.py:
+  const void* pre_w;            //   60-63) runs in this launch in front of the first block (x is ignored then); pre_w: fragment-order
+  const float* pre_b;           //   [tap][64][64-padded Cin] copy
+  int pre_cpad;
   unsigned* ctrl;               // [0] epoch base  [1] arrivals  [2] give-ups (sticky)
   unsigned long long* xccw;     // [tiles] {tag, XCC id} words
   void* gran;                   // granule rings P, S: 2 x 2 slots x [tiles] x RP_RING
@@ -84,7 +88,9 @@ __device__ __forceinline__ unsigned rp_cvt2(float a, float b) {
 __device__ __forceinline__ int rp_lds(int r, int c, int slot) { return (r * RP_PW + c) * 128 + ((slot ^ (((c >> 1) & 3) << 1)) << 4); }
 
 // D: prefetch distance of the weight stream in K steps (divides 18); L: LDS fragment look-ahead
-template <int D, int L>
+// PRE: the input-stage conv of generator_F in front of the first block: one more conv pass (generator input, staged into the M plane
+// with its channels zero-padded to 64, -> relu(conv + b) -> X) and one more hand-off (the ring of X)
+template <int D, int L, bool PRE = false>
 __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(18 % D == 0 && L >= 1 && L <= 16, "weight ring slots are reused across convs");
@@ -108,7 +114,9 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
     unsigned limit = p.spin_limit;
 
     // ---- the input plane: 612 positions x 8 slots = 4896 16-byte items, 10 per thread (outside the image: zeros) --------------
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.bytes, 0x00020000);
+    const int xpix = PRE ? p.pre_cpad * 2 : 128;          // bytes per pixel of the tensor staged first (PRE: the chunks beyond it are zeros)
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRE ? p.pre_x : p.x), 0,
+                                                       (int)((unsigned)(p.N * p.H * p.W) * (unsigned)xpix), 0x00020000);
     u32x4c xr[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -116,16 +124,17 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
       const int pos = item >> 3, slot = item & 7;
       const int r = pos / RP_PW, c = pos % RP_PW;
       const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-      const bool ok = item < RP_PH * RP_PW * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * 128 + slot * 16) : RC_OOB), 0, 0);
+      const bool ok = item < RP_PH * RP_PW * 8 && slot * 16 < xpix && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? (unsigned)(((n * p.H + gy) * p.W + gx) * xpix + slot * 16) : RC_OOB), 0, 0);
     }
 
     // ---- the weight stream: position g of a block: g < 18 K step g of conv_1, else step g - 18 of conv_2; 36 .. 53 = the next
     //      block's conv_1 (same registers: the slot of step s is re-requested for step s + D right after its last MFMA)
     auto rsrc_w = [&](const void* w) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, w ? 9 * 64 * 64 * 2 : 0, 0x00020000); };
     auto rsrc_b = [&](const float* q) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q), 0, q ? 256 : 0, 0x00020000); };
-    auto rsW1 = rsrc_w(p.w1[0]), rsW2 = rsrc_w(p.w2[0]);
-    auto rsW1n = rsrc_w(nb > 1 ? p.w1[1] : nullptr);
+    // (PRE: the input conv takes the place of a "second conv" in front of block 0: positions 18 .. 35, block 0's conv_1 behind it)
+    auto rsW1 = rsrc_w(PRE ? nullptr : p.w1[0]), rsW2 = rsrc_w(PRE ? p.pre_w : p.w2[0]);
+    auto rsW1n = rsrc_w(PRE ? p.w1[0] : (nb > 1 ? p.w1[1] : nullptr));
     u32x4c wq[D][2];
     const int wlane = ch * 2048 + lane * 16;             // this wave's two channel tiles: 2 ch, 2 ch + 1
 #define RP_WISSUE(g)                                                                                                           \
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
       else wq[(g) % D][j_] = __builtin_amdgcn_raw_buffer_load_b128(rsW1n, wlane + j_ * 1024, ((g) - 36) * 4096, 0);             \
     }                                                                                                                          \
   } while (0)
-    rc_static_for<0, D>([&](auto i) { RP_WISSUE(decltype(i)::value); });
+    rc_static_for<0, D>([&](auto i) { RP_WISSUE((PRE ? 18 : 0) + decltype(i)::value); });
 
     // ---- who is where: lanes 0 .. 7 of every wave read the XCC word of neighbour d = lane --------------------------------------
     //      d: 0 up, 1 down, 2 left, 3 right, 4 up-left, 5 up-right, 6 down-left, 7 down-right
@@ -169,41 +178,44 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
     }
     auto is_cross = [&](int d) { return ((cross >> d) & 1u) != 0u; };
 
-    // ---- the sweep items of this thread (4: top row, bottom row, a side column, a corner) -------------------------------------
-    unsigned goff[4];
-    int lpos[4];
-    {
+    // ---- the sweep: ALL 1600 items belong to the first four waves (7 per thread: 2 of the top row, 2 of the bottom row, one of each
+    //      side column, a corner), recomputed at every sweep (no registers held across the matrix phases).  The two waves of a SIMD
+    //      do not interleave -- the older one runs its MFMAs first (lesson 40) -- so waves 0..3 are through their conv and epilogue
+    //      thousands of cycles before waves 4..7 and poll in what would be barrier time, while the late waves go from their
+    //      epilogue straight to the barrier instead of starting a sweep of their own then (round trip + delivery off the critical path)
+    auto sweep_items = [&](unsigned (&goff)[7], int (&lpos)[7]) {
       auto item = [&](int k, int d, int src, int r, int c, int q) {
         const int t = nbtile(d);
         goff[k] = t >= 0 ? (unsigned)t * (unsigned)RP_RING + (unsigned)src + (is_cross(d) ? 2u * p.gslot : 0u) : RC_OOB;
         lpos[k] = rp_lds(r, c, q >> 1) + (q & 1) * 8;
       };
-      {
-        const int px = tid & 15, q = ((tid >> 6) & 3) * 4 + ((tid >> 4) & 3), c = 1 + ((tid >> 8) & 1) * 16 + px;
-        item(0, 0, RP_ROW_B + tid * 16, 0, c, q);          // the upper neighbour's bottom row, in the order it was stored
-        item(1, 1, RP_ROW_T + tid * 16, 17, c, q);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;                      // a row in the order it was stored: [half][ct][fg][px]
+        const int px = i & 15, q = ((i >> 6) & 3) * 4 + ((i >> 4) & 3), c = 1 + ((i >> 8) & 1) * 16 + px;
+        item(u, 0, RP_ROW_B + i * 16, 0, c, q);            // the upper neighbour's bottom row
+        item(2 + u, 1, RP_ROW_T + i * 16, 17, c, q);
       }
       {
         // a side column in the order it was stored: [wave][side][r][j][fg] (the left halo = the left neighbour's RIGHT side)
-        const int i = tid & 255, wv = i >> 5, row = 4 * (wv >> 1) + ((i >> 3) & 3), q = ((wv & 1) * 2 + ((i >> 2) & 1)) * 4 + (i & 3);
-        if (tid < 256) item(2, 2, RP_COL + wv * 1024 + 512 + (i & 31) * 16, row + 1, 0, q);
-        else item(2, 3, RP_COL + wv * 1024 + (i & 31) * 16, row + 1, 33, q);
+        const int i = tid, wv = i >> 5, row = 4 * (wv >> 1) + ((i >> 3) & 3), q = ((wv & 1) * 2 + ((i >> 2) & 1)) * 4 + (i & 3);
+        item(4, 2, RP_COL + wv * 1024 + 512 + (i & 31) * 16, row + 1, 0, q);
+        item(5, 3, RP_COL + wv * 1024 + (i & 31) * 16, row + 1, 33, q);
       }
       {
         const int cid = (tid >> 4) & 3, q = tid & 15;
         const int src = (cid < 2 ? RP_ROW_B : RP_ROW_T) + ((cid & 1) == 0 ? 4096 + 240 : 0) + (q >> 2) * 1024 + (q & 3) * 256;
-        item(3, 4 + cid, src, cid < 2 ? 0 : 17, (cid & 1) == 0 ? 0 : 33, q);
-        if (tid >= 64) goff[3] = RC_OOB;
+        item(6, 4 + cid, src, cid < 2 ? 0 : 17, (cid & 1) == 0 ? 0 : 33, q);
+        if (tid >= 64) goff[6] = RC_OOB;
       }
-    }
+    };
     // ---- what this lane publishes ----------------------------------------------------------------------------------------------
     // rows (waves of pq 0: the top row, pq 3: the bottom row): granule of pixel tile (row, half h), channel tile 2 ch + j at
     // rowbase + h * 4096 + j * 1024, straight from the epilogue registers (a store instruction = one contiguous KiB).
     // columns (every wave: 4 rows x 32 channels of the left and of the right column): the 8 lanes that hold them (frow 0 from the
     // h = 0 tiles, frow 15 from the h = 1 tiles) put the payload into the wave's 512-byte LDS staging area, all 64 lanes read it back
-    // in storage order and store ONE contiguous KiB.  (First form: 64-byte pieces straight from those lanes -- with PLAIN stores
-    // (ring P) a granule then reached a same-XCD reader TORN, new tags around an old payload, sporadically; only whole lines are
-    // written as a unit, the rule of lesson 34 again.)
+    // in storage order and store ONE contiguous KiB (whole lines: lesson 34; the first form stored 64-byte pieces straight from those
+    // lanes, and its wrong pixels -- first read as torn granules -- were the store-data hazard described at the row stores below).
     const bool rowpub = pq == 0 || pq == 3;
     const unsigned rowbase = (unsigned)b * RP_RING + (pq == 0 ? RP_ROW_T : RP_ROW_B) + ch * 2048 + lane * 16;
     bool rowS[2];
@@ -231,32 +243,34 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
     const int ea = rp_lds(4 * pq + 1, frow + 1, 4 * ch + (fg >> 1)) + (fg & 1) * 8;
     const int gyb = y0 + 4 * pq, gxb = x0 + frow;
 
-    // ---- stage the input plane, clear M ------------------------------------------------------------------------------------------
+    // ---- stage the input plane, clear the other one (PRE: the generator input goes to M, X starts as zeros) -----------------------
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       const int item = tid + k * 512;
       const int pos = item >> 3, slot = item & 7;
       if (item < RP_PH * RP_PW * 8) {
-        *reinterpret_cast<u32x4c*>(smem + rp_lds(pos / RP_PW, pos % RP_PW, slot)) = xr[k];
-        *reinterpret_cast<u32x4c*>(smem + RP_PLANE + item * 16) = u32x4c{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4c*>(smem + (PRE ? RP_PLANE : 0) + rp_lds(pos / RP_PW, pos % RP_PW, slot)) = xr[k];
+        *reinterpret_cast<u32x4c*>(smem + (PRE ? 0 : RP_PLANE) + item * 16) = u32x4c{0u, 0u, 0u, 0u};
       }
     }
     __syncthreads();
     if (p.prio) __builtin_amdgcn_s_setprio(3);
 
-    for (int k = 0; k < nb; ++k) {
-      const bool last = k + 1 >= nb;
-      const u32x4c bq1[2] = {__builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b1[k]), (ch * 32 + fg * 4) * 4, 0, 0),
-                             __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b1[k]), (ch * 32 + 16 + fg * 4) * 4, 0, 0)};
-      const u32x4c bq2[2] = {__builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b2[k]), (ch * 32 + fg * 4) * 4, 0, 0),
-                             __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(p.b2[k]), (ch * 32 + 16 + fg * 4) * 4, 0, 0)};
-
-      // one conv: SECOND = false: X -> relu(. + b1) -> M; true: M -> . + b2 + X (skip) -> X in place
-      auto conv = [&](auto second_tag) {
-        constexpr bool SECOND = decltype(second_tag)::value;
-        const unsigned char* src = smem + (SECOND ? RP_PLANE : 0);
-        unsigned char* dst = smem + (SECOND ? 0 : RP_PLANE);
-        constexpr int G0 = SECOND ? 18 : 0;
+    constexpr unsigned EB = PRE ? 1u : 0u;               // hand-offs in front of block 0
+    int k = 0;
+    bool last = false;
+    u32x4c bq1[2], bq2[2];
+    auto load_b = [&](u32x4c (&bq)[2], const float* b) {
+      bq[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(b), (ch * 32 + fg * 4) * 4, 0, 0);
+      bq[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b(b), (ch * 32 + 16 + fg * 4) * 4, 0, 0);
+    };
+    // one conv: MODE 0: X -> relu(. + b1) -> M; 1: M -> . + b2 + X (skip) -> X in place; 2 (PRE): M -> relu(. + pre_b) -> X
+    auto conv = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool SECOND = MODE == 1, FROM_M = MODE != 0;
+        const unsigned char* src = smem + (FROM_M ? RP_PLANE : 0);
+        unsigned char* dst = smem + (FROM_M ? 0 : RP_PLANE);
+        constexpr int G0 = FROM_M ? 18 : 0;
         RP_STAMP(k, SECOND ? 5 : 0);
         f32x4 acc[8][2];
 #pragma unroll
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
         //      first (the skip operands requested up front), then the publishes, then the LDS writes: what the neighbours wait for
         //      leaves as early as it can
         const bool pub = !(SECOND && last);
-        const unsigned e = 2u * (unsigned)k + (SECOND ? 1u : 0u);
+        const unsigned e = MODE == 2 ? 0u : EB + 2u * (unsigned)k + (SECOND ? 1u : 0u);
         const unsigned tag = epoch0 + e + 1u;
         const unsigned soff = (e & 1u) * p.gslot;
         float bv[2][4];
@@ -340,9 +354,13 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
               for (int j = 0; j < 2; ++j) {
                 const u32x2c ov = rr == 0 ? o[0][h][j] : o[3][h][j];
                 const u32x4c gr = u32x4c{ov.x, tag, ov.y, tag};
-                const unsigned off = rowbase + h * 4096 + j * 1024;
-                __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(rowS[h] ? off + sring : RC_OOB), (int)soff, RC_SC1);
-                __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)off, (int)soff, 0);
+                // (the slot offset goes into the VECTOR offset, soffset = 0: with an SGPR soffset hipcc leaves out the wait state
+                //  between a 16-byte store and the next write of its data registers -- LLVM's hazard recognizer holds that MUBUF
+                //  hazard not to exist then -- and on gfx950 the odd hand-offs (slot 1) then published granules whose last lanes
+                //  carried the NEXT granule's payload under the right tags: profiles/r06aj_trace_plane.txt, lesson 41)
+                const unsigned off = rowbase + h * 4096 + j * 1024 + soff;
+                __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(rowS[h] ? off + sring : RC_OOB), 0, RC_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)off, 0, 0);
               }
           }
           if (colsrc) {
@@ -354,8 +372,8 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
           __builtin_amdgcn_wave_barrier();                 // same-wave LDS operations are ordered; keep the compiler from mixing them
           const u32x2c oc = *reinterpret_cast<const u32x2c*>(stg + lane * 8);
           const u32x4c gr = u32x4c{oc.x, tag, oc.y, tag};
-          __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(colS ? colbase + sring : RC_OOB), (int)soff, RC_SC1);
-          __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)colbase, (int)soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(colS ? colbase + soff + sring : RC_OOB), 0, RC_SC1);
+          __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(colbase + soff), 0, 0);
           __builtin_amdgcn_wave_barrier();
         }
         RP_STAMP(k, SECOND ? 8 : 3);
@@ -367,17 +385,31 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
             for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x2c*>(elem(r, h, j)) = o[r][h][j];
         RP_STAMP(k, SECOND ? 9 : 4);
         // ---- hand-off: the ring of the destination plane from the neighbours' same conv ------------------------------------------
-        if (pub && limit) {
-          if (!rc_sweep<4, 0>(rsG, goff, lpos, dst, soff, tag, limit, nullptr)) {
+        if (pub && limit && wave < 4) {
+          unsigned goff[7];
+          int lpos[7];
+          sweep_items(goff, lpos);
+          if (!rc_sweep<7, 0>(rsG, goff, lpos, dst, soff, tag, limit, nullptr)) {
             limit = 0;
             if (lane == 0) __hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (p.prio) __builtin_amdgcn_s_setprio(3);
         }
         __syncthreads();
-      };
-      conv(std::false_type{});
-      conv(std::true_type{});
+    };
+    if constexpr (PRE) {
+      load_b(bq1, p.pre_b);
+      conv(std::integral_constant<int, 2>{});
+      rsW1 = rsW1n;
+      rsW2 = rsrc_w(p.w2[0]);
+      rsW1n = rsrc_w(nb > 1 ? p.w1[1] : nullptr);
+    }
+    for (k = 0; k < nb; ++k) {
+      last = k + 1 >= nb;
+      load_b(bq1, p.b1[k]);
+      load_b(bq2, p.b2[k]);
+      conv(std::integral_constant<int, 0>{});
+      conv(std::integral_constant<int, 1>{});
       RP_STAMP(k, 10);
       rsW1 = rsW1n;
       rsW2 = rsrc_w(last ? nullptr : p.w2[last ? 0 : k + 1]);
@@ -403,7 +435,7 @@ __global__ __launch_bounds__(512) void resblock_plane_kernel(RpP p) {
     const unsigned old = __hip_atomic_fetch_add(p.ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned)p.nwg - 1u) {
       __hip_atomic_store(p.ctrl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.ctrl, epoch0 + 2u * (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.ctrl, epoch0 + 2u * (unsigned)nb + (PRE ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -418,16 +450,20 @@ extern "C" int tg_resblock_plane_scratch_bytes(int N, int H, int W, int64_t* byt
 }
 
 extern "C" int tg_resblock_plane(const void* x, int nblocks, const void* const* w1, const float* const* b1, const void* const* w2,
-                                 const float* const* b2, void* out, void* scratch, int N, int H, int W, int C, int dtype, int variant,
-                                 void* stream) {
+                                 const float* const* b2, void* out, void* scratch, const void* pre_x, int pre_cpad, const void* pre_w_frag,
+                                 const float* pre_b, int N, int H, int W, int C, int dtype, int variant, void* stream) {
   TG_CHECK_ARG(dtype == TG_BF16 && C == 64, "bf16 tensors with 64 channels only");
   TG_CHECK_ARG(nblocks >= 1 && nblocks <= RP_MAXB, "1 .. 16 blocks per launch");
-  TG_CHECK_ARG(x && w1 && w2 && out && scratch && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
-  TG_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)scratch) & 15) == 0, "pointers must be 16-byte aligned");
+  TG_CHECK_ARG((x || pre_x) && w1 && w2 && out && scratch && N > 0 && H > 0 && W > 0, "null pointer / empty tensor");
+  TG_CHECK_ARG(!pre_x || (pre_w_frag && pre_cpad >= 8 && pre_cpad <= 64 && pre_cpad % 8 == 0),
+               "the input-stage conv in front of the trunk: fragment-order weights, 8 .. 64 padded input channels");
+  TG_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)scratch | (uintptr_t)pre_x | (uintptr_t)pre_w_frag) & 15) == 0,
+               "pointers must be 16-byte aligned");
   const int64_t bytes = (int64_t)N * H * W * 128;
   TG_CHECK_ARG(bytes < ((int64_t)1 << 31), "tensor too large for 32-bit buffer offsets");
   RpP p;
   p.x = x; p.out = out;
+  p.pre_x = pre_x; p.pre_w = pre_w_frag; p.pre_b = pre_b; p.pre_cpad = pre_cpad;
   for (int k = 0; k < RP_MAXB; ++k) {
     const bool on = k < nblocks;
     p.w1[k] = on ? w1[k] : nullptr; p.w2[k] = on ? w2[k] : nullptr;
@@ -453,25 +489,25 @@ extern "C" int tg_resblock_plane(const void* x, int nblocks, const void* const* 
   p.prio = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double px = (double)N * H * W;
-  const double fl = 2.0 * 2.0 * px * 64.0 * 576.0 * nblocks;
-  const double by = 2.0 * px * 128.0 + nblocks * 2.0 * 73728.0;
+  const double fl = 2.0 * 2.0 * px * 64.0 * 576.0 * nblocks + (pre_x ? 2.0 * px * 64.0 * 9.0 * pre_cpad : 0.0);
+  const double by = px * (128.0 + (pre_x ? 2.0 * pre_cpad : 128.0)) + (nblocks * 2.0 + (pre_x ? 1.0 : 0.0)) * 73728.0;
   constexpr int LDS = RP_LDS;
-  auto go = [&](auto dtag, auto ltag) {
+  auto go = [&](auto dtag, auto ltag, auto ptag) {
     constexpr int D = decltype(dtag)::value, L = decltype(ltag)::value;
-    auto kern = resblock_plane_kernel<D, L>;
+    constexpr bool PRE = decltype(ptag)::value;
+    auto kern = resblock_plane_kernel<D, L, PRE>;
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       attr_done = true;
     }
-    TG_LAUNCH("resblock_plane", fl, by, kern, dim3(p.nwg), dim3(512), LDS, st, p);
+    TG_LAUNCH(PRE ? "resblock_plane<in>" : "resblock_plane", fl, by, kern, dim3(p.nwg), dim3(512), LDS, st, p);
   };
   using I6 = std::integral_constant<int, 6>;
   using I8 = std::integral_constant<int, 8>;
   using I9 = std::integral_constant<int, 9>;
-  switch (variant) {
-    case 1: go(I9{}, I8{}); break;
-    default: go(I6{}, I8{}); break;
-  }
+  if (pre_x) go(I6{}, I8{}, std::true_type{});
+  else if (variant == 1) go(I9{}, I8{}, std::false_type{});
+  else go(I6{}, I8{}, std::false_type{});
   TG_CHECK_LAUNCH();
 }

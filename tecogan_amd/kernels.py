@@ -261,25 +261,30 @@ def resblock_plane_scratch(N, H, W, device):
 class PlaneArgs:
     """The per-block pointer arrays of one tg_resblock_plane call, built once (the tensors they point to are kept alive here)."""
 
-    def __init__(self, x, w1, b1, w2, b2, out, scratch, variant=0):
+    def __init__(self, x, w1, b1, w2, b2, out, scratch, variant=0, pre=None):
+        """pre: (generator input [N,H,W,Cpad], the input conv's fragment-order weights, bias) -- the input-stage conv runs in the same
+        launch in front of the first block; `x` may then be None."""
         nb = len(w1)
-        assert nb == len(w2) and 1 <= nb <= 16 and tuple(out.shape) == tuple(x.shape) and out.dtype == x.dtype
-        self.keep = (x, w1, b1, w2, b2, out, scratch)
+        assert nb == len(w2) and 1 <= nb <= 16 and out.shape[-1] == 64
+        assert (x is None and pre is not None and tuple(pre[0].shape[:3]) == tuple(out.shape[:3])) or (tuple(out.shape) == tuple(x.shape) and out.dtype == x.dtype)
+        self.keep = (x, w1, b1, w2, b2, out, scratch, pre)
         arr = lambda ts: None if ts is None else (C.c_void_p * nb)(*[None if t is None else _p(t) for t in ts])   # noqa: E731
         self.a = (arr(w1), arr(b1), arr(w2), arr(b2))
-        self.nb, self.variant, self.x, self.out, self.scratch = nb, variant, x, out, scratch
+        self.nb, self.variant, self.x, self.out, self.scratch, self.pre = nb, variant, x, out, scratch, pre
 
     def launch(self):
-        N, H, W, Cn = self.x.shape
+        N, H, W, Cn = self.out.shape
         w1, b1, w2, b2 = self.a
-        check(lib().tg_resblock_plane(_p(self.x), self.nb, w1, b1, w2, b2, _p(self.out), _p(self.scratch), N, H, W, Cn, dt(self.x),
+        px, pw, pb = self.pre if self.pre is not None else (None, None, None)
+        check(lib().tg_resblock_plane(_p(self.x), self.nb, w1, b1, w2, b2, _p(self.out), _p(self.scratch), _p(px),
+                                      px.shape[-1] if px is not None else 0, _p(pw), _p(pb), N, H, W, Cn, dt(self.out),
                                       self.variant, _stream()), "tg_resblock_plane")
         return self.out
 
 
-def resblock_plane(x, w1, b1, w2, b2, out, scratch, variant=0):
+def resblock_plane(x, w1, b1, w2, b2, out, scratch, variant=0, pre=None):
     """nb residual blocks of the stateless forward as ONE persistent launch (csrc/resblock_plane.hip); fragment-order weights."""
-    return PlaneArgs(x, w1, b1, w2, b2, out, scratch, variant).launch()
+    return PlaneArgs(x, w1, b1, w2, b2, out, scratch, variant, pre).launch()
 
 
 def conv3x3_c64_frag_ok(N, H, W):

@@ -177,6 +177,7 @@ class Generator:
         #                 unit at most and at least half the chip's worth of tiles (1080p output: 255 tiles); else fused_block
         self.resblock_plane = True
         self.plane_variant = 0
+        self.plane_input_conv = True   # ... with the input-stage conv in front of the first block, in the same launch
         self._plane_scratch = {}       # (N, H, W) -> exchange scratch, allocated (zeroed) on first use: in the eager warm-up run
         self.input_in_group = True     # the input conv's weight gradient as a narrower last group of the trunk's grouped launch
         self.resblock_lat = self.hr_fwd_lat = self.hr_bwd_lat = True
@@ -199,23 +200,31 @@ class Generator:
         state, main.py:207); with a state and out=False the [-1,1] frame itself is not written at all."""
         assert not keep, "training uses begin_sequence/forward_t"
         ps, p = self.ps, self.P
-        a = conv_fwd(ps, p + "input_stage/conv/Conv/weights", p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU)
+        win = p + "input_stage/conv/Conv/weights"
+        # (the trunk's launch can take the input-stage conv in front of its first block: decided before that conv is launched)
+        plane_in = (self.resblock_plane and self.plane_input_conv and self.ws_frag and ps.frag and x_in.dtype == torch.bfloat16
+                    and 1 <= self.nres <= 16 and K.resblock_plane_ok(*x_in.shape[:3]) and ps.packed_frag(win, True) is not None
+                    and x_in.shape[-1] % 8 == 0 and x_in.shape[-1] <= 64)
+        a = None if plane_in else conv_fwd(ps, win, p + "input_stage/conv/Conv/biases", x_in, 1, ACT_RELU)
         # (one launch per residual block -- r kept in LDS, both convs on MFMA -- was built and measured in round 3: parity
         #  green, 35.2 us per block against 35.3 us for these two launches: bound by 2-way-conflicted LDS fragment reads under
         #  the gfx950 ds_read_b128 lane grouping; numbers and cycle stamps in profiles/r03p_resblock_ws.txt, kernel deleted)
-        wsf = self.ws_frag and ps.frag and a.dtype == torch.bfloat16 and K.conv3x3_c64_frag_ok(*a.shape[:3])
-        bufs = [torch.empty_like(a), torch.empty_like(a)] if (wsf and self.fused_block) else None
-        plane = wsf and self.resblock_plane and 1 <= self.nres <= 16 and K.resblock_plane_ok(*a.shape[:3])
+        wsf = plane_in or (self.ws_frag and ps.frag and a.dtype == torch.bfloat16 and K.conv3x3_c64_frag_ok(*a.shape[:3]))
+        bufs = [torch.empty_like(a), torch.empty_like(a)] if (wsf and self.fused_block and not plane_in) else None
+        plane = plane_in or (wsf and self.resblock_plane and 1 <= self.nres <= 16 and K.resblock_plane_ok(*a.shape[:3]))
         if plane:
-            key = tuple(a.shape[:3])
+            key = tuple(x_in.shape[:3])
             if key not in self._plane_scratch:
                 assert not torch.cuda.is_current_stream_capturing(), "the exchange scratch is zeroed ONCE: allocate it in the eager warm-up"
-                self._plane_scratch[key] = K.resblock_plane_scratch(*key, a.device)
+                self._plane_scratch[key] = K.resblock_plane_scratch(*key, x_in.device)
             names = [p + "resblock_%d/" % i for i in range(1, self.nres + 1)]
+            pre = (x_in, ps.packed_frag(win, True), ps.view(p + "input_stage/conv/Conv/biases")) if plane_in else None
+            trunk = a if a is not None else torch.empty(*key, 64, device=x_in.device, dtype=x_in.dtype)
             a = K.resblock_plane(a, [ps.packed_frag(s + "conv_1/Conv/weights", True) for s in names],
                                  [ps.view(s + "conv_1/Conv/biases") for s in names],
                                  [ps.packed_frag(s + "conv_2/Conv/weights", True) for s in names],
-                                 [ps.view(s + "conv_2/Conv/biases") for s in names], a, self._plane_scratch[key], self.plane_variant)
+                                 [ps.view(s + "conv_2/Conv/biases") for s in names], trunk, self._plane_scratch[key], self.plane_variant,
+                                 pre=pre)
         for i in range(1, (0 if plane else self.nres) + 1):
             s = p + "resblock_%d/" % i
             if bufs is not None:

@@ -1779,6 +1779,49 @@ def test_resblock_plane_is_bit_identical_to_per_block_launches_and_matches_oracl
             a_k = a_ref[i].float().cpu()
 
 
+@pytest.mark.parametrize("nb", [16, 2])
+@pytest.mark.parametrize("shape", [(1, 48, 96), (1, 40, 70), (2, 33, 64), (1, 270, 480)])
+def test_resblock_plane_with_the_input_conv_in_front(shape, nb):
+    """lib/frvsr.py:60-70: net = relu(conv2(gen_inputs, 3, 64, 1)); then the residual blocks.  The input-stage conv inside the trunk's
+    launch (tg_resblock_plane pre_x: one more conv pass on the tile, its ring by one more hand-off).  a[0] is read out exactly through
+    a one-block launch with zero block weights (x + 0): held per element against the oracle (small shapes) and against the generic
+    launch; the trunk behind it bit for bit against nb x tg_resblock started from that a[0].  The generator input has 51 channels in
+    56-channel pixels; the fragment-order weight copy pads them to 64 with zeros."""
+    N, H, W = shape
+    bf = lambda t: t.bfloat16().float()                                   # noqa: E731
+    xin = torch.zeros(N, H, W, 56)
+    xin[..., :51] = bf(rnd(N, H, W, 51, seed=7))
+    w_in, b_in = bf(rnd(3, 3, 51, 64, seed=8, scale=0.08)), rnd(64, seed=9, scale=0.2)
+    ws = [bf(rnd(3, 3, 64, 64, seed=40 + i, scale=0.05)) for i in range(2 * nb)]
+    bs = [rnd(64, seed=80 + i, scale=0.2) for i in range(2 * nb)]
+    wt = lambda w: K.frag_order(w.permute(0, 1, 3, 2).reshape(9, 64, 64).contiguous().to(DEV, torch.bfloat16))      # noqa: E731
+    wf, bd = [wt(w) for w in ws], [b.to(DEV) for b in bs]
+    w64 = torch.zeros(3, 3, 64, 64)
+    w64[:, :, :51] = w_in
+    pre = (_dev_bf(xin), wt(w64), b_in.to(DEV))
+    scratch = K.resblock_plane_scratch(N, H, W, DEV)
+    new = lambda: torch.full((N, H, W, 64), 7.0, device=DEV, dtype=torch.bfloat16)      # noqa: E731
+    zw = torch.zeros(9 * 64 * 64, device=DEV, dtype=torch.bfloat16)
+    a0 = K.resblock_plane(None, [zw], None, [zw], None, new(), scratch, pre=pre)        # a[0] + conv(relu(conv(a[0], 0)), 0) = a[0]
+    torch.cuda.synchronize()
+    assert int(scratch[2]) == 0 and int(scratch[0]) == 3                                # one hand-off more than 2 per block
+    if H * W <= 48 * 96:
+        tight(a0, torch.relu(O.conv2(xin[..., :51], w_in, b_in, 1)), "a[0] inside the trunk launch %s" % (shape,))
+    w56 = torch.zeros(3, 3, 56, 64)
+    w56[:, :, :51] = w_in
+    d = K.conv_desc(N, H, W, 56, H, W, 64, 3, 3, 1, 1, 1, 0, TG_BF16, TG_BF16, ACT_RELU)
+    g0 = K.conv_forward(d, pre[0], w56.permute(0, 1, 3, 2).reshape(9, 64, 56).contiguous().to(DEV, torch.bfloat16), pre[2], None, None, new())
+    tight(a0, g0.float().cpu(), "a[0] against its own launch %s" % (shape,), rel=8e-3)   # (summation orders may differ: one bf16 step at most)
+    a = a0
+    for i in range(nb):
+        a = K.resblock(0, a, wf[2 * i], bd[2 * i], wf[2 * i + 1], bd[2 * i + 1], None, None, None, torch.empty_like(a), w_frag=True)
+    for rep in range(2):
+        o = K.resblock_plane(None, wf[0::2], bd[0::2], wf[1::2], bd[1::2], new(), scratch, pre=pre)
+        torch.cuda.synchronize()
+        assert int(scratch[2]) == 0 and int(scratch[0]) == 3 + (rep + 1) * (2 * nb + 1)
+        assert torch.equal(o.view(torch.int16), a.view(torch.int16)), "launch %d %s" % (rep, shape)
+
+
 def test_resblock_plane_beside_other_work_and_what_it_rejects():
     """The launch needs every workgroup resident: it is refused (TG_EINVAL) when there are more 16x32 tiles than compute units, and
     `resblock_plane_ok` keeps the engine on the per-block kernel below half a chip's worth of tiles.  Beside a GEMM on a second

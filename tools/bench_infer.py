@@ -12,11 +12,13 @@ ap.add_argument("--dtype", default="bf16"); ap.add_argument("--nres", type=int, 
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--no-lookahead", action="store_true")
 ap.add_argument("--window", type=int, default=0, help="lookahead window: FNet on the next K frame pairs as one batch (0: one-frame lookahead)")
+ap.add_argument("--no-plane-in", action="store_true", help="the input-stage conv as its own launch instead of inside tg_resblock_plane")
 ap.add_argument("--no-plane", action="store_true", help="the residual trunk as 16 tg_resblock_c64_thr launches instead of tg_resblock_plane")
 a = ap.parse_args()
 tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 eng = InferenceEngine(a.nres, a.h, a.w, "cuda", tdt, use_graph=not a.no_graph)
 eng.G.resblock_plane = not a.no_plane
+eng.G.plane_input_conv = not a.no_plane_in
 frames = torch.rand(8, 1, a.h, a.w, 3, device="cuda")
 nx = (lambda i: None) if (a.no_lookahead or a.window) else (lambda i: frames[(i + 1) % 8])
 eng.window = max(a.window, 1)
