@@ -484,8 +484,12 @@ __global__ __launch_bounds__(256, 2) void resblock_chain_kernel(RcP p) {
       const u32x2c o = rc_pack4(v);
       const unsigned tag = epoch0 + (unsigned)k + 1u;
       const u32x4c gr = u32x4c{o.x, tag, o.y, tag};
-      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last ? RC_OOB : pubS_off), (int)((unsigned)(2 + (k & 1)) * p.gslot), RC_SC1);
-      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last ? RC_OOB : pub_off), (int)((unsigned)(k & 1) * p.gslot), 0);
+      // (the slot offsets in the VECTOR offset, soffset = 0: behind a 16-byte store with an SGPR soffset hipcc leaves out the wait
+      //  state before the store's data registers are rewritten -- here the centre's v_cndmask one instruction later -- and gfx950
+      //  needs it: csrc/resblock_plane.hip, DESIGN lesson 41)
+      const unsigned slotP = (unsigned)(k & 1) * p.gslot, slotS = slotP + 2u * p.gslot;
+      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last || pubS_off == RC_OOB ? RC_OOB : pubS_off + slotS), 0, RC_SC1);
+      __builtin_amdgcn_raw_buffer_store_b128(gr, rsG, (int)(last || pub_off == RC_OOB ? RC_OOB : pub_off + slotP), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b64(o, rsO, (int)out_off, 0, 0);
       *reinterpret_cast<u32x2c*>(ctr) = out_ok ? o : u32x2c{0u, 0u};   // (a partial tile's pixels outside the image stay the next conv's zero padding)
     }
