@@ -45,8 +45,9 @@ def tg_name(k):
         return "conv4x4s2_bwd<%s>" % ",".join(t for t, on in (("res", m.group(1)), ("aux", m.group(2))) if on == "true")
     if "resblock_thr_kernel" in k:
         return "resblock_thr"
-    if "resblock_plane_kernel" in k:
-        return "resblock_plane"
+    m = re.search(r"resblock_plane_kernel<\d+, \d+(?:, (true|false))?>", k)      # <D, L, PRE>
+    if m:
+        return "resblock_plane<in>" if m.group(1) == "true" else "resblock_plane"
     m = re.search(r"conv3x3_c8_kernel<(\d+)>", k)
     if m:
         return "conv3x3_c8<%s>" % m.group(1)

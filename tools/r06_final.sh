@@ -9,7 +9,7 @@ cd /tmp
 B="python $R/bench.py --no-sub --no-roofline --no-cpu-baseline"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_z_teco -o teco -- $B --steps 20 --warmup 3 > $O/prof_z_teco.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_z_frvsr -o frvsr -- $B --steps 40 --warmup 3 --config frvsr > $O/prof_z_frvsr.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_z_inf -o inf -- python $R/tools/bench_infer.py > $O/prof_z_inf.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_z_inf -o inf -- python $R/tools/bench_infer.py --window 16 --warmup 40 --frames 80 > $O/prof_z_inf.log 2>&1
 for n in teco:tecogan frvsr:frvsr inf:infer1080p; do d=${n%%:*}; f=${n##*:}; db=$(find $O/prof_z_$d -name "*.db" | head -1); python $R/tools/prof_summary.py $db $O/r06_${f}_bf16_kernel_stats.txt 60; rm -rf $O/prof_z_$d; done
 head -12 $O/r06_tecogan_bf16_kernel_stats.txt | cut -c1-160
 P="$B --steps 2 --warmup 1 --no-graph"
