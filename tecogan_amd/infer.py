@@ -36,6 +36,7 @@ from . import kernels as K
 from . import promise
 from .nets import FNET_CPAD, GEN_CPAD, FNet, Generator
 from .params import ParamStore, fnet_spec, generator_spec, init_values
+from .streams import capture_guard
 
 
 class InferenceEngine:
@@ -123,7 +124,7 @@ class InferenceEngine:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 # (thread-local capture mode: a caller's writer thread may be issuing its own copies meanwhile, main.py)
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with capture_guard(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._window_flows(k)
                 self._win_graphs[k] = g
             self._win_graphs[k].replay()
@@ -174,7 +175,7 @@ class InferenceEngine:
                 self.pre_gen.copy_(keep[1])
                 self.flow_next.copy_(keep[2])
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with capture_guard(), torch.cuda.graph(g):
                     self._program(*key)
                 self.graphs[key] = g
             self.graphs[key].replay()

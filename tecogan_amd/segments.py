@@ -10,7 +10,7 @@ import time
 
 import torch
 
-from .streams import shared_stream
+from .streams import shared_stream, capture_guard
 
 from . import kernels as K
 
@@ -326,6 +326,10 @@ class SegmentRunner:
         # (a captured RCCL exchange that fails to capture is an ERROR: a silent eager fallback on an 8-GPU node would only
         #  show up as a slower number.  TG_EXCHANGE=eager selects the eager-split exchange explicitly.)
         self._segs = []
+        with capture_guard():
+            self._capture_program()
+
+    def _capture_program(self):
         if self.segmented:
             self._run_program("capture")
             self.exchange_nodes = {sg["name"]: sg["nodes"] for sg in self._segs if "nodes" in sg}

@@ -1,4 +1,7 @@
-"""Process-wide HIP streams shared by every engine (see shared_stream)."""
+"""Process-wide HIP streams shared by every engine (see shared_stream), and the capture guard."""
+import contextlib
+import gc
+
 import torch
 
 _STREAMS = {}
@@ -14,3 +17,20 @@ def shared_stream(dev, key):
     if k not in _STREAMS:
         _STREAMS[k] = torch.cuda.Stream(device=dev)
     return _STREAMS[k]
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """No cyclic garbage collection while a stream captures.  A dead reference cycle that holds a torch.cuda.CUDAGraph (an engine of
+    an earlier run whose closures or a caught exception's traceback kept it in a cycle) is freed whenever the collector happens to
+    run; inside a capture its destructor's hipGraphDestroy / hipGraphExecDestroy fails with "operation not permitted when stream is
+    capturing", the exception leaves a C++ destructor and the process aborts (met in the GPU suite: profiles/r06zz_pytest_gpu.log;
+    torch.cuda.graph no longer collects on entry by default).  Collect BEFORE, keep the collector off DURING the capture."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()

@@ -779,3 +779,43 @@ def test_comm_thread_preserves_segment_order_and_raises_a_worker_failure_once():
     assert all(th != "tecogan-comm" for _, _, _, th in log)
     assert [n for k, n, _, _ in log if k == "replay" and n.startswith("ar_")] == ["ar_d", "ar_g", "ar_f"]
     r.close()
+
+
+def test_capture_guard_keeps_the_cyclic_collector_off_during_a_capture():
+    """tecogan_amd/streams.capture_guard: a dead cycle holding a CUDAGraph must not be freed while a stream captures (its
+    destructor's hipGraphDestroy would abort the process): collected before, collector off inside, state restored -- also when
+    the body raises, also when the collector was already off."""
+    import gc
+    from tecogan_amd.streams import capture_guard
+
+    class Node:
+        freed = []
+
+        def __init__(self, tag):
+            self.me, self.tag = self, tag                     # a reference cycle: only the cyclic collector frees it
+
+        def __del__(self):
+            Node.freed.append(self.tag)
+
+    assert gc.isenabled()
+    Node("before")
+    with capture_guard():
+        assert "before" in Node.freed and not gc.isenabled()  # collected on entry
+        Node("inside")
+        for _ in range(200000):                               # allocation pressure that would trigger generation 0..2
+            [] + []
+        assert "inside" not in Node.freed
+    assert gc.isenabled()
+    gc.collect()
+    assert "inside" in Node.freed
+    with pytest.raises(ValueError):
+        with capture_guard():
+            raise ValueError("x")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with capture_guard():
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
