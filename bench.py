@@ -194,7 +194,7 @@ def roofline_entry(e, steps, dtype, pmc):
     us = e["total_us"] / max(e["calls"], 1)
     out = {"kernel": e["name"], "calls_per_step": e["calls"] / steps, "us_per_launch": round(us, 3),
            "us_per_step": round(e["total_us"] / steps, 1)}
-    c = pmc.get(e["name"], {})
+    c = pmc.get(e["name"]) or pmc.get(e["name"].replace(",in>", ">"), {})      # (tools/knames.py names the trunk launch with and without the input conv alike)
     if e["flops"] > 0:
         ach = e["flops"] / e["total_us"] / 1e6                          # TFLOP/s
         out.update(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[dtype], unit="TFLOP/s",

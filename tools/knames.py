@@ -20,9 +20,11 @@ def tg_name(k):
     if m:
         return {("false", "false"): "resblock_lat<fwd>", ("true", "false"): "resblock_lat<bwd>",
                 ("false", "true"): "resblock_lat<mask2>", ("true", "true"): "resblock_lat<bwd,mask2>"}[m.groups()]
-    m = re.search(r"hr_fwd_lat_kernel<(true|false)>", k)
+    m = re.search(r"hr_fwd_lat_kernel<(true|false)(?:, (\d+), (\d+))?>", k)      # <FUSE, HF_TI, HF_TJ>
     if m:
-        return "hr_fwd_lat<tail>" if m.group(1) == "true" else "hr_fwd_lat<deconv>"
+        if m.group(1) == "false":
+            return "hr_fwd_lat<deconv>"
+        return "hr_fwd_lat<tail>" if m.group(2) in (None, "4") else "hr_fwd_lat<tail,%sx%s>" % (m.group(2), m.group(3))
     m = re.search(r"deconv_bwd_lat_kernel<(true|false)>", k)
     if m:
         return "deconv_bwd_lat<aux>" if m.group(1) == "true" else "deconv_bwd_lat<>"
