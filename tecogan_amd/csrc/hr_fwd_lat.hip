@@ -54,6 +54,20 @@ __constant__ float kBicubicF[4][4] = {{0.f, 1.f, 0.f, 0.f},
                                       {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f}};
 }  // namespace
 
+#ifdef TG_HF_TRACE
+// [wave 0..3][stamp 0..15] of the middle workgroup of a fused-tail launch (tools: -DTG_HF_TRACE via tools/build_variant.py)
+__device__ unsigned long long tg_hf_trace_buf[4 * 16];
+#define HF_STAMP(i)                                                                                                   \
+  do {                                                                                                                \
+    if (FUSE && blockIdx.x == gridDim.x / 2 && lane == 0) tg_hf_trace_buf[wave * 16 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
+extern "C" int tg_debug_hf_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_hf_trace_buf), sizeof(unsigned long long) * 4 * 16);
+}
+#else
+#define HF_STAMP(i) do { } while (0)
+#endif
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void hf_static_for(F&& f) {
   if constexpr (I < N) {
@@ -79,6 +93,18 @@ __device__ __forceinline__ void hf_static_for(F&& f) {
 template <bool FUSE, int HF_TI, int HF_TJ>
 __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_lat_kernel(HfP p) {
   constexpr bool BIG = HF_TI * HF_TJ != 32;
+  // PIPE: the 8 x 16 form's code paths (LDS fragments a step ahead, the output conv's weights requested before the last phase, its
+  // pixel tiles as independent accumulators side by side) for the 4 x 8 form too (-DHF_PIPE).  Built from the cycle stamps of
+  // profiles/r06ao_trace_hf.txt -- a 4 x 8 workgroup's 19.6k cycles are a serial chain: 6.0k in the phases' MFMA loops (0.9k of MFMA:
+  // every step waits for its own LDS reads), 5.5k in the phase epilogues, 1.7k for the output conv's weights requested after the last
+  // phase, 4.0k in two 18-deep dependent MFMA chains -- and measured (r06ap_trace_hf.txt): the chain does not get shorter (a step of
+  // 2-3 MFMAs covers no LDS round trip, 18 weight loads cost their issue wherever they stand: 21.6k cycles), 1080p frame 0.527 ->
+  // 0.523 ms, TecoGAN step 7.247 -> 7.265 ms: off.  What stays: no store is issued for a t2 that is not kept (the inference frame).
+#ifdef HF_PIPE
+  constexpr bool PIPE = true;
+#else
+  constexpr bool PIPE = BIG;
+#endif
   // phase geometry: NA x NB pixels per phase; the fused tail also needs the one-pixel ring of t2 around its own block
   constexpr int NA = FUSE ? HF_TI + 1 : HF_TI, NB = FUSE ? HF_TJ + 1 : HF_TJ;
   constexpr int NPH = NA * NB, NT = (NPH + 15) / 16;                     // 45 -> 3 tiles | 32 -> 2 tiles
@@ -144,6 +170,7 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
     const int ti = tq % p.tiles_i, n = tq / p.tiles_i;
     const int i0 = ti * HF_TI, j0 = tj * HF_TJ;
 
+    HF_STAMP(0);
     // ---- global loads of the tile, in consumption order; none behind a branch ------------------------------------------------
     constexpr int XITEMS = RI * RJ * 8, XL = (XITEMS + 255) / 256;         // 480 | 360 16-byte items
     u32x4f xr[XL];
@@ -163,6 +190,7 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
       if (item < XITEMS) *reinterpret_cast<u32x4f*>(xs + (item >> 3) * HF_P + (item & 7) * 16) = xr[k];
     }
     __syncthreads();
+    HF_STAMP(1);
 
     // ---- the four phases: out[2a+py, 2b+px]; a = i0 + pa - (FUSE and py), b likewise; the input pixel of tap (ky, kx) is
     //      (a - (ky == 2), b - (kx == 2)) = region position (pa + 1 - (FUSE and py) - (ky == 2), ...) ------------------------------
@@ -173,7 +201,8 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (!BIG) {
+      if constexpr (FUSE && PIPE && ph == 3) load_w3();
+      if constexpr (!PIPE) {
         hf_static_for<0, ntap * 2>([&](auto qv) {
           constexpr int q = decltype(qv)::value, s = s0 + q, tap = hf_tap_order(s >> 1), kk = s & 1, ky = tap / 3, kx = tap % 3;
           constexpr int dy = 1 - (FUSE ? py : 0) - (ky == 2 ? 1 : 0), dx = 1 - (FUSE ? px : 0) - (kx == 2 ? 1 : 0);
@@ -215,6 +244,7 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
           }
         });
       }
+      HF_STAMP(2 + 2 * ph);
       // epilogue of the phase: bias, ReLU; own pixels -> HBM; fused tail: every pixel of the ring block -> LDS (zero outside the image)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -229,18 +259,21 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
         o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
         if (!inimg) o = u32x2f{0u, 0u};
         const bool own = inimg && Y >= 2 * i0 && Y < 2 * i0 + 2 * HF_TI && X >= 2 * j0 && X < 2 * j0 + 2 * HF_TJ;
-        __builtin_amdgcn_raw_buffer_store_b64(o, rsY, (int)(own ? (unsigned)(((n * Ho + Y) * Wo + X) * 128 + cbyte) : HF_OOB), 0, 0);
+        if (!FUSE || p.y != nullptr)                      // (the inference frame keeps no t2: no store issued at all)
+          __builtin_amdgcn_raw_buffer_store_b64(o, rsY, (int)(own ? (unsigned)(((n * Ho + Y) * Wo + X) * 128 + cbyte) : HF_OOB), 0, 0);
         if constexpr (FUSE) {
           const int pos = pok[t] ? (Y - (2 * i0 - 1)) * BW + X - (2 * j0 - 1) : BH * BW;      // (padding lanes: the dump position)
           *reinterpret_cast<u32x2f*>(bs + pos * HF_P + cbyte) = o;
         }
       }
+      HF_STAMP(3 + 2 * ph);
     });
     if constexpr (FUSE) {
       // ---- fused tail: output conv (64 -> 3) + bicubic_four(LR) skip + value range, as hr_tail.hip ----------------------------
-      load_w3();
+      if constexpr (!PIPE) load_w3();
       __syncthreads();                                   // the ring block is complete
-      if constexpr (!BIG) {
+      HF_STAMP(10);
+      if constexpr (!PIPE) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {                       // this wave's two rows of the own 8 x 16 block: lane frow = column
           const int yl = wave * 2 + g;                     // own row -> block row yl + 1, block column frow + 1
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
       } else {
         // this wave's pixel tiles of the own block (16 columns of a row each: lane frow = column), G at a time with independent
         // accumulators (4 x 8: two tiles, one after the other, as before)
-        constexpr int CGX = 2 * HF_TJ / 16, PT = 2 * HF_TI * CGX / 4, G = 4;
+        constexpr int CGX = 2 * HF_TJ / 16, PT = 2 * HF_TI * CGX / 4, G = PT < 4 ? PT : 4;
 #pragma unroll
         for (int g0 = 0; g0 < PT; g0 += G) {
           int yo[G], xo[G], xc[G], ycl[G];
@@ -375,6 +408,7 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
         }
       }
     }
+    HF_STAMP(11);
   }
 #undef HF_WISSUE
 #undef HF_WLOAD
