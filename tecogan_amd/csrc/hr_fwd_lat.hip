@@ -68,6 +68,13 @@ extern "C" int tg_debug_hf_trace(unsigned long long* out) {
 #define HF_STAMP(i) do { } while (0)
 #endif
 
+typedef float f32x2h __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2h __attribute__((ext_vector_type(2)));
+// two fp32 -> two bf16 in one v_cvt_pk_bf16_f32 (round to nearest even, as f2bf)
+__device__ __forceinline__ unsigned hf_cvt2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2h{a, b}, bf16x2h));
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void hf_static_for(F&& f) {
   if constexpr (I < N) {
@@ -93,13 +100,14 @@ __device__ __forceinline__ void hf_static_for(F&& f) {
 template <bool FUSE, int HF_TI, int HF_TJ>
 __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_lat_kernel(HfP p) {
   constexpr bool BIG = HF_TI * HF_TJ != 32;
-  // PIPE: the 8 x 16 form's code paths (LDS fragments a step ahead, the output conv's weights requested before the last phase, its
-  // pixel tiles as independent accumulators side by side) for the 4 x 8 form too (-DHF_PIPE).  Built from the cycle stamps of
-  // profiles/r06ao_trace_hf.txt -- a 4 x 8 workgroup's 19.6k cycles are a serial chain: 6.0k in the phases' MFMA loops (0.9k of MFMA:
-  // every step waits for its own LDS reads), 5.5k in the phase epilogues, 1.7k for the output conv's weights requested after the last
-  // phase, 4.0k in two 18-deep dependent MFMA chains -- and measured (r06ap_trace_hf.txt): the chain does not get shorter (a step of
-  // 2-3 MFMAs covers no LDS round trip, 18 weight loads cost their issue wherever they stand: 21.6k cycles), 1080p frame 0.527 ->
-  // 0.523 ms, TecoGAN step 7.247 -> 7.265 ms: off.  What stays: no store is issued for a t2 that is not kept (the inference frame).
+  // Round 6, from the cycle stamps of tools/trace_hf.py (profiles/r06ao_trace_hf.txt: a 4 x 8 workgroup's 19.6k cycles are a serial
+  // chain -- 6.0k in the phases' MFMA loops of which 0.9k are MFMA, 5.5k in the phase epilogues, 1.7k for the output conv's weights
+  // requested after the last phase, 4.0k in the output conv): the phases' LDS fragments are requested a step ahead, the phase
+  // epilogues take their positions and masks from registers filled while the region loads fly, the output conv runs its pixel tiles
+  // as independent MFMA chains side by side with the fragments in a register ring and its bicubic operands requested before the last
+  // phase, no store is issued for a t2 that is not kept.  Same MFMA order per element: bit-identical.  17.4k cycles
+  // (r06as_trace_hf.txt).  -DHF_PIPE also requests the output conv's weights before the last phase: measured neutral (18 loads cost
+  // their issue wherever they stand, r06ap_trace_hf.txt).
 #ifdef HF_PIPE
   constexpr bool PIPE = true;
 #else
@@ -184,6 +192,27 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
     }
     hf_static_for<0, HF_DIST>([&](auto i) { HF_WISSUE(decltype(i)::value); });
     __builtin_amdgcn_sched_barrier(0);
+    // ---- what the twelve phase epilogues need, once and while the region loads fly (round 6: the cycle stamps of
+    //      profiles/r06ao_trace_hf.txt put 5.5k of a workgroup's 19.6k cycles into these epilogues -- ~60 instructions of index
+    //      arithmetic and compares per pixel tile and phase).  Pixel (phase, tile t) of this lane: Y = 2 A + dyc, X = 2 B + dxc with
+    //      A = i0 + ppa[t], B = j0 + ppb[t] and dyc = -py (fused tail) / +py: lane masks per (t, py) and (t, px), the LDS and HBM
+    //      positions of phase (0, 0); the phase part of both is a constant
+    bool yok[NT][2], xok[NT][2], yown[NT][2], xown[NT][2];
+    int posb[FUSE ? NT : 1];
+    unsigned ybase[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int d = FUSE ? -q : q;
+        yok[t][q] = pok[t] && (unsigned)(2 * (i0 + ppa[t]) + d) < (unsigned)Ho;
+        xok[t][q] = (unsigned)(2 * (j0 + ppb[t]) + d) < (unsigned)Wo;
+        yown[t][q] = (unsigned)(2 * ppa[t] + d) < (unsigned)(2 * HF_TI);
+        xown[t][q] = (unsigned)(2 * ppb[t] + d) < (unsigned)(2 * HF_TJ);
+      }
+      ybase[t] = (unsigned)(((n * Ho + 2 * (i0 + ppa[t])) * Wo + 2 * (j0 + ppb[t])) * 128 + cbyte);
+      if constexpr (FUSE) posb[t] = ((2 * ppa[t] + 1) * BW + 2 * ppb[t] + 1) * HF_P + cbyte;
+    }
 #pragma unroll
     for (int k = 0; k < XL; ++k) {
       const int item = tid + k * 256;
@@ -194,30 +223,37 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
 
     // ---- the four phases: out[2a+py, 2b+px]; a = i0 + pa - (FUSE and py), b likewise; the input pixel of tap (ky, kx) is
     //      (a - (ky == 2), b - (kx == 2)) = region position (pa + 1 - (FUSE and py) - (ky == 2), ...) ------------------------------
+    // output conv: this wave's PT pixel tiles of the own block (16 columns of a row each: lane frow = column), G at a time.  Their
+    // bicubic operands (four 8-byte loads per lane and tile from the LR frame) are requested at the start of the LAST phase when all
+    // tiles are one group (the 4 x 8 form): ~3k cycles ahead of their use, in registers the first phases' weights have left
+    constexpr int CGX = 2 * HF_TJ / 16, PT = 2 * HF_TI * CGX / 4, G = PT < 4 ? PT : 4;
+    constexpr bool LQ_EARLY = FUSE && PT == G;
+    u32x2f lqe[LQ_EARLY ? G : 1][4];
+    auto lq_issue = [&](int u, u32x2f (&dst)[4]) {
+      // bicubic: 16-lane group fg gathers LR row clamp(yo / 4 - 1 + fg)
+      const int yl = u / CGX, xl = (u % CGX) * 16 + frow;
+      const int yc = min(2 * i0 + yl, Ho - 1), xcq = min(2 * j0 + xl, Wo - 1);
+      const int li = yc >> 2, lj = xcq >> 2;
+      const int ry = min(max(li + fg - 1, 0), h - 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rx = min(max(lj + k - 1, 0), w - 1);
+        dst[k] = __builtin_amdgcn_raw_buffer_load_b64(rsL, ((n * h + ry) * w + rx) * p.Cpad * 2, 0, 0);
+      }
+    };
     hf_static_for<0, 4>([&](auto phv) {
       constexpr int ph = decltype(phv)::value, py = ph >> 1, px = ph & 1;
+      if constexpr (LQ_EARLY && ph == 3) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) lq_issue(wave * PT + q, lqe[q]);
+      }
       constexpr int s0 = ph == 0 ? 0 : ph == 1 ? 8 : ph == 2 ? 12 : 16;       // first stream position of the phase
       constexpr int ntap = ph == 0 ? 4 : ph == 3 ? 1 : 2;
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (FUSE && PIPE && ph == 3) load_w3();
-      if constexpr (!PIPE) {
-        hf_static_for<0, ntap * 2>([&](auto qv) {
-          constexpr int q = decltype(qv)::value, s = s0 + q, tap = hf_tap_order(s >> 1), kk = s & 1, ky = tap / 3, kx = tap % 3;
-          constexpr int dy = 1 - (FUSE ? py : 0) - (ky == 2 ? 1 : 0), dx = 1 - (FUSE ? px : 0) - (kx == 2 ? 1 : 0);
-          HF_WISSUE(s + HF_DIST);
-          uint4 bf[NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            bf[t] = *reinterpret_cast<const uint4*>(xs + ((ppa[t] + dy) * RJ + ppb[t] + dx) * HF_P + kk * 64 + fg * 16);
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wB[s]), *reinterpret_cast<bf16x8*>(&bf[t]),
-                                                             acc[t], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      } else {
+      {
         auto xfrag = [&](auto qv, int t) {
           constexpr int q = decltype(qv)::value, s = s0 + q, tap = hf_tap_order(s >> 1), kk = s & 1, ky = tap / 3, kx = tap % 3;
           constexpr int dy = 1 - (FUSE ? py : 0) - (ky == 2 ? 1 : 0), dx = 1 - (FUSE ? px : 0) - (kx == 2 ? 1 : 0);
@@ -246,24 +282,25 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
       }
       HF_STAMP(2 + 2 * ph);
       // epilogue of the phase: bias, ReLU; own pixels -> HBM; fused tail: every pixel of the ring block -> LDS (zero outside the image)
+      constexpr int dyc = FUSE ? -py : py, dxc = FUSE ? -px : px;
+      const int ydelta = (dyc * Wo + dxc) * 128;                        // wave-uniform
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int a = i0 + ppa[t] - (FUSE ? py : 0), bcol = j0 + ppb[t] - (FUSE ? px : 0);
-        const int Y = 2 * a + py, X = 2 * bcol + px;
-        const bool inimg = pok[t] && (unsigned)Y < (unsigned)Ho && (unsigned)X < (unsigned)Wo;
+        const bool inimg = yok[t][py] && xok[t][px];
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][r] + bv[r], 0.f);
         u32x2f o;
-        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        o.x = hf_cvt2(v[0], v[1]);
+        o.y = hf_cvt2(v[2], v[3]);
         if (!inimg) o = u32x2f{0u, 0u};
-        const bool own = inimg && Y >= 2 * i0 && Y < 2 * i0 + 2 * HF_TI && X >= 2 * j0 && X < 2 * j0 + 2 * HF_TJ;
-        if (!FUSE || p.y != nullptr)                      // (the inference frame keeps no t2: no store issued at all)
-          __builtin_amdgcn_raw_buffer_store_b64(o, rsY, (int)(own ? (unsigned)(((n * Ho + Y) * Wo + X) * 128 + cbyte) : HF_OOB), 0, 0);
+        if (!FUSE || p.y != nullptr) {                    // (the inference frame keeps no t2: no store issued at all)
+          const bool own = inimg && yown[t][py] && xown[t][px];
+          __builtin_amdgcn_raw_buffer_store_b64(o, rsY, (int)(own ? ybase[t] + (unsigned)ydelta : HF_OOB), 0, 0);
+        }
         if constexpr (FUSE) {
-          const int pos = pok[t] ? (Y - (2 * i0 - 1)) * BW + X - (2 * j0 - 1) : BH * BW;      // (padding lanes: the dump position)
-          *reinterpret_cast<u32x2f*>(bs + pos * HF_P + cbyte) = o;
+          const int pos = pok[t] ? posb[t] + (dyc * BW + dxc) * HF_P : BH * BW * HF_P + cbyte;     // (padding lanes: the dump position)
+          *reinterpret_cast<u32x2f*>(bs + pos) = o;
         }
       }
       HF_STAMP(3 + 2 * ph);
@@ -273,63 +310,9 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
       if constexpr (!PIPE) load_w3();
       __syncthreads();                                   // the ring block is complete
       HF_STAMP(10);
-      if constexpr (!PIPE) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {                       // this wave's two rows of the own 8 x 16 block: lane frow = column
-          const int yl = wave * 2 + g;                     // own row -> block row yl + 1, block column frow + 1
-          // bicubic: 16-lane group fg gathers LR row clamp(yo / 4 - 1 + fg); the four loads are requested BEFORE the MFMA chain
-          const int yo = 2 * i0 + yl, xo = 2 * j0 + frow;
-          const bool mine = yo < Ho && xo < Wo;
-          const int yc = min(yo, Ho - 1), xc = min(xo, Wo - 1);
-          const int li = yc >> 2, lj = xc >> 2;
-          const int ry = min(max(li + fg - 1, 0), h - 1);
-          const float wy = kBicubicF[yc & 3][fg];
-          u32x2f lq[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int rx = min(max(lj + k - 1, 0), w - 1);
-            lq[k] = __builtin_amdgcn_raw_buffer_load_b64(rsL, ((n * h + ry) * w + rx) * p.Cpad * 2, 0, 0);
-          }
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          const unsigned char* Bf = bs + (yl * BW + frow) * HF_P + fg * 16;
-          constexpr int CH = 18;
-#pragma unroll
-          for (int c0 = 0; c0 < 18; c0 += CH) {
-            uint4 bfr[CH];
-#pragma unroll
-            for (int s = 0; s < CH; ++s)
-              bfr[s] = *reinterpret_cast<const uint4*>(Bf + ((((c0 + s) >> 1) / 3) * BW + ((c0 + s) >> 1) % 3) * HF_P + (s & 1) * 64);
-#pragma unroll
-            for (int s = 0; s < CH; ++s)
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w3f[c0 + s]), *reinterpret_cast<bf16x8*>(&bfr[s]), acc, 0, 0, 0);
-          }
-          // lanes fg == 0 hold channels 0..2 of pixel (yo, xo)
-          float part[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float wgt = wy * kBicubicF[xc & 3][k];
-            part[0] += wgt * __uint_as_float(lq[k].x << 16);
-            part[1] += wgt * __uint_as_float(lq[k].x & 0xffff0000u);
-            part[2] += wgt * __uint_as_float(lq[k].y << 16);
-          }
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            part[c] += __shfl_xor(part[c], 16, 64);
-            part[c] += __shfl_xor(part[c], 32, 64);
-          }
-          const bool st = fg == 0 && mine;
-          const unsigned off = st ? (unsigned)((((n * Ho + yo) * Wo + xo) * 3) * 4) : HF_OOB;
-          const float f0 = (acc[0] + b3[0] + part[0]) * 2.f - 1.f, f1 = (acc[1] + b3[1] + part[1]) * 2.f - 1.f,
-                      f2 = (acc[2] + b3[2] + part[2]) * 2.f - 1.f;
-          const u32x3f o = {__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2)};
-          __builtin_amdgcn_raw_buffer_store_b96(o, rsF, (int)off, 0, 0);
-          const u32x3f os = {__float_as_uint(f0 * 0.5f + 0.5f), __float_as_uint(f1 * 0.5f + 0.5f), __float_as_uint(f2 * 0.5f + 0.5f)};
-          __builtin_amdgcn_raw_buffer_store_b96(os, rsS, (int)off, 0, 0);
-        }
-      } else {
+      {
         // this wave's pixel tiles of the own block (16 columns of a row each: lane frow = column), G at a time with independent
-        // accumulators (4 x 8: two tiles, one after the other, as before)
-        constexpr int CGX = 2 * HF_TJ / 16, PT = 2 * HF_TI * CGX / 4, G = PT < 4 ? PT : 4;
+        // accumulators
 #pragma unroll
         for (int g0 = 0; g0 < PT; g0 += G) {
           int yo[G], xo[G], xc[G], ycl[G];
@@ -341,18 +324,16 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
           for (int q = 0; q < G; ++q) {
             const int u = wave * PT + g0 + q;
             const int yl = u / CGX, xl = (u % CGX) * 16 + frow;       // own pixel -> block row yl + 1, block column xl + 1
-            // bicubic: 16-lane group fg gathers LR row clamp(yo / 4 - 1 + fg); the four loads are requested BEFORE the MFMA chain
             yo[q] = 2 * i0 + yl; xo[q] = 2 * j0 + xl;
             mine[q] = yo[q] < Ho && xo[q] < Wo;
             const int yc = min(yo[q], Ho - 1);
             xc[q] = min(xo[q], Wo - 1); ycl[q] = yc;
-            const int li = yc >> 2, lj = xc[q] >> 2;
-            const int ry = min(max(li + fg - 1, 0), h - 1);
             wy[q] = kBicubicF[yc & 3][fg];
+            if constexpr (LQ_EARLY) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int rx = min(max(lj + k - 1, 0), w - 1);
-              lq[q][k] = __builtin_amdgcn_raw_buffer_load_b64(rsL, ((n * h + ry) * w + rx) * p.Cpad * 2, 0, 0);
+              for (int k = 0; k < 4; ++k) lq[q][k] = lqe[q][k];
+            } else {
+              lq_issue(u, lq[q]);
             }
             Bf[q] = bs + (yl * BW + xl) * HF_P + fg * 16;
           }
@@ -362,23 +343,24 @@ __global__ __launch_bounds__(256, (HF_TI * HF_TJ >= 128 ? 1 : 2)) void hr_fwd_la
           auto bfrag = [&](int s, int q) {
             return *reinterpret_cast<const uint4*>(Bf[q] + (((s >> 1) / 3) * BW + (s >> 1) % 3) * HF_P + (s & 1) * 64);
           };
-          uint4 cur[G], nxt[G];
+          // G independent 18-deep MFMA chains side by side, their LDS fragments LA steps ahead in a register ring (a step is G MFMAs
+          // of ~36 cycles each behind its predecessor: LA steps cover an LDS round trip; 64 registers for either form)
+          constexpr int LA = 4 / G;
+          uint4 fr[LA][G];
 #pragma unroll
-          for (int q = 0; q < G; ++q) cur[q] = bfrag(0, q);
+          for (int a = 0; a < LA; ++a)
+#pragma unroll
+            for (int q = 0; q < G; ++q) fr[a][q] = bfrag(a, q);
           hf_static_for<0, 18>([&](auto sv) {
             constexpr int s = decltype(sv)::value;
-            if constexpr (s + 1 < 18) {
-#pragma unroll
-              for (int q = 0; q < G; ++q) nxt[q] = bfrag(s + 1, q);
-            }
 #pragma unroll
             for (int q = 0; q < G; ++q)
-              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w3f[s]), *reinterpret_cast<bf16x8*>(&cur[q]), acc[q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (s + 1 < 18) {
+              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w3f[s]), *reinterpret_cast<bf16x8*>(&fr[s % LA][q]), acc[q], 0, 0, 0);
+            if constexpr (s + LA < 18) {
 #pragma unroll
-              for (int q = 0; q < G; ++q) cur[q] = nxt[q];
+              for (int q = 0; q < G; ++q) fr[s % LA][q] = bfrag(s + LA, q);
             }
+            __builtin_amdgcn_sched_barrier(0);
           });
 #pragma unroll
           for (int q = 0; q < G; ++q) {

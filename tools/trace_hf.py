@@ -13,7 +13,7 @@ from tecogan_amd import kernels as K  # noqa: E402
 from tools.microbench import graph_timeit  # noqa: E402
 
 DEV = "cuda"
-N, h2, w2 = 1, 540, 960
+N, h2, w2 = (4, 64, 64) if "--train" in sys.argv else (1, 540, 960)      # t1 of the training recurrence / of the 1080p frame
 t1 = torch.randn(N, h2, w2, 64, device=DEV).bfloat16()
 f2 = K.frag_order((torch.randn(9, 64, 64, device=DEV) * 0.06).bfloat16())
 w3 = (torch.randn(9, 3, 64, device=DEV) * 0.06).bfloat16()
@@ -23,7 +23,7 @@ st = torch.empty(N, 2 * h2, 2 * w2, 3, device=DEV)
 lib = C.CDLL(L.LIB_PATH)
 names = ["region load + barrier", "phase 0 MFMAs", "epilogue", "phase 1 MFMAs", "epilogue", "phase 2 MFMAs", "epilogue", "phase 3 MFMAs",
          "epilogue", "w3 + barrier", "output conv"]
-for tile in ("4", "8"):
+for tile in (("4",) if "--train" in sys.argv else ("4", "8")):
     os.environ["TG_HR_TAIL_TILE"] = tile
     us = graph_timeit(lambda: K.hr_tail_train(t1, f2, bt, w3, bo, gen_in, None, None, st), 10, 5)
     print("tile form %s x %s: %.1f us per launch" % ((("4", "8") if tile == "4" else ("8", "16")) + (us,)))
