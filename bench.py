@@ -135,7 +135,9 @@ def time_steps(eng, steps, warmup, fence):
     t1 = time.perf_counter()
     fence()
     HOST_ENQUEUE_MS[0] = (t1 - t0) / steps * 1e3
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    eng.check_handoffs()                  # (after the clock: a trunk launch that lost a workgroup makes the number invalid -- fail loudly)
+    return dt
 
 
 def exchange_timeline(eng, steps=6):
@@ -344,6 +346,7 @@ def sub_inference(device, h=270, w=480, frames=120):
     run(frames)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    eng.check_handoffs()
     return {"workload": "configs[4]: 4x inference %dx%d -> %dx%d, %d-frame stream, hipGraph step (residual trunk as one persistent launch; "
                         "FNet on the next %d frame pairs as one batch), bf16, num_resblock=16" % (w, h, 4 * w, 4 * h, frames, K_),
             "value": round(frames / dt, 2), "unit": "HR frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),

@@ -44,6 +44,7 @@ def save_checkpoint(eng, output_dir, step, avg=None):
     avg = (running averages of the loss slots, their update count): the reference's EMA shadow variables are graph variables
     and travel with its checkpoints, so the displayed averages continue after a resume instead of restarting from 0."""
     from tecogan_amd.checkpoint import save_bundle
+    eng.check_handoffs()                       # (never write weights trained through a trunk launch that lost a workgroup)
     path = os.path.join(output_dir, "model-%d" % step)
     torch.save({"variables": eng.ps.state_dict(), "adam_m": eng.ps.m.cpu(), "adam_v": eng.ps.v.cpu(),
                 "sched": eng.sched.cpu(), "global_step": step, "avg_raw": None if avg is None else avg[0].cpu(),
@@ -202,6 +203,7 @@ def _inference_loop(FLAGS, data, eng, writer, image_dir, max_iter):
             writer.submit(os.path.join(image_dir, "%s.%s" % (filename, FLAGS.output_ext)), out[0])
         else:   # first 5 frames: mirrored warm-up, timed but not saved (reference main.py:268-269)
             print("Warming up %d" % (5 - i))
+    eng.check_handoffs()                       # (a trunk launch that lost a workgroup would have written garbage frames: fail loudly)
     print("total time " + str(srtime) + ", frame number " + str(max_iter))
 
 

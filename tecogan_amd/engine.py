@@ -630,3 +630,11 @@ class TrainEngine(SegmentRunner, ExchangeMixin):
 
     def global_step(self):
         return int(self.sched[0].item())
+
+    def check_handoffs(self):
+        """Raise if a one-launch trunk lost a workgroup (see Generator.handoff_give_ups): called where the host synchronises anyway
+        (checkpoints, the end of a bench run)."""
+        n = self.G.handoff_give_ups()
+        if n:
+            raise RuntimeError("tg_resblock_chain: %d workgroup(s) gave up waiting for a neighbour (a launch did not get all its "
+                               "workgroups resident): results since are invalid" % n)

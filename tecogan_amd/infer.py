@@ -70,6 +70,13 @@ class InferenceEngine:
         """values: TF-variable-name -> tensor for the 'generator' and 'fnet' scopes (main.py:221-224)."""
         self.ps.load(values)
 
+    def check_handoffs(self):
+        """Raise if the one-launch trunk lost a workgroup (Generator.handoff_give_ups; synchronises): the end of a clip is the place."""
+        n = self.G.handoff_give_ups()
+        if n:
+            raise RuntimeError("tg_resblock_plane: %d workgroup(s) gave up waiting for a neighbour (a launch did not get all its "
+                               "workgroups resident): frames since are invalid" % n)
+
     def reset(self):
         self.pre_inputs.zero_()
         self.pre_gen.zero_()

@@ -325,6 +325,17 @@ class Generator:
         for c in ca:
             c.launch()
 
+    def handoff_give_ups(self):
+        """Workgroups of the one-launch trunks (csrc/resblock_chain.hip, resblock_plane.hip) that gave up waiting for a neighbour
+        since the scratch was allocated (sticky counters; reading them synchronises).  Non-zero means a launch could not get all
+        its workgroups resident within the spin bound and its result was garbage: callers check at natural sync points and raise."""
+        n = 0
+        if self.seq is not None and self.seq.get("chain_scratch") is not None:
+            n += int(self.seq["chain_scratch"][2])
+        for sc in self._plane_scratch.values():
+            n += int(sc[2])
+        return n
+
     def _chained(self):
         q = self.seq
         return (self._fused_blocks() and self.resblock_chain and self.nres >= 2 and self.ps.frag

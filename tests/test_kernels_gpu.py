@@ -1848,6 +1848,14 @@ def test_resblock_plane_beside_other_work_and_what_it_rejects():
         o = K.resblock_plane(x, ws[0::2], None, ws[1::2], None, torch.full_like(x, 7.0), scratch)
         torch.cuda.synchronize()
         assert int(scratch[2]) == 0 and torch.equal(o.view(torch.int16), a.view(torch.int16)), "launch %d beside a GEMM" % rep
+    # the sticky give-up counter is what the engines check (Generator.handoff_give_ups -> check_handoffs): a non-zero count raises
+    from tecogan_amd.infer import InferenceEngine
+    eng = InferenceEngine(1, 16, 32, DEV, torch.bfloat16, use_graph=False)
+    eng.G._plane_scratch[(1, 16, 32)] = K.resblock_plane_scratch(1, 16, 32, DEV)
+    eng.check_handoffs()
+    eng.G._plane_scratch[(1, 16, 32)][2] = 3
+    with pytest.raises(RuntimeError, match="3 workgroup"):
+        eng.check_handoffs()
 
 
 
